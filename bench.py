@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the YOLO-Nano hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full eval-mode forward (ShuffleNetV2 backbone + FPN/PAN neck + 3 heads + score head +
+per-class NMS, everything on the device through the C ABI `yn_infer`) over one synthetic batch that is
+already resident in HBM.  Workload = BASELINE.json configs[1]: YOLO-Nano-1.0x, 416x416, bs=32 per GPU,
+COCO 80-class head, fp32, thresholds = the model's eval defaults (conf 0.001 / nms 0.50,
+models/yolo_nano.py:13) so that NMS does real work on random weights.  Multi-GPU = independent image
+shards, one process per GPU, no data-path collective ("scaling": "weak": 32 images per GPU).
+
+Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline and cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--backbone", default="1.0x")
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--conf", type=float, default=0.001)
+    ap.add_argument("--nms", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--profile-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sd, anchors):
+    """The PyTorch-CPU port of the reference's eval path (oracle/torch_port.py) + the C oracle's postprocess,
+    timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as orc
+    from oracle.torch_port import TorchNet
+    from yolo_nano_amd import weights
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    orc.lib().yo_set_num_threads(cores)
+    net = TorchNet(sd, args.backbone, args.classes)
+    n = args.cpu_images
+    x = weights.make_input(n, args.size, seed=0)
+
+    def one():
+        heads = net.forward_raw(x)
+        k = 0
+        for b in range(n):
+            bbox, cls = net.score_head(heads, args.size, anchors, image=b)
+            k += len(orc.postprocess(bbox, cls, args.conf, args.nms)[1])
+        return k
+    one()                                                   # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 50):
+        one()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * reps / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d reps of a %d-image batch, %dx%d, torch-CPU network + C-oracle NMS, %.1f s" % (reps, n, args.size, args.size, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for the barrier / max-over-ranks
+
+    from yolo_nano_amd import arch, capi, weights
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
+    sd = weights.make_state_dict(args.backbone, args.classes)
+    B, S = args.batch, args.size
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        h = capi.Handle(S, args.classes, anchors, args.backbone, args.conf, args.nms, max_batch=B, device=dev, stream=stream)
+        h.load_state_dict(sd)
+        h.fold_bn()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        x = torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32)   # synthetic, resident in HBM
+        out = h.alloc_outputs(B)
+        counts_host = torch.empty((B,), dtype=torch.int32).pin_memory()
+        h.use_graph(not args.no_graph)
+
+        def step():
+            h.infer(x, out)
+            counts_host.copy_(out[4], non_blocking=True)
+
+        def sync_all():
+            stream.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kept = int(counts_host.sum().item())
+
+        # PCIe-inclusive variant (not `value`): also bring the kept rows of every image to the host
+        pcie = None
+        if rank == 0:
+            hb = torch.empty((B, h.N, 4), dtype=torch.float32).pin_memory()
+            n_pc = max(5, args.steps // 10)
+            stream.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_pc):
+                step()
+                stream.synchronize()
+                for b, k in enumerate(counts_host.tolist()):
+                    hb[b, :k].copy_(out[0][b, :k], non_blocking=True)
+            stream.synchronize()
+            pcie = B * n_pc / (time.perf_counter() - t1)
+
+        # ---- per-kernel durations measured live with HIP events on the launch stream --------------------
+        roof, kernels, pipeline = None, [], None
+        if rank == 0:
+            h.use_graph(False)
+            h.profile_enable(True)
+            agg = {}
+            for _ in range(args.profile_steps):
+                h.profile_enable(True)                 # resets the record list
+                h.infer(x, out)
+                stream.synchronize()
+                for layer, kern, ms, fl, by in h.profile_records():
+                    a = agg.setdefault(kern, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+                    a["ms"] += ms; a["launches"] += 1; a["flops"] += fl; a["bytes"] += by
+            h.profile_enable(False)
+            ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            tot_ms = sum(a["ms"] for a in agg.values())
+            for kern, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                n = a["launches"]
+                avg_ms = a["ms"] / n
+                ai = a["flops"] / max(a["bytes"], 1.0)
+                bound = "mfma" if ai > ridge else "hbm"
+                if bound == "mfma":
+                    ach, peak, unit = a["flops"] / n / (avg_ms * 1e-3) / 1e12, PEAK_F32_TFLOPS, "TFLOP/s"
+                else:
+                    ach, peak, unit = a["bytes"] / n / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+                kernels.append({"kernel": kern, "launches_per_step": n // args.profile_steps, "avg_us": round(avg_ms * 1e3, 2),
+                                "share": round(a["ms"] / tot_ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
+                                "unit": unit, "frac": round(ach / peak, 4)})
+            d = kernels[0]
+            roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                    "frac": d["frac"], "traffic": None, "avg_us": d["avg_us"], "share_of_step": d["share"]}
+            fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
+            by = sum(a["bytes"] for a in agg.values()) / args.profile_steps
+            floor_ms = max(fl / (PEAK_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3
+            pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
+                        "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
+
+        h.use_graph(False)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        if rank == 0:
+            line = {
+                "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
+                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1])"
+                                       % (args.backbone, S, S, B, args.classes),
+                           "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
+                           "parallelism": "image-sharded x%d, no collective" % world, "hipgraph": not args.no_graph,
+                           "detections_per_step_rank0": kept},
+                "roofline": roof,
+                "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
+                "pipeline": dict(pipeline or {}, frac_of_floor=round((pipeline["roofline_floor_ms"] / ms_per_step), 4) if pipeline else None),
+                "pcie_inclusive_images_per_s": round(pcie, 1) if pcie else None,
+                "kernels": kernels,
+            }
+            print(json.dumps(line), flush=True)
+        h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

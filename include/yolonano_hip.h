@@ -1,0 +1,152 @@
+/*
+ * yolonano_hip.h — C ABI of libyolonano_hip.so, the MI355X (gfx950) YOLO-Nano hot path.
+ *
+ * The reference (yjh0410/YOLO-Nano) has no FFI/plugin interface: its boundary is the Python
+ * surface of `YOLONano` (models/yolo_nano.py:12-376).  This header is the C boundary that sits
+ * directly under that surface; every entry point names the reference code it replaces.  The host
+ * shim `yolo_nano_amd.YOLONano` binds these with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every function returns 0 on success, non-zero on failure; yn_last_error(h) gives the text
+ *     (yn_last_error(NULL) for a failed yn_create).
+ *   - one handle = one device + one HIP stream; a handle is not thread-safe.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller; the handle owns only its
+ *     weights and its activation workspace.  Nothing here synchronises the stream unless noted.
+ *   - activations cross this boundary as float32.  Raw head tensors are NHWC
+ *     [B, H, W, A*(1+C+4)] — the layout models/yolo_nano.py:312 permutes to before splitting.
+ *   - candidate index  n = off_s + (y*W_s + x)*A + a ,  scales in order stride 8, 16, 32
+ *     (models/yolo_nano.py:308-330);  N = A * sum_s (S/stride_s)^2.
+ */
+#ifndef YOLONANO_HIP_H
+#define YOLONANO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yn_handle yn_handle;
+
+enum { YN_BACKBONE_0_5X = 0, YN_BACKBONE_1_0X = 1, YN_BACKBONE_1_5X = 2, YN_BACKBONE_2_0X = 3 };
+enum { YN_ACT_NONE = 0, YN_ACT_RELU = 1, YN_ACT_LEAKY = 2 };
+
+/* Mirrors YOLONano.__init__(device, input_size, num_classes, trainable, conf_thresh, nms_thresh,
+ * anchor_size, backbone, diou_nms)  — models/yolo_nano.py:13-27. */
+typedef struct yn_config {
+    int   input_size;      /* S, multiple of 32 */
+    int   num_classes;     /* C */
+    int   num_anchors;     /* A per scale (3) */
+    float anchors[18];     /* [3 scales][A][w,h] in input pixels (data/config.py:11-17) */
+    int   backbone;        /* YN_BACKBONE_* (backbone/shufflenetv2.py:95-102) */
+    float conf_thresh;     /* models/yolo_nano.py:19 */
+    float nms_thresh;      /* models/yolo_nano.py:20 */
+    int   diou_nms;        /* models/yolo_nano.py:21 */
+    int   max_batch;       /* workspace is sized for this many images at input_size */
+    int   device;          /* HIP device ordinal */
+    void* stream;          /* hipStream_t; NULL = default stream */
+} yn_config;
+
+/* ---- lifetime / configuration -------------------------------------------------------------- */
+int  yn_abi_version(void);
+int  yn_create(const yn_config* cfg, yn_handle** out);          /* YOLONano.__init__            :13  */
+void yn_destroy(yn_handle* h);
+const char* yn_last_error(yn_handle* h);
+int  yn_set_grid(yn_handle* h, int input_size);                 /* YOLONano.set_grid            :115 */
+int  yn_set_stream(yn_handle* h, void* stream);
+int  yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int diou_nms);
+int  yn_num_predictions(yn_handle* h);                          /* N for the current grid            */
+int  yn_use_graph(yn_handle* h, int enable);                    /* hipGraph-capture yn_infer/forward */
+int  yn_synchronize(yn_handle* h);
+
+/* ---- weights ------------------------------------------------------------------------------- */
+/* nn.Module.load_state_dict (eval.py:127, benchmark.py:132): one call per state-dict entry, using
+ * the reference's 469 key names; `host_ptr` float32 (int64 for num_batches_tracked, ignored).   */
+int  yn_load_param(yn_handle* h, const char* state_dict_key, const void* host_ptr,
+                   const int64_t* shape, int ndim);
+/* Same, source already in HBM (e.g. a torch Parameter's data_ptr()). */
+int  yn_load_param_dev(yn_handle* h, const char* state_dict_key, const void* dev_ptr,
+                       const int64_t* shape, int ndim);
+/* utils/fuse_conv_bn.py:6-53 — fold every BN into its conv and repack for the kernels.  Must be
+ * called after loading parameters and before inference.  A conv whose BN keys were never loaded
+ * is taken as already folded (the state dict of a model that went through fuse_conv_bn()).      */
+int  yn_fold_bn(yn_handle* h);
+/* Read back the folded weight/bias of one conv in the reference layout [Cout,Cin/g,k,k] / [Cout]
+ * (parity check of utils/fuse_conv_bn.py:17-21). `conv_key` e.g. "smooth_1.convs.0".           */
+int  yn_get_folded(yn_handle* h, const char* conv_key, float* host_weight, float* host_bias);
+
+/* ---- the network --------------------------------------------------------------------------- */
+/* YOLONano.forward lines 284-301: backbone, FPN+PAN neck, three heads.  x_dev: NCHW
+ * [B,3,S,S] float32.  Outputs: NHWC raw head tensors [B,S/8,S/8,A(5+C)], [B,S/16,..], [B,S/32,..]. */
+int  yn_forward_raw(yn_handle* h, const float* x_dev, int B,
+                    float* head_s8_dev, float* head_s16_dev, float* head_s32_dev);
+
+/* Lines 308-330 + 362-367 for EVERY image of the batch (the reference only finishes image 0):
+ * all_bbox [B,N,4] = clamp(decode_boxes/S, 0, 1); all_class [B,N,C] = softmax(cls)*sigmoid(obj). */
+int  yn_score_full(yn_handle* h, const float* head_s8_dev, const float* head_s16_dev,
+                   const float* head_s32_dev, int B, float* all_bbox_dev, float* all_class_dev);
+
+/* YOLONano.decode_boxes :139-156 — txtytwth [B, sum HW, A, 4] -> xyxy pixels [B, N, 4]. */
+int  yn_decode_boxes(yn_handle* h, const float* txtytwth_dev, int B, float* xyxy_dev);
+
+/* YOLONano.create_grid :86-112 — host arrays grid [HWtot,2], stride [HWtot,A,2], anchors [HWtot,A,2]. */
+int  yn_create_grid(yn_handle* h, int input_size, float* grid_host, float* stride_host, float* anchor_host);
+
+/* ---- post-processing ----------------------------------------------------------------------- */
+/* YOLONano.nms :159-188 / diou_nms :191-242 — one class.  dets [n,4] xyxy, scores [n]; writes the
+ * kept indices in pick order (descending score; equal scores: higher index first) and the count. */
+int  yn_nms(yn_handle* h, const float* dets_dev, const float* scores_dev, int n, float nms_thresh,
+            int diou, int32_t* keep_dev, int32_t* count_dev);
+
+/* YOLONano.postprocess :245-279, batched: all_local [B,N,4], all_conf [B,N,C] ->
+ * per image b: count[b] = K_b and, in ascending candidate order, out_boxes[b,0:K_b,4],
+ * out_scores[b,0:K_b], out_cls[b,0:K_b], out_index[b,0:K_b] (candidate index; may be NULL).
+ * Output buffers have capacity N per image. */
+int  yn_postprocess(yn_handle* h, const float* all_local_dev, const float* all_conf_dev, int B, int N, int C,
+                    float* out_boxes_dev, float* out_scores_dev, int32_t* out_cls_dev,
+                    int32_t* out_index_dev, int32_t* count_dev);
+
+/* The whole eval-mode YOLONano.forward :282-376 for a batch: network + score head + per-class NMS,
+ * all on device, no host round trip.  Outputs as yn_postprocess. */
+int  yn_infer(yn_handle* h, const float* x_dev, int B,
+              float* out_boxes_dev, float* out_scores_dev, int32_t* out_cls_dev,
+              int32_t* out_index_dev, int32_t* count_dev);
+
+/* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
+/* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],
+ * dense [Cout,Cin,3,3]; bias [Cout] or NULL. */
+int  yn_op_dwconv3x3(yn_handle* h, const float* x, int B, int H, int W, int C, int stride,
+                     const float* w, const float* bias, int act, float* y);
+int  yn_op_pwconv(yn_handle* h, const float* x, int B, int H, int W, int Cin, int Cout,
+                  const float* w, const float* bias, int act, float* y);
+/* x2/resample: 0 none, 1 add nearest-up2 of x2 [B,H/2,W/2,Cin], 2 add nearest-down of x2 [B,2H,2W,Cin]
+ * (models/yolo_nano.py:291-296 fused into the conv's prologue).  Cin must be a multiple of 32. */
+int  yn_op_conv3x3(yn_handle* h, const float* x, const float* x2, int resample, int B, int H, int W,
+                   int Cin, int Cout, const float* w, const float* bias, int act, float* y);
+/* stem: x NCHW [B,3,H,W] -> y NHWC [B,Ho,Wo,Cout], 3x3 stride 2 pad 1 (backbone/shufflenetv2.py:109) */
+int  yn_op_stem(yn_handle* h, const float* x_nchw, int B, int H, int W, int Cout,
+                const float* w, const float* bias, int act, float* y);
+int  yn_op_maxpool3x3s2(yn_handle* h, const float* x, int B, int H, int W, int C, float* y);
+/* ShuffleV2Block (backbone/shufflenetv2.py:31-78), weights taken from the handle's loaded params:
+ * block = "backbone.stage2.1" etc.  x [B,H,W,Cin] -> y [B,H/stride,W/stride,Cout]. */
+int  yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, int H, int W, float* y);
+/* NCHW <-> NHWC helpers for the tests and the host shim */
+int  yn_op_nchw_to_nhwc(yn_handle* h, const float* x, int B, int C, int H, int W, float* y);
+int  yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W, float* y);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* When enabled, every kernel launch of yn_forward_raw / yn_infer is bracketed by a pair of HIP
+ * events recorded on the handle's stream (graph replay is bypassed while enabled).  After the
+ * call, yn_profile_get(i) returns the launch's layer name, the kernel symbol, its measured duration and its
+ * ALGORITHMIC flops / bytes (each conv reads its input once and writes its output once, weights
+ * once — DESIGN.md §Measurement).  bench.py builds its `roofline` block from these. */
+int  yn_profile_enable(yn_handle* h, int enable);
+int  yn_profile_count(yn_handle* h);
+int  yn_profile_get(yn_handle* h, int i, char* name, int name_cap, char* kernel, int kernel_cap,
+                    float* ms, double* alg_flops, double* alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLONANO_HIP_H */

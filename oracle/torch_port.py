@@ -1,0 +1,94 @@
+"""PyTorch-CPU restatement of the reference's eval-mode network.  TEST INFRASTRUCTURE ONLY.
+
+Same role and same restrictions as oracle.py (only tests/, smoke() and bench.py's cpu_baseline leg
+import it).  It exists because the reference itself runs on torch's CPU kernels: timing THIS port
+(all host cores) is the honest CPU baseline for bench.py (`cpu_baseline.kind = "port"`), and it
+cross-checks the plain-C oracle.  Wiring follows models/yolo_nano.py:282-301 and
+backbone/shufflenetv2.py:69-78,157-167; the BN folding is utils/fuse_conv_bn.py:17-21.
+Pinned against tests/golden in tests/test_oracle_golden.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from yolo_nano_amd import arch
+
+
+class TorchNet:
+    def __init__(self, state_dict, backbone="1.0x", num_classes=20, num_anchors=3):
+        self.C, self.A, self.backbone = num_classes, num_anchors, backbone
+        sd = {k: torch.as_tensor(np.asarray(v)) for k, v in state_dict.items()}
+        self.specs = {s.name: s for s in arch.conv_specs(backbone, num_classes, num_anchors)}
+        self.wb = {}
+        for s in self.specs.values():
+            w = sd[s.conv + ".weight"].float()
+            b = sd.get(s.conv + ".bias")
+            if s.bn is not None and (s.bn + ".weight") in sd:
+                f = sd[s.bn + ".weight"] / torch.sqrt(sd[s.bn + ".running_var"] + arch.BN_EPS)
+                b0 = b if b is not None else torch.zeros_like(f)
+                w = w * f.reshape(-1, 1, 1, 1)
+                b = (b0 - sd[s.bn + ".running_mean"]) * f + sd[s.bn + ".bias"]
+            self.wb[s.name] = (w.contiguous(), b.contiguous())
+
+    def conv(self, name, x):
+        s = self.specs[name]
+        w, b = self.wb[name]
+        y = F.conv2d(x, w, b, stride=s.stride, padding=0 if s.kind == "pw" else 1, groups=s.cout if s.kind == "dw3" else 1)
+        if s.act == arch.ACT_RELU:
+            return F.relu_(y)
+        if s.act == arch.ACT_LEAKY:
+            return F.leaky_relu_(y, 0.1)
+        return y
+
+    def block(self, p, x, stride):
+        if stride == 1:
+            x1, x2 = x.chunk(2, dim=1)
+            out = torch.cat((x1, self.conv(p + ".b2.pw2", self.conv(p + ".b2.dw", self.conv(p + ".b2.pw1", x2)))), 1)
+        else:
+            b1 = self.conv(p + ".b1.pw", self.conv(p + ".b1.dw", x))
+            b2 = self.conv(p + ".b2.pw2", self.conv(p + ".b2.dw", self.conv(p + ".b2.pw1", x)))
+            out = torch.cat((b1, b2), 1)
+        B, C, H, W = out.shape
+        return out.view(B, 2, C // 2, H, W).transpose(1, 2).contiguous().view(B, C, H, W)
+
+    @torch.no_grad()
+    def forward_raw(self, x):
+        x = torch.as_tensor(x).float()
+        x = F.max_pool2d(self.conv("stem", x), 3, 2, 1)
+        feats = []
+        for si, rep in enumerate(arch.STAGE_REPEATS):
+            for bi in range(rep):
+                x = self.block("backbone.stage%d.%d" % (si + 2, bi), x, 2 if bi == 0 else 1)
+            feats.append(x)
+        p3, p4, p5 = (self.conv("conv1x1_%d" % i, f) for i, f in enumerate(feats))
+        p4 = self.conv("smooth_0", p4 + F.interpolate(p5, scale_factor=2.0))
+        p3 = self.conv("smooth_1", p3 + F.interpolate(p4, scale_factor=2.0))
+        p4 = self.conv("smooth_2", p4 + F.interpolate(p3, scale_factor=0.5))
+        p5 = self.conv("smooth_3", p5 + F.interpolate(p4, scale_factor=0.5))
+        outs = []
+        for h, p in ((1, p3), (2, p4), (3, p5)):
+            for j in range(5):
+                p = self.conv("head_det_%d.%d" % (h, j), p)
+            outs.append(p)
+        return outs
+
+    @torch.no_grad()
+    def score_head(self, heads, S, anchors, image=0):
+        """models/yolo_nano.py:308-330,362-367 for one image -> numpy (all_bbox [N,4], all_class [N,C])"""
+        A, C = self.A, self.C
+        anc = torch.tensor(anchors, dtype=torch.float32).view(3, A, 2)
+        boxes, clss = [], []
+        for si, (h, st) in enumerate(zip(heads, arch.STRIDES)):
+            Hs = S // st
+            p = h[image].permute(1, 2, 0).reshape(Hs * Hs, -1)
+            obj = torch.sigmoid(p[:, :A]).reshape(-1, 1)
+            cls = torch.softmax(p[:, A:A + A * C].reshape(-1, C), dim=1) * obj
+            t = p[:, A * (1 + C):].reshape(Hs * Hs, A, 4)
+            gy, gx = torch.meshgrid(torch.arange(Hs), torch.arange(Hs), indexing="ij")
+            g = torch.stack([gx, gy], -1).float().view(-1, 1, 2)
+            cxy = (torch.sigmoid(t[..., :2]) + g) * st
+            wh = torch.exp(t[..., 2:]) * anc[si][None]
+            b = torch.cat([cxy - wh / 2, cxy + wh / 2], -1).view(-1, 4)
+            boxes.append(torch.clamp(b / S, 0., 1.))
+            clss.append(cls)
+        return torch.cat(boxes, 0).numpy(), torch.cat(clss, 0).numpy()

@@ -163,3 +163,29 @@ def test_nms_tie_rule_is_pinned():
     """numpy's argsort tie order is unpinned in the reference; the build's rule: equal scores -> higher index first."""
     boxes = np.array([[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3]], dtype=np.float32)
     assert orc.nms(boxes, np.array([0.5, 0.5, 0.5], np.float32)) == [2, 1]
+
+
+def test_torch_port_matches_reference_and_c_oracle(golden):
+    """oracle/torch_port.py (the cpu_baseline of bench.py) against the same fixtures."""
+    from oracle.torch_port import TorchNet
+    case = golden("net_voc320.npz")
+    sd = weights.make_state_dict("1.0x", 20)
+    net = TorchNet(sd, "1.0x", 20)
+    heads = net.forward_raw(weights.make_input(1, 320, seed=1))
+    for i, h in enumerate(heads):
+        np.testing.assert_allclose(h.numpy(), case["head%d" % (i + 1)], atol=1e-4, rtol=0)
+    bbox, cls = net.score_head(heads, 320, arch.MULTI_ANCHOR_SIZE)
+    np.testing.assert_allclose(bbox, case["all_bbox"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(cls, case["all_class"], atol=1e-4, rtol=0)
+
+
+def test_oracle_end_to_end_416(golden):
+    """C oracle at the BASELINE config-2 resolution: sampled head values and detection count."""
+    case = golden("net_coco416.npz")
+    net, heads, S, C = _heads(case, True)
+    for i, h in enumerate(heads):
+        flat = h.reshape(-1)
+        np.testing.assert_allclose(flat[case["head%d_idx" % (i + 1)]], case["head%d_val" % (i + 1)], atol=1e-4, rtol=0)
+    bbox, cls = orc.score_decode([h[0] for h in heads], S, C, arch.MULTI_ANCHOR_SIZE_COCO)
+    b, s, c = orc.postprocess(bbox, cls, float(case["conf_thresh"]), float(case["nms_thresh"]))
+    assert abs(len(s) - len(case["scores"])) <= max(2, len(case["scores"]) // 200)

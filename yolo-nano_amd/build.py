@@ -1,0 +1,51 @@
+"""Build recipe for libyolonano_hip.so (hipcc, gfx950 only, in-tree).
+
+    python -m yolo_nano_amd.build      ->  yolo-nano_amd/libyolonano_hip.so
+
+hipcc cross-compiles for gfx950 without a GPU.  kernels_post.hip is built with
+-ffp-contract=off because its NMS arithmetic must match numpy's float32 operation
+sequence bit for bit (models/yolo_nano.py:159-188).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libyolonano_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("yn_api.hip", [])]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
+          "-Wno-pass-failed"]
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    d.append(os.path.join(os.path.dirname(HERE), "include", "yolonano_hip.h"))
+    d.append(os.path.abspath(__file__))
+    return d
+
+
+def _compile(item):
+    src, extra = item
+    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in _deps()):
+        return OUT
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    subprocess.check_call(cmd)
+    if verbose:
+        print("built", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,346 @@
+"""ctypes binding of libyolonano_hip.so (include/yolonano_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is
+visible, creating a handle raises.  torch is imported first on purpose — it loads
+its bundled libamdhip64.so.7, and the library then resolves the same runtime by
+soname, so torch tensors' ``data_ptr()`` and torch streams are valid in it.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
+
+from . import arch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolonano_hip.so")
+
+_vp = ctypes.c_void_p
+_i32, _f32 = ctypes.c_int, ctypes.c_float
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+BACKBONE_ID = {"0.5x": 0, "1.0x": 1, "1.5x": 2, "2.0x": 3}
+
+
+class YnConfig(ctypes.Structure):
+    _fields_ = [("input_size", _i32), ("num_classes", _i32), ("num_anchors", _i32),
+                ("anchors", _f32 * 18), ("backbone", _i32), ("conf_thresh", _f32), ("nms_thresh", _f32),
+                ("diou_nms", _i32), ("max_batch", _i32), ("device", _i32), ("stream", _vp)]
+
+
+# name -> (restype, argtypes); every symbol include/yolonano_hip.h declares
+SIGNATURES = {
+    "yn_abi_version": (_i32, []),
+    "yn_create": (_i32, [ctypes.POINTER(YnConfig), ctypes.POINTER(_vp)]),
+    "yn_destroy": (None, [_vp]),
+    "yn_last_error": (ctypes.c_char_p, [_vp]),
+    "yn_set_grid": (_i32, [_vp, _i32]),
+    "yn_set_stream": (_i32, [_vp, _vp]),
+    "yn_set_thresholds": (_i32, [_vp, _f32, _f32, _i32]),
+    "yn_num_predictions": (_i32, [_vp]),
+    "yn_use_graph": (_i32, [_vp, _i32]),
+    "yn_synchronize": (_i32, [_vp]),
+    "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
+    "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
+    "yn_fold_bn": (_i32, [_vp]),
+    "yn_get_folded": (_i32, [_vp, ctypes.c_char_p, _vp, _vp]),
+    "yn_forward_raw": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "yn_score_full": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "yn_decode_boxes": (_i32, [_vp, _vp, _i32, _vp]),
+    "yn_create_grid": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "yn_nms": (_i32, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _vp]),
+    "yn_postprocess": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_infer": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "yn_op_conv3x3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "yn_op_stem": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "yn_op_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "yn_op_shuffle_block": (_i32, [_vp, ctypes.c_char_p, _vp, _i32, _i32, _i32, _vp]),
+    "yn_op_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "yn_op_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "yn_profile_enable": (_i32, [_vp, _i32]),
+    "yn_profile_count": (_i32, [_vp]),
+    "yn_profile_get": (_i32, [_vp, _i32, ctypes.c_char_p, _i32, ctypes.c_char_p, _i32, ctypes.POINTER(_f32),
+                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+class YnError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree HIP library and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise YnError("%s is missing — build it with `python -m yolo_nano_amd.build` "
+                          "(there is no CPU fallback for the product path)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)              # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        assert t.is_contiguous(), "tensor must be contiguous"
+        return t.data_ptr()
+    return t
+
+
+class Handle:
+    """One yn_handle = one device + one stream.  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, input_size, num_classes, anchor_size, backbone="1.0x", conf_thresh=0.001,
+                 nms_thresh=0.5, diou_nms=False, max_batch=1, device=None, stream=None):
+        self.lib = load_library()
+        if backbone not in BACKBONE_ID:
+            raise YnError("unknown backbone %r" % (backbone,))
+        if not torch.cuda.is_available():
+            raise YnError("no MI355X visible: the YOLO-Nano HIP path needs a GPU (no CPU fallback)")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise YnError("device must be a GPU, got %s" % (dev,))
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        flat = [float(v) for wh in anchor_size for v in wh]
+        if len(flat) % 6:
+            raise YnError("anchor_size must hold 3*A [w,h] pairs")
+        self.A = len(flat) // 6
+        cfg = YnConfig()
+        cfg.input_size, cfg.num_classes, cfg.num_anchors = int(input_size), int(num_classes), self.A
+        for i, v in enumerate(flat):
+            cfg.anchors[i] = v
+        cfg.backbone = BACKBONE_ID[backbone]
+        cfg.conf_thresh, cfg.nms_thresh, cfg.diou_nms = float(conf_thresh), float(nms_thresh), int(bool(diou_nms))
+        cfg.max_batch, cfg.device = int(max_batch), self.device.index
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device) if stream is None else stream
+            cfg.stream = st.cuda_stream
+            h = _vp()
+            if self.lib.yn_create(ctypes.byref(cfg), ctypes.byref(h)):
+                raise YnError("yn_create: " + self.lib.yn_last_error(None).decode())
+        self.h = h
+        self.C, self.S = int(num_classes), int(input_size)
+        self.backbone = backbone
+        self.head_ch = arch.head_channels(self.C, self.A)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.yn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc:
+            raise YnError("%s: %s" % (what, self.lib.yn_last_error(self.h).decode()))
+
+    # ---- configuration
+    @property
+    def N(self):
+        return self.lib.yn_num_predictions(self.h)
+
+    def set_grid(self, S):
+        self._ck(self.lib.yn_set_grid(self.h, int(S)), "yn_set_grid")
+        self.S = int(S)
+
+    def set_stream(self, stream):
+        self._ck(self.lib.yn_set_stream(self.h, stream.cuda_stream), "yn_set_stream")
+
+    def set_thresholds(self, conf, nms, diou=False):
+        self._ck(self.lib.yn_set_thresholds(self.h, float(conf), float(nms), int(bool(diou))), "yn_set_thresholds")
+
+    def use_graph(self, on=True):
+        self._ck(self.lib.yn_use_graph(self.h, int(bool(on))), "yn_use_graph")
+
+    def synchronize(self):
+        self._ck(self.lib.yn_synchronize(self.h), "yn_synchronize")
+
+    # ---- weights
+    def load_param(self, key, value):
+        """value: numpy array / CPU tensor (host copy) or a GPU tensor (device copy)."""
+        if isinstance(value, torch.Tensor) and value.is_cuda:
+            v = value.detach()
+            if v.dtype != torch.float32 and v.dtype != torch.int64:
+                v = v.float()
+            v = v.contiguous()
+            shape = (ctypes.c_int64 * max(v.dim(), 1))(*v.shape)
+            self._ck(self.lib.yn_load_param_dev(self.h, key.encode(), v.data_ptr(), shape, v.dim()), "yn_load_param_dev(%s)" % key)
+            return
+        import numpy as np
+        a = value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else np.asarray(value)
+        if a.dtype != np.int64:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+        shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+        self._ck(self.lib.yn_load_param(self.h, key.encode(), a.ctypes.data, shape, a.ndim), "yn_load_param(%s)" % key)
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            self.load_param(k, v)
+
+    def fold_bn(self):
+        self._ck(self.lib.yn_fold_bn(self.h), "yn_fold_bn")
+
+    def get_folded(self, conv_key, weight_shape):
+        import numpy as np
+        w = np.empty(weight_shape, dtype=np.float32)
+        b = np.empty((weight_shape[0],), dtype=np.float32)
+        self._ck(self.lib.yn_get_folded(self.h, conv_key.encode(), w.ctypes.data, b.ctypes.data), "yn_get_folded")
+        return w, b
+
+    # ---- network
+    def head_shapes(self, B):
+        return [(B, self.S // s, self.S // s, self.head_ch) for s in arch.STRIDES]
+
+    def forward_raw(self, x, out=None):
+        """x: cuda float32 NCHW [B,3,S,S] -> three NHWC head tensors."""
+        B = x.shape[0]
+        assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape[1:]) == (3, self.S, self.S), (x.shape, self.S)
+        x = x.contiguous()
+        if out is None:
+            out = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.head_shapes(B)]
+        self._ck(self.lib.yn_forward_raw(self.h, x.data_ptr(), B, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()), "yn_forward_raw")
+        return out
+
+    def score_full(self, heads):
+        B = heads[0].shape[0]
+        N = self.N
+        bbox = torch.empty((B, N, 4), dtype=torch.float32, device=heads[0].device)
+        cls = torch.empty((B, N, self.C), dtype=torch.float32, device=heads[0].device)
+        self._ck(self.lib.yn_score_full(self.h, _ptr(heads[0]), _ptr(heads[1]), _ptr(heads[2]), B, bbox.data_ptr(), cls.data_ptr()), "yn_score_full")
+        return bbox, cls
+
+    def decode_boxes(self, txtytwth):
+        t = txtytwth.contiguous().float()
+        B = t.shape[0]
+        out = torch.empty((B, self.N, 4), dtype=torch.float32, device=t.device)
+        self._ck(self.lib.yn_decode_boxes(self.h, t.data_ptr(), B, out.data_ptr()), "yn_decode_boxes")
+        return out
+
+    def create_grid(self, S):
+        import numpy as np
+        HW = sum((S // s) ** 2 for s in arch.STRIDES)
+        g = np.empty((1, HW, 1, 2), np.float32)
+        st = np.empty((1, HW, self.A, 2), np.float32)
+        an = np.empty((1, HW, self.A, 2), np.float32)
+        self._ck(self.lib.yn_create_grid(self.h, int(S), g.ctypes.data, st.ctypes.data, an.ctypes.data), "yn_create_grid")
+        return g, st, an
+
+    # ---- post-processing
+    def nms(self, dets, scores, thresh, diou=False):
+        n = int(scores.shape[0])
+        keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dets.device)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+        self._ck(self.lib.yn_nms(self.h, _ptr(dets.contiguous()), _ptr(scores.contiguous()), n, float(thresh), int(bool(diou)),
+                                 keep.data_ptr(), cnt.data_ptr()), "yn_nms")
+        return keep[: int(cnt.item())]
+
+    def alloc_outputs(self, B, N=None, device=None):
+        N = self.N if N is None else N
+        device = self.device if device is None else device
+        return (torch.empty((B, N, 4), dtype=torch.float32, device=device),
+                torch.empty((B, N), dtype=torch.float32, device=device),
+                torch.empty((B, N), dtype=torch.int32, device=device),
+                torch.empty((B, N), dtype=torch.int32, device=device),
+                torch.zeros((B,), dtype=torch.int32, device=device))
+
+    def postprocess(self, all_local, all_conf, out=None):
+        """all_local [B,N,4], all_conf [B,N,C] cuda float32 -> (boxes, scores, cls, index, count) device buffers"""
+        B, N, C = all_conf.shape
+        out = self.alloc_outputs(B, N, all_conf.device) if out is None else out
+        self._ck(self.lib.yn_postprocess(self.h, _ptr(all_local.contiguous()), _ptr(all_conf.contiguous()), B, N, C,
+                                         *[o.data_ptr() for o in out]), "yn_postprocess")
+        return out
+
+    def infer(self, x, out=None):
+        B = x.shape[0]
+        assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape[1:]) == (3, self.S, self.S), (x.shape, self.S)
+        x = x.contiguous()
+        out = self.alloc_outputs(B, device=x.device) if out is None else out
+        self._ck(self.lib.yn_infer(self.h, x.data_ptr(), B, *[o.data_ptr() for o in out]), "yn_infer")
+        return out
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self._ck(self.lib.yn_profile_enable(self.h, int(bool(on))), "yn_profile_enable")
+
+    def profile_records(self):
+        """[(layer name, kernel symbol, ms, algorithmic flops, algorithmic bytes)] of the last profiled call."""
+        n = self.lib.yn_profile_count(self.h)
+        recs = []
+        name = ctypes.create_string_buffer(96)
+        kern = ctypes.create_string_buffer(96)
+        ms, fl, by = _f32(), ctypes.c_double(), ctypes.c_double()
+        for i in range(n):
+            self._ck(self.lib.yn_profile_get(self.h, i, name, 96, kern, 96, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)), "yn_profile_get")
+            recs.append((name.value.decode(), kern.value.decode(), ms.value, fl.value, by.value))
+        return recs
+
+    # ---- single operators (NHWC device tensors; weights in torch layout on the device) -----------
+    def op_dwconv3x3(self, x, w, bias, stride=1, act=0):
+        B, H, W, C = x.shape
+        y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_dwconv3x3(self.h, _ptr(x.contiguous()), B, H, W, C, stride, _ptr(w.contiguous()),
+                                          _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_dwconv3x3")
+        return y
+
+    def op_pwconv(self, x, w, bias, act=0):
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_pwconv(self.h, _ptr(x.contiguous()), B, H, W, Cin, Cout, _ptr(w.contiguous()),
+                                       _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_pwconv")
+        return y
+
+    def op_conv3x3(self, x, w, bias, act=0, x2=None, resample=0):
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_conv3x3(self.h, _ptr(x.contiguous()), _ptr(x2.contiguous()) if x2 is not None else None, resample,
+                                        B, H, W, Cin, Cout, _ptr(w.contiguous()),
+                                        _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_conv3x3")
+        return y
+
+    def op_stem(self, x_nchw, w, bias, act=0):
+        B, _, H, W = x_nchw.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), dtype=torch.float32, device=x_nchw.device)
+        self._ck(self.lib.yn_op_stem(self.h, _ptr(x_nchw.contiguous()), B, H, W, Cout, _ptr(w.contiguous()),
+                                     _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_stem")
+        return y
+
+    def op_maxpool(self, x):
+        B, H, W, C = x.shape
+        y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_maxpool3x3s2(self.h, _ptr(x.contiguous()), B, H, W, C, y.data_ptr()), "yn_op_maxpool3x3s2")
+        return y
+
+    def op_shuffle_block(self, block, x, cout, stride):
+        B, H, W, _ = x.shape
+        y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_shuffle_block(self.h, block.encode(), _ptr(x.contiguous()), B, H, W, y.data_ptr()), "yn_op_shuffle_block")
+        return y
+
+    def to_nhwc(self, x):
+        B, C, H, W = x.shape
+        y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_nchw_to_nhwc(self.h, _ptr(x.contiguous()), B, C, H, W, y.data_ptr()), "yn_op_nchw_to_nhwc")
+        return y
+
+    def to_nchw(self, x):
+        B, H, W, C = x.shape
+        y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_nhwc_to_nchw(self.h, _ptr(x.contiguous()), B, C, H, W, y.data_ptr()), "yn_op_nhwc_to_nchw")
+        return y

@@ -1,0 +1,942 @@
+// yn_api.hip — the C ABI of libyolonano_hip.so (see include/yolonano_hip.h) and the network executor.
+//
+// The handle owns: the raw parameters (reference state-dict keys), the folded + packed weights, one
+// activation arena in HBM, NMS scratch, and optional hipGraphs of the fixed-shape pipelines.
+// Network wiring restates models/yolo_nano.py:282-301 and backbone/shufflenetv2.py:69-78,157-167.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/yolonano_hip.h"
+#include "yn_internal.h"
+
+using namespace ynk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Param {
+    void* dev = nullptr;
+    size_t bytes = 0;
+    size_t numel = 0;
+    std::vector<int64_t> shape;
+};
+
+enum { K_PW = 0, K_DW = 1, K_DENSE3 = 2, K_STEM = 3 };
+
+struct Layer {
+    std::string name, conv, bn;
+    int kind = 0, cin = 0, cout = 0, stride = 1, has_bias = 0, act = 0;
+    float* w_packed = nullptr;
+    float* b_packed = nullptr;
+    float* w_ref = nullptr;
+    float* b_ref = nullptr;
+    size_t w_numel = 0;
+    int Kp = 0, Npad = 0;
+};
+
+struct ProfRec {
+    std::string name, kernel;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+struct GraphEntry {
+    std::vector<uintptr_t> key;
+    hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
+
+struct yn_handle {
+    yn_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, Param> params;
+    std::vector<Layer> layers;
+    std::map<std::string, int> by_name;
+    std::map<std::string, int> by_conv;
+    bool folded = false;
+    int stage_ch[3] = {0, 0, 0};
+    int head_ch = 0;
+    GridInfo grid;
+    // arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    int arena_S = 0, arena_B = 0;
+    // NMS scratch + candidate buffers (sized max_batch * N)
+    float* cand_boxes = nullptr; float* cand_scores = nullptr; int32_t* cand_cls = nullptr;
+    NmsWork nms{};
+    size_t nms_cap = 0;           // elements B*N currently allocated
+    size_t nms_seg_cap = 0;       // B*C
+    float* heads_int[3] = {nullptr, nullptr, nullptr};
+    size_t heads_cap = 0;
+    // graphs / profiling
+    bool use_graph = false;
+    std::vector<GraphEntry> graphs;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+};
+
+namespace {
+
+int fail(yn_handle* h, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return 1;
+}
+
+#define HIPCHK(h, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail((h), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+const int STAGE_CH[4][3] = {{48, 96, 192}, {116, 232, 464}, {176, 352, 704}, {244, 488, 976}};
+const int STAGE_REP[3] = {4, 8, 4};
+const int NECK = 96;
+
+void add_layer(yn_handle* h, const std::string& name, const std::string& conv, const std::string& bn,
+               int kind, int cin, int cout, int stride, int has_bias, int act)
+{
+    Layer L;
+    L.name = name; L.conv = conv; L.bn = bn; L.kind = kind; L.cin = cin; L.cout = cout;
+    L.stride = stride; L.has_bias = has_bias; L.act = act;
+    h->by_name[name] = (int)h->layers.size();
+    h->by_conv[conv] = (int)h->layers.size();
+    h->layers.push_back(L);
+}
+
+// the 77 convolutions, same naming as yolo_nano_amd/arch.py conv_specs()
+void build_layers(yn_handle* h)
+{
+    char p[128], a[160], b[160];
+    const int* sc = STAGE_CH[h->cfg.backbone];
+    for (int i = 0; i < 3; ++i) h->stage_ch[i] = sc[i];
+    add_layer(h, "stem", "backbone.conv1.0", "backbone.conv1.1", K_STEM, 3, 24, 2, 0, YN_ACT_RELU);
+    int cin = 24;
+    for (int si = 0; si < 3; ++si) {
+        const int cout = sc[si], bf = cout / 2;
+        for (int bi = 0; bi < STAGE_REP[si]; ++bi) {
+            snprintf(p, sizeof p, "backbone.stage%d.%d", si + 2, bi);
+            const std::string P = p;
+            if (bi == 0) {
+                add_layer(h, P + ".b1.dw", P + ".branch1.0", P + ".branch1.1", K_DW, cin, cin, 2, 0, YN_ACT_NONE);
+                add_layer(h, P + ".b1.pw", P + ".branch1.2", P + ".branch1.3", K_PW, cin, bf, 1, 0, YN_ACT_RELU);
+            }
+            const int b2in = bi == 0 ? cin : bf;
+            add_layer(h, P + ".b2.pw1", P + ".branch2.0", P + ".branch2.1", K_PW, b2in, bf, 1, 0, YN_ACT_RELU);
+            add_layer(h, P + ".b2.dw", P + ".branch2.3", P + ".branch2.4", K_DW, bf, bf, bi == 0 ? 2 : 1, 0, YN_ACT_NONE);
+            add_layer(h, P + ".b2.pw2", P + ".branch2.5", P + ".branch2.6", K_PW, bf, bf, 1, 0, YN_ACT_RELU);
+        }
+        cin = cout;
+    }
+    for (int i = 0; i < 3; ++i) {
+        snprintf(a, sizeof a, "conv1x1_%d", i);
+        add_layer(h, a, std::string(a) + ".convs.0", std::string(a) + ".convs.1", K_PW, sc[i], NECK, 1, 1, YN_ACT_LEAKY);
+    }
+    for (int i = 0; i < 4; ++i) {
+        snprintf(a, sizeof a, "smooth_%d", i);
+        add_layer(h, a, std::string(a) + ".convs.0", std::string(a) + ".convs.1", K_DENSE3, NECK, NECK, 1, 1, YN_ACT_LEAKY);
+    }
+    h->head_ch = h->cfg.num_anchors * (1 + h->cfg.num_classes + 4);
+    for (int hd = 1; hd <= 3; ++hd) {
+        for (int j = 0; j < 4; ++j) {
+            snprintf(a, sizeof a, "head_det_%d.%d", hd, j);
+            snprintf(b, sizeof b, "head_det_%d.%d.convs", hd, j);
+            add_layer(h, a, std::string(b) + ".0", std::string(b) + ".1", (j & 1) ? K_PW : K_DW, NECK, NECK, 1, 1, YN_ACT_LEAKY);
+        }
+        snprintf(a, sizeof a, "head_det_%d.4", hd);
+        add_layer(h, a, a, "", K_PW, NECK, h->head_ch, 1, 1, YN_ACT_NONE);
+    }
+}
+
+int set_grid_info(yn_handle* h, int S)
+{
+    if (S <= 0 || (S % 32) != 0) return fail(h, "input_size %d is not a positive multiple of 32", S);
+    GridInfo& g = h->grid;
+    g.S = S; g.C = h->cfg.num_classes; g.A = h->cfg.num_anchors;
+    int off = 0;
+    for (int s = 0; s < 3; ++s) {
+        const int w = S / (8 << s);
+        g.w[s] = w; g.hw[s] = w * w; g.off[s] = off;
+        off += w * w * g.A;
+    }
+    g.N = off;
+    for (int i = 0; i < 18; ++i) g.anchors[i] = h->cfg.anchors[i];
+    return 0;
+}
+
+const Param* find_param(yn_handle* h, const std::string& key)
+{
+    auto it = h->params.find(key);
+    return it == h->params.end() ? nullptr : &it->second;
+}
+
+// ---- arena ------------------------------------------------------------------------------------
+size_t network_arena_bytes(yn_handle* h, int B, int S)
+{
+    // generous closed form: every buffer of run_network(), no reuse across stages
+    const size_t px2 = (size_t)B * (S / 2) * (S / 2), px4 = px2 / 4;
+    size_t fl = px2 * 24 + px4 * 24;
+    int cin = 24;
+    size_t cur = px4;
+    for (int si = 0; si < 3; ++si) {
+        const int C = h->stage_ch[si], bf = C / 2;
+        const size_t po = cur / 4;
+        fl += po * cin + po * bf + cur * bf + po * bf + 2 * po * C;
+        cin = C; cur = po;
+    }
+    const size_t p3 = (size_t)B * (S / 8) * (S / 8), p4 = p3 / 4, p5 = p4 / 4;
+    fl += (p3 + p4 + p5) * NECK * 2 + p4 * NECK;      // laterals, smoothed (p4 twice)
+    fl += p3 * NECK * 2;                               // head ping-pong (largest scale)
+    return fl * sizeof(float) + 64 * 256;
+}
+
+int ensure_arena(yn_handle* h, int B, int S)
+{
+    const size_t need = network_arena_bytes(h, B, S);
+    if (need <= h->arena_bytes) return 0;
+    if (h->arena) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+    HIPCHK(h, hipMalloc((void**)&h->arena, need));
+    h->arena_bytes = need;
+    h->graphs.clear();
+    return 0;
+}
+
+float* arena_take(yn_handle* h, size_t floats)
+{
+    size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
+    if (h->arena_used + bytes > h->arena_bytes) return nullptr;
+    float* p = (float*)(h->arena + h->arena_used);
+    h->arena_used += bytes;
+    return p;
+}
+
+int ensure_post(yn_handle* h, int B, int N, int C)
+{
+    const size_t need = (size_t)B * N, need_seg = (size_t)B * C;
+    if (need > h->nms_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        void** ptrs[] = {(void**)&h->cand_boxes, (void**)&h->cand_scores, (void**)&h->cand_cls,
+                         (void**)&h->nms.bucket, (void**)&h->nms.keep, (void**)&h->nms.state};
+        for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
+        HIPCHK(h, hipMalloc((void**)&h->cand_boxes, need * 4 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&h->cand_scores, need * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&h->cand_cls, need * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.bucket, need * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.keep, need * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.state, need * sizeof(int32_t)));
+        h->nms_cap = need;
+        h->graphs.clear();
+    }
+    if (need_seg > h->nms_seg_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->nms.seg_count) HIPCHK(h, hipFree(h->nms.seg_count));
+        if (h->nms.seg_off) HIPCHK(h, hipFree(h->nms.seg_off));
+        HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
+        h->nms_seg_cap = need_seg;
+        h->graphs.clear();
+    }
+    return 0;
+}
+
+int ensure_heads(yn_handle* h, int B)
+{
+    const size_t need = (size_t)B * (h->grid.hw[0] + h->grid.hw[1] + h->grid.hw[2]) * h->head_ch;
+    if (need <= h->heads_cap) {
+        // re-derive the split for the current grid
+        h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * h->head_ch;
+        h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * h->head_ch;
+        return 0;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->heads_int[0]) HIPCHK(h, hipFree(h->heads_int[0]));
+    HIPCHK(h, hipMalloc((void**)&h->heads_int[0], need * sizeof(float) + 1024));
+    h->heads_cap = need;
+    h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * h->head_ch;
+    h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * h->head_ch;
+    h->graphs.clear();
+    return 0;
+}
+
+// ---- profiling brackets ---------------------------------------------------------------------------
+hipEvent_t take_event(yn_handle* h)
+{
+    if (h->event_next == h->event_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->event_pool.push_back(e);
+    }
+    return h->event_pool[h->event_next++];
+}
+
+struct Bracket {
+    yn_handle* h;
+    bool on;
+    Bracket(yn_handle* h_, const std::string& name, double flops, double bytes) : h(h_), on(h_->profiling)
+    {
+        if (!on) return;
+        ProfRec r;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        r.e0 = take_event(h); r.e1 = take_event(h);
+        (void)hipEventRecord(r.e0, h->stream);
+        h->prof.push_back(r);
+    }
+    ~Bracket()
+    {
+        if (!on) return;
+        (void)hipEventRecord(h->prof.back().e1, h->stream);
+        h->prof.back().kernel = last_kernel_name();
+    }
+};
+
+// ---- layer launchers ------------------------------------------------------------------------------
+const Layer& L(yn_handle* h, const std::string& name) { return h->layers[h->by_name.at(name)]; }
+
+void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
+            float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
+{
+    GemmArgs a{};
+    a.in = in; a.in_ld = in_ld; a.in_off = in_off;
+    a.Wp = l.w_packed; a.bias = l.b_packed;
+    a.out = out; a.out_ld = out_ld; a.out_off = out_off;
+    a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
+    a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
+               4.0 * (M * (double)(l.cin + l.cout + (pass ? 2 * l.cout : 0)) + (double)l.cin * l.cout));
+    launch_pw(a, h->stream);
+}
+
+void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, int B, int H, int W,
+            float* out, int out_ld, int out_off)
+{
+    DwArgs a{};
+    a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.w = l.w_packed; a.bias = l.b_packed;
+    a.out = out; a.out_ld = out_ld; a.out_off = out_off;
+    a.B = B; a.H = H; a.W = W; a.C = l.cout; a.stride = l.stride; a.act = l.act;
+    const double Mi = (double)B * H * W, Mo = (double)B * ((H - 1) / l.stride + 1) * ((W - 1) / l.stride + 1);
+    Bracket br(h, l.name, 2.0 * Mo * 9 * l.cout, 4.0 * (Mi + Mo) * l.cout);
+    launch_dw(a, h->stream);
+}
+
+void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int resample, int B, int H, int W, float* out)
+{
+    GemmArgs a{};
+    a.in = in; a.in_ld = l.cin; a.in_off = 0; a.in2 = in2; a.resample = resample; a.H = H; a.W = W;
+    a.Wp = l.w_packed; a.bias = l.b_packed; a.out = out; a.out_ld = l.cout; a.out_off = 0;
+    a.M = B * H * W; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    const double M = (double)a.M;
+    const double in2px = resample == 1 ? M / 4 : (resample == 2 ? M * 4 : 0);
+    Bracket br(h, l.name, 2.0 * M * 9 * l.cin * l.cout, 4.0 * ((M + in2px) * l.cin + M * l.cout + 9.0 * l.cin * l.cout));
+    launch_conv3x3(a, h->stream);
+}
+
+// The network: x NCHW [B,3,S,S] -> three NHWC head tensors.
+int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
+{
+    const int S = h->grid.S;
+    h->arena_used = 0;
+#define TAKE(var, floats)                                                                   \
+    float* var = arena_take(h, (size_t)(floats));                                           \
+    if (!var) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes)
+    const int H1 = S / 2, H2 = S / 4;
+    TAKE(a0, (size_t)B * H1 * H1 * 24);
+    TAKE(a1, (size_t)B * H2 * H2 * 24);
+    {
+        const Layer& l = L(h, "stem");
+        const double Mo = (double)B * H1 * H1;
+        Bracket br(h, "stem", 2.0 * Mo * 27 * 24, 4.0 * ((double)B * 3 * S * S + Mo * 24));
+        launch_stem(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a0, h->stream);
+    }
+    {
+        Bracket br(h, "maxpool", 0.0, 4.0 * 24 * ((double)B * H1 * H1 + (double)B * H2 * H2));
+        launch_maxpool(a0, B, H1, H1, 24, a1, h->stream);
+    }
+    const float* cur = a1;
+    int curC = 24, curH = H2;
+    const float* cfeat[3];
+    char nm[96];
+    for (int si = 0; si < 3; ++si) {
+        const int C = h->stage_ch[si], bf = C / 2, Ho = curH / 2;
+        const long Mi = (long)B * curH * curH, Mo = (long)B * Ho * Ho;
+        TAKE(tdw1, Mo * curC);
+        TAKE(tb1, Mo * bf);
+        TAKE(t1, Mi * bf);
+        TAKE(t2, Mo * bf);
+        TAKE(oA, Mo * C);
+        TAKE(oB, Mo * C);
+        snprintf(nm, sizeof nm, "backbone.stage%d.0", si + 2);
+        const std::string P0 = nm;
+        // stride-2 block: backbone/shufflenetv2.py:73-74
+        run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
+        run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+        run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
+        run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
+        run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
+        float* o_cur = oA;
+        float* o_nxt = oB;
+        for (int bi = 1; bi < STAGE_REP[si]; ++bi) {
+            snprintf(nm, sizeof nm, "backbone.stage%d.%d", si + 2, bi);
+            const std::string P = nm;
+            // stride-1 block: backbone/shufflenetv2.py:70-72 — x1 = ch [0,bf) passes through, x2 = ch [bf,C)
+            run_pw(h, L(h, P + ".b2.pw1"), o_cur, C, bf, Mo, t1, bf, 0, nullptr, 0, 0);
+            run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, Ho, Ho, t2, bf, 0);
+            run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, o_nxt, C, 0, o_cur, C, 0);
+            float* tmp = o_cur; o_cur = o_nxt; o_nxt = tmp;
+        }
+        cfeat[si] = o_cur;
+        cur = o_cur; curC = C; curH = Ho;
+    }
+    // neck: models/yolo_nano.py:286-296
+    const int W3 = S / 8, W4 = S / 16, W5 = S / 32;
+    const long M3 = (long)B * W3 * W3, M4 = (long)B * W4 * W4, M5 = (long)B * W5 * W5;
+    TAKE(p3, M3 * NECK); TAKE(p4, M4 * NECK); TAKE(p5, M5 * NECK);
+    run_pw(h, L(h, "conv1x1_0"), cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0);
+    run_pw(h, L(h, "conv1x1_1"), cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0);
+    run_pw(h, L(h, "conv1x1_2"), cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0);
+    TAKE(p4a, M4 * NECK); TAKE(p3a, M3 * NECK); TAKE(p4b, M4 * NECK); TAKE(p5a, M5 * NECK);
+    run_c3(h, L(h, "smooth_0"), p4, p5, 1, B, W4, W4, p4a);        // p4 + up2(p5)
+    run_c3(h, L(h, "smooth_1"), p3, p4a, 1, B, W3, W3, p3a);       // p3 + up2(p4)
+    run_c3(h, L(h, "smooth_2"), p4a, p3a, 2, B, W4, W4, p4b);      // p4 + down(p3)
+    run_c3(h, L(h, "smooth_3"), p5, p4b, 2, B, W5, W5, p5a);       // p5 + down(p4)
+    // heads: models/yolo_nano.py:299-301
+    TAKE(hA, M3 * NECK); TAKE(hB, M3 * NECK);
+    const float* feats[3] = {p3a, p4b, p5a};
+    const int Ws[3] = {W3, W4, W5};
+    for (int hd = 0; hd < 3; ++hd) {
+        const long M = (long)B * Ws[hd] * Ws[hd];
+        snprintf(nm, sizeof nm, "head_det_%d", hd + 1);
+        const std::string P = nm;
+        run_dw(h, L(h, P + ".0"), feats[hd], NECK, 0, B, Ws[hd], Ws[hd], hA, NECK, 0);
+        run_pw(h, L(h, P + ".1"), hA, NECK, 0, M, hB, NECK, 0, nullptr, 0, 0);
+        run_dw(h, L(h, P + ".2"), hB, NECK, 0, B, Ws[hd], Ws[hd], hA, NECK, 0);
+        run_pw(h, L(h, P + ".3"), hA, NECK, 0, M, hB, NECK, 0, nullptr, 0, 0);
+        run_pw(h, L(h, P + ".4"), hB, NECK, 0, M, heads[hd], h->head_ch, 0, nullptr, 0, 0);
+    }
+#undef TAKE
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int check_ready(yn_handle* h, int B)
+{
+    if (!h->folded) return fail(h, "weights not prepared: call yn_fold_bn() after loading parameters");
+    if (B <= 0) return fail(h, "batch must be positive (got %d)", B);
+    return 0;
+}
+
+// run `body` directly, or captured into / replayed from a hipGraph keyed by `key`
+template <class F>
+int run_maybe_graph(yn_handle* h, const std::vector<uintptr_t>& key, F body)
+{
+    if (!h->use_graph || h->profiling) return body();
+    for (GraphEntry& g : h->graphs)
+        if (g.key == key) { HIPCHK(h, hipGraphLaunch(g.exec, h->stream)); return 0; }
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(h, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    GraphEntry ge;
+    ge.key = key;
+    HIPCHK(h, hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    h->graphs.push_back(ge);
+    HIPCHK(h, hipGraphLaunch(ge.exec, h->stream));
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+#pragma GCC visibility push(default)
+extern "C" {
+
+int yn_abi_version(void) { return 1; }
+
+const char* yn_last_error(yn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int yn_create(const yn_config* cfg, yn_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, "yn_create: null argument");
+    *out = nullptr;
+    if (cfg->backbone < 0 || cfg->backbone > 3)
+        return fail(nullptr, "unsupported backbone id %d (0.5x/1.0x/1.5x/2.0x = 0..3)", cfg->backbone);   // models/yolo_nano.py:35-37
+    if (cfg->num_anchors < 1 || cfg->num_anchors > 3) return fail(nullptr, "num_anchors must be 1..3");
+    if (cfg->num_classes < 1 || cfg->num_classes > 1024) return fail(nullptr, "num_classes out of range");
+    if (cfg->input_size <= 0 || cfg->input_size % 32) return fail(nullptr, "input_size must be a positive multiple of 32");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available (%s)", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "device %d out of range (%d devices)", cfg->device, ndev);
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, "hipSetDevice(%d): %s", cfg->device, hipGetErrorString(e));
+    yn_handle* h = new yn_handle();
+    h->cfg = *cfg;
+    if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
+    h->stream = (hipStream_t)cfg->stream;
+    build_layers(h);
+    if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
+    *out = h;
+    return 0;
+}
+
+void yn_destroy(yn_handle* h)
+{
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->params) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (Layer& l : h->layers) {
+        if (l.w_packed) (void)hipFree(l.w_packed);
+        if (l.b_packed) (void)hipFree(l.b_packed);
+        if (l.w_ref) (void)hipFree(l.w_ref);
+        if (l.b_ref) (void)hipFree(l.b_ref);
+    }
+    void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.state,
+                    h->nms.seg_count, h->nms.seg_off, h->heads_int[0]};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+int yn_set_grid(yn_handle* h, int input_size)
+{
+    if (!h) return 1;
+    if (set_grid_info(h, input_size)) return 1;
+    h->cfg.input_size = input_size;
+    return 0;
+}
+
+int yn_set_stream(yn_handle* h, void* stream)
+{
+    if (!h) return 1;
+    if ((hipStream_t)stream != h->stream) {
+        for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
+    h->stream = (hipStream_t)stream;
+    return 0;
+}
+
+int yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int diou_nms)
+{
+    if (!h) return 1;
+    if (conf_thresh != h->cfg.conf_thresh || nms_thresh != h->cfg.nms_thresh || diou_nms != h->cfg.diou_nms) {
+        for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
+    h->cfg.conf_thresh = conf_thresh; h->cfg.nms_thresh = nms_thresh; h->cfg.diou_nms = diou_nms;
+    return 0;
+}
+
+int yn_num_predictions(yn_handle* h) { return h ? h->grid.N : -1; }
+
+int yn_use_graph(yn_handle* h, int enable) { if (!h) return 1; h->use_graph = enable != 0; return 0; }
+
+int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
+
+// ---- weights -----------------------------------------------------------------------------------
+static int load_param_impl(yn_handle* h, const char* key, const void* ptr, const int64_t* shape, int ndim, bool from_dev)
+{
+    if (!h || !key) return 1;
+    if (!ptr) return fail(h, "yn_load_param(%s): null data", key);
+    const std::string k = key;
+    const bool is_i64 = k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0;
+    if (is_i64) return 0;                                   // bookkeeping counter, unused in eval
+    // validate the key against the architecture
+    const size_t dot = k.rfind('.');
+    if (dot == std::string::npos) return fail(h, "unknown state-dict key '%s'", key);
+    const std::string prefix = k.substr(0, dot), leaf = k.substr(dot + 1);
+    const Layer* owner = nullptr;
+    bool is_bn = false;
+    auto it = h->by_conv.find(prefix);
+    if (it != h->by_conv.end() && (leaf == "weight" || leaf == "bias")) owner = &h->layers[it->second];
+    if (!owner) {
+        for (const Layer& l : h->layers)
+            if (!l.bn.empty() && l.bn == prefix) { owner = &l; is_bn = true; break; }
+    }
+    if (!owner) return fail(h, "unexpected state-dict key '%s'", key);
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    size_t expect;
+    if (is_bn || leaf == "bias") expect = owner->cout;
+    else if (owner->kind == K_DW) expect = (size_t)owner->cout * 9;
+    else if (owner->kind == K_PW) expect = (size_t)owner->cout * owner->cin;
+    else expect = (size_t)owner->cout * owner->cin * 9;
+    if (numel != expect) return fail(h, "size mismatch for '%s': got %zu elements, expected %zu", key, numel, expect);
+    Param& p = h->params[k];
+    const size_t bytes = numel * sizeof(float);
+    if (p.bytes != bytes) {
+        if (p.dev) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(p.dev)); p.dev = nullptr; }
+        HIPCHK(h, hipMalloc(&p.dev, bytes));
+        p.bytes = bytes;
+    }
+    p.numel = numel;
+    p.shape.assign(shape, shape + ndim);
+    HIPCHK(h, hipMemcpyAsync(p.dev, ptr, bytes, from_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (!from_dev) HIPCHK(h, hipStreamSynchronize(h->stream));   // host buffer may be freed by the caller
+    h->folded = false;
+    return 0;
+}
+
+int yn_load_param(yn_handle* h, const char* key, const void* host_ptr, const int64_t* shape, int ndim)
+{
+    return load_param_impl(h, key, host_ptr, shape, ndim, false);
+}
+
+int yn_load_param_dev(yn_handle* h, const char* key, const void* dev_ptr, const int64_t* shape, int ndim)
+{
+    return load_param_impl(h, key, dev_ptr, shape, ndim, true);
+}
+
+int yn_fold_bn(yn_handle* h)
+{
+    if (!h) return 1;
+    for (Layer& l : h->layers) {
+        const Param* w = find_param(h, l.conv + ".weight");
+        if (!w) return fail(h, "missing parameter '%s.weight'", l.conv.c_str());
+        const Param* b = find_param(h, l.conv + ".bias");
+        const Param *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+        if (!l.bn.empty()) {
+            g = find_param(h, l.bn + ".weight"); be = find_param(h, l.bn + ".bias");
+            mu = find_param(h, l.bn + ".running_mean"); var = find_param(h, l.bn + ".running_var");
+            const int have = (g != nullptr) + (be != nullptr) + (mu != nullptr) + (var != nullptr);
+            if (have != 0 && have != 4) return fail(h, "incomplete BatchNorm parameters for '%s'", l.bn.c_str());
+            if (have == 0 && !b) return fail(h, "'%s' has neither BatchNorm statistics nor a folded bias", l.conv.c_str());
+        } else if (!b) return fail(h, "missing parameter '%s.bias'", l.conv.c_str());
+        FoldArgs a{};
+        a.w = (const float*)w->dev; a.b = b ? (const float*)b->dev : nullptr;
+        a.gamma = g ? (const float*)g->dev : nullptr; a.beta = be ? (const float*)be->dev : nullptr;
+        a.mean = mu ? (const float*)mu->dev : nullptr; a.var = var ? (const float*)var->dev : nullptr;
+        a.eps = 1e-5f;
+        a.Cout = l.cout; a.Cin = l.cin;
+        size_t packed_floats;
+        if (l.kind == K_DW) { a.kind = 1; a.kk = 9; packed_floats = (size_t)9 * l.cout; l.Npad = l.cout; l.Kp = 9; }
+        else if (l.kind == K_STEM) { a.kind = 2; a.kk = 9; packed_floats = (size_t)27 * l.cout; l.Npad = l.cout; l.Kp = 27; }
+        else {
+            a.kind = 0; a.kk = (l.kind == K_DENSE3) ? 9 : 1;
+            const int K = l.cin * a.kk;
+            l.Kp = (K + 1) & ~1; l.Npad = (l.cout + 31) & ~31;
+            packed_floats = (size_t)l.Kp * l.Npad;
+        }
+        a.Kp = l.Kp; a.Npad = l.Npad;
+        if (!l.w_packed) {
+            HIPCHK(h, hipMalloc((void**)&l.w_packed, packed_floats * sizeof(float)));
+            HIPCHK(h, hipMalloc((void**)&l.b_packed, (size_t)((l.Npad + 31) & ~31) * sizeof(float)));
+            HIPCHK(h, hipMalloc((void**)&l.w_ref, w->numel * sizeof(float)));
+            HIPCHK(h, hipMalloc((void**)&l.b_ref, (size_t)l.cout * sizeof(float)));
+            l.w_numel = w->numel;
+        }
+        HIPCHK(h, hipMemsetAsync(l.w_packed, 0, packed_floats * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(l.b_packed, 0, (size_t)((l.Npad + 31) & ~31) * sizeof(float), h->stream));
+        a.w_ref = l.w_ref; a.b_ref = l.b_ref; a.w_packed = l.w_packed; a.b_packed = l.b_packed;
+        launch_fold_pack(a, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->folded = true;
+    return 0;
+}
+
+int yn_get_folded(yn_handle* h, const char* conv_key, float* host_weight, float* host_bias)
+{
+    if (!h) return 1;
+    if (!h->folded) return fail(h, "yn_get_folded before yn_fold_bn");
+    auto it = h->by_conv.find(conv_key);
+    if (it == h->by_conv.end()) return fail(h, "unknown conv '%s'", conv_key);
+    const Layer& l = h->layers[it->second];
+    HIPCHK(h, hipMemcpyAsync(host_weight, l.w_ref, l.w_numel * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(host_bias, l.b_ref, (size_t)l.cout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- network -----------------------------------------------------------------------------------
+int yn_forward_raw(yn_handle* h, const float* x_dev, int B, float* head_s8, float* head_s16, float* head_s32)
+{
+    if (!h) return 1;
+    if (check_ready(h, B)) return 1;
+    if (ensure_arena(h, B, h->grid.S)) return 1;
+    float* const heads[3] = {head_s8, head_s16, head_s32};
+    std::vector<uintptr_t> key = {1, (uintptr_t)B, (uintptr_t)h->grid.S, (uintptr_t)x_dev, (uintptr_t)head_s8, (uintptr_t)head_s16, (uintptr_t)head_s32};
+    return run_maybe_graph(h, key, [&]() { return run_network(h, x_dev, B, heads); });
+}
+
+int yn_score_full(yn_handle* h, const float* h8, const float* h16, const float* h32, int B, float* all_bbox, float* all_class)
+{
+    if (!h) return 1;
+    const float* const heads[3] = {h8, h16, h32};
+    launch_score_full(heads, h->grid, B, all_bbox, all_class, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_decode_boxes(yn_handle* h, const float* txtytwth, int B, float* xyxy)
+{
+    if (!h) return 1;
+    launch_decode_boxes(txtytwth, h->grid, B, xyxy, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_create_grid(yn_handle* h, int input_size, float* grid, float* stride, float* anchor)
+{
+    if (!h) return 1;
+    if (input_size <= 0 || input_size % 32) return fail(h, "input_size must be a positive multiple of 32");
+    const int A = h->cfg.num_anchors;
+    size_t cell = 0;
+    for (int s = 0; s < 3; ++s) {
+        const int st = 8 << s, w = input_size / st;
+        for (int y = 0; y < w; ++y)
+            for (int x = 0; x < w; ++x, ++cell) {
+                grid[cell * 2 + 0] = (float)x; grid[cell * 2 + 1] = (float)y;      // (x, y): models/yolo_nano.py:96
+                for (int a = 0; a < A; ++a) {
+                    stride[(cell * A + a) * 2 + 0] = (float)st; stride[(cell * A + a) * 2 + 1] = (float)st;
+                    anchor[(cell * A + a) * 2 + 0] = h->cfg.anchors[(s * A + a) * 2 + 0];
+                    anchor[(cell * A + a) * 2 + 1] = h->cfg.anchors[(s * A + a) * 2 + 1];
+                }
+            }
+    }
+    return 0;
+}
+
+// ---- post-processing ---------------------------------------------------------------------------
+int yn_nms(yn_handle* h, const float* dets, const float* scores, int n, float nms_thresh, int diou, int32_t* keep, int32_t* count)
+{
+    if (!h) return 1;
+    if (n < 0) return fail(h, "yn_nms: negative n");
+    if (ensure_post(h, 1, n > 0 ? n : 1, 1)) return 1;
+    launch_nms_single(dets, scores, n, nms_thresh, diou, h->nms.state, keep, count, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_postprocess(yn_handle* h, const float* all_local, const float* all_conf, int B, int N, int C,
+                   float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count)
+{
+    if (!h) return 1;
+    if (B <= 0 || N < 0 || C <= 0) return fail(h, "yn_postprocess: bad sizes B=%d N=%d C=%d", B, N, C);
+    if (N == 0) { HIPCHK(h, hipMemsetAsync(count, 0, sizeof(int32_t) * B, h->stream)); return 0; }
+    if (ensure_post(h, B, N, C)) return 1;
+    launch_argmax_cand(all_local, all_conf, B, N, C, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->stream);
+    launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, N, C, h->cfg.nms_thresh, h->cfg.diou_nms, h->nms,
+                        out_boxes, out_scores, out_cls, out_index, count, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* out_scores, int32_t* out_cls,
+             int32_t* out_index, int32_t* count)
+{
+    if (!h) return 1;
+    if (check_ready(h, B)) return 1;
+    const GridInfo g = h->grid;
+    if (ensure_arena(h, B, g.S) || ensure_post(h, B, g.N, g.C) || ensure_heads(h, B)) return 1;
+    std::vector<uintptr_t> key = {2, (uintptr_t)B, (uintptr_t)g.S, (uintptr_t)x_dev, (uintptr_t)out_boxes, (uintptr_t)out_scores,
+                                  (uintptr_t)out_cls, (uintptr_t)out_index, (uintptr_t)count};
+    return run_maybe_graph(h, key, [&]() {
+        float* const heads[3] = {h->heads_int[0], h->heads_int[1], h->heads_int[2]};
+        if (run_network(h, x_dev, B, heads)) return 1;
+        const float* const ch[3] = {heads[0], heads[1], heads[2]};
+        {
+            set_last_kernel_name("decode_kernel<false>");
+            Bracket br(h, "decode", 0.0, 4.0 * B * ((double)(g.N / g.A) * h->head_ch + 6.0 * g.N));
+            launch_decode_cand(ch, g, B, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->stream);
+        }
+        {
+            set_last_kernel_name("bucket_kernel+nms_kernel+compact_kernel");
+            Bracket br(h, "nms", 0.0, 4.0 * B * 12.0 * g.N);
+            launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, g.N, g.C, h->cfg.nms_thresh, h->cfg.diou_nms, h->nms,
+                                out_boxes, out_scores, out_cls, out_index, count, h->stream);
+        }
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    });
+}
+
+// ---- single operators ----------------------------------------------------------------------------
+namespace {
+struct TmpLayer {
+    Layer l;
+    yn_handle* h;
+    int rc = 0;
+    TmpLayer(yn_handle* h_, int kind, int cin, int cout, int stride, int act, const float* w, const float* bias) : h(h_)
+    {
+        l.name = "op"; l.kind = kind; l.cin = cin; l.cout = cout; l.stride = stride; l.act = act;
+        FoldArgs a{};
+        a.w = w; a.b = bias; a.eps = 1e-5f; a.Cout = cout; a.Cin = cin;
+        size_t packed;
+        if (kind == K_DW) { a.kind = 1; a.kk = 9; packed = (size_t)9 * cout; l.Npad = cout; l.Kp = 9; }
+        else if (kind == K_STEM) { a.kind = 2; a.kk = 9; packed = (size_t)27 * cout; l.Npad = cout; l.Kp = 27; }
+        else { a.kind = 0; a.kk = kind == K_DENSE3 ? 9 : 1; const int K = cin * a.kk; l.Kp = (K + 1) & ~1; l.Npad = (cout + 31) & ~31; packed = (size_t)l.Kp * l.Npad; }
+        a.Kp = l.Kp; a.Npad = l.Npad;
+        const size_t bfl = (size_t)((l.Npad + 31) & ~31);
+        if (hipMalloc((void**)&l.w_packed, packed * sizeof(float)) != hipSuccess || hipMalloc((void**)&l.b_packed, bfl * sizeof(float)) != hipSuccess) { rc = 1; return; }
+        (void)hipMemsetAsync(l.w_packed, 0, packed * sizeof(float), h->stream);
+        (void)hipMemsetAsync(l.b_packed, 0, bfl * sizeof(float), h->stream);
+        a.w_packed = l.w_packed; a.b_packed = l.b_packed;
+        launch_fold_pack(a, h->stream);
+    }
+    ~TmpLayer()
+    {
+        (void)hipStreamSynchronize(h->stream);
+        if (l.w_packed) (void)hipFree(l.w_packed);
+        if (l.b_packed) (void)hipFree(l.b_packed);
+    }
+};
+}  // namespace
+
+int yn_op_dwconv3x3(yn_handle* h, const float* x, int B, int H, int W, int C, int stride, const float* w, const float* bias, int act, float* y)
+{
+    if (!h) return 1;
+    if (C & 1) return fail(h, "yn_op_dwconv3x3: C must be even");
+    TmpLayer t(h, K_DW, C, C, stride, act, w, bias);
+    if (t.rc) return fail(h, "yn_op_dwconv3x3: out of memory");
+    run_dw(h, t.l, x, C, 0, B, H, W, y, C, 0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_pwconv(yn_handle* h, const float* x, int B, int H, int W, int Cin, int Cout, const float* w, const float* bias, int act, float* y)
+{
+    if (!h) return 1;
+    if (Cin & 1) return fail(h, "yn_op_pwconv: Cin must be even");
+    TmpLayer t(h, K_PW, Cin, Cout, 1, act, w, bias);
+    if (t.rc) return fail(h, "yn_op_pwconv: out of memory");
+    run_pw(h, t.l, x, Cin, 0, (long)B * H * W, y, Cout, 0, nullptr, 0, 0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_conv3x3(yn_handle* h, const float* x, const float* x2, int resample, int B, int H, int W, int Cin, int Cout,
+                  const float* w, const float* bias, int act, float* y)
+{
+    if (!h) return 1;
+    if (Cin % 32) return fail(h, "yn_op_conv3x3: Cin must be a multiple of 32");
+    if (resample && !x2) return fail(h, "yn_op_conv3x3: resample without x2");
+    TmpLayer t(h, K_DENSE3, Cin, Cout, 1, act, w, bias);
+    if (t.rc) return fail(h, "yn_op_conv3x3: out of memory");
+    run_c3(h, t.l, x, x2, resample, B, H, W, y);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_stem(yn_handle* h, const float* x, int B, int H, int W, int Cout, const float* w, const float* bias, int act, float* y)
+{
+    if (!h) return 1;
+    if (Cout != 24) return fail(h, "yn_op_stem: Cout must be 24");
+    TmpLayer t(h, K_STEM, 3, Cout, 2, act, w, bias);
+    if (t.rc) return fail(h, "yn_op_stem: out of memory");
+    launch_stem(x, B, H, W, t.l.w_packed, t.l.b_packed, Cout, act, y, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_maxpool3x3s2(yn_handle* h, const float* x, int B, int H, int W, int C, float* y)
+{
+    if (!h) return 1;
+    if (C % 4) return fail(h, "yn_op_maxpool3x3s2: C must be a multiple of 4");
+    launch_maxpool(x, B, H, W, C, y, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, int H, int W, float* y)
+{
+    if (!h) return 1;
+    if (!h->folded) return fail(h, "yn_op_shuffle_block before yn_fold_bn");
+    const std::string P = block;
+    if (!h->by_name.count(P + ".b2.pw1")) return fail(h, "unknown block '%s'", block);
+    const bool s2 = h->by_name.count(P + ".b1.dw") != 0;
+    const Layer& pw1 = L(h, P + ".b2.pw1");
+    const int bf = pw1.cout, C = 2 * bf;
+    const int Cin = s2 ? pw1.cin : C;
+    const int Ho = s2 ? (H - 1) / 2 + 1 : H, Wo = s2 ? (W - 1) / 2 + 1 : W;
+    const long Mi = (long)B * H * W, Mo = (long)B * Ho * Wo;
+    float *t1 = nullptr, *t2 = nullptr, *tdw = nullptr, *tb1 = nullptr;
+    HIPCHK(h, hipMalloc((void**)&t1, Mi * bf * sizeof(float)));
+    HIPCHK(h, hipMalloc((void**)&t2, Mo * bf * sizeof(float)));
+    if (s2) {
+        HIPCHK(h, hipMalloc((void**)&tdw, Mo * Cin * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&tb1, Mo * bf * sizeof(float)));
+        run_dw(h, L(h, P + ".b1.dw"), x, Cin, 0, B, H, W, tdw, Cin, 0);
+        run_pw(h, L(h, P + ".b1.pw"), tdw, Cin, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+        run_pw(h, pw1, x, Cin, 0, Mi, t1, bf, 0, nullptr, 0, 0);
+        run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, H, W, t2, bf, 0);
+        run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, y, C, 0, tb1, bf, 0);
+    } else {
+        run_pw(h, pw1, x, C, bf, Mi, t1, bf, 0, nullptr, 0, 0);
+        run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, H, W, t2, bf, 0);
+        run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, y, C, 0, x, C, 0);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(t1); (void)hipFree(t2);
+    if (tdw) (void)hipFree(tdw);
+    if (tb1) (void)hipFree(tb1);
+    return 0;
+}
+
+int yn_op_nchw_to_nhwc(yn_handle* h, const float* x, int B, int C, int H, int W, float* y)
+{
+    if (!h) return 1;
+    launch_nchw_to_nhwc(x, B, C, H, W, y, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W, float* y)
+{
+    if (!h) return 1;
+    launch_nhwc_to_nchw(x, B, C, H, W, y, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+int yn_profile_enable(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    h->profiling = enable != 0;
+    h->prof.clear();
+    h->event_next = 0;
+    return 0;
+}
+
+int yn_profile_count(yn_handle* h) { return h ? (int)h->prof.size() : -1; }
+
+int yn_profile_get(yn_handle* h, int i, char* name, int name_cap, char* kernel, int kernel_cap, float* ms,
+                   double* alg_flops, double* alg_bytes)
+{
+    if (!h) return 1;
+    if (i < 0 || i >= (int)h->prof.size()) return fail(h, "yn_profile_get: index %d out of range", i);
+    const ProfRec& r = h->prof[i];
+    HIPCHK(h, hipEventSynchronize(r.e1));
+    float t = 0.0f;
+    HIPCHK(h, hipEventElapsedTime(&t, r.e0, r.e1));
+    if (name && name_cap > 0) { strncpy(name, r.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (kernel && kernel_cap > 0) { strncpy(kernel, r.kernel.c_str(), kernel_cap - 1); kernel[kernel_cap - 1] = 0; }
+    if (ms) *ms = t;
+    if (alg_flops) *alg_flops = r.flops;
+    if (alg_bytes) *alg_bytes = r.bytes;
+    return 0;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,81 @@
+// yn_internal.h — shared declarations between the C-ABI layer (yn_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ynk {
+
+// ---- GEMM-shaped convolutions (pointwise 1x1 and dense 3x3) on the f32 MFMA ----------------------
+// A operand = activations, NHWC: row m (= pixel) has K contiguous floats at in + m*in_ld + in_off.
+// B operand = folded weights packed k-pair interleaved: Wp[(k/2)][n][k&1], n in [0,Npad), zero padded.
+struct GemmArgs {
+    const float* in;   int in_ld;   int in_off;
+    const float* in2;  int resample;            // conv3x3 only: 0 none, 1 += up2(in2), 2 += down2(in2)
+    int H, W;                                   // conv3x3 only: spatial extent (M = B*H*W)
+    const float* Wp;   const float* bias;       // [Kp/2][Npad][2], [Npad]
+    float* out;        int out_ld;  int out_off;
+    const float* pass; int pass_ld; int pass_off; // shuffle mode: out[m][2n] = pass[m][n], out[m][2n+1] = res
+    int M, K, N, Npad, act;
+};
+
+struct DwArgs {
+    const float* in;  int in_ld;  int in_off;
+    const float* w;   const float* bias;        // [9][C], [C]
+    float* out;       int out_ld; int out_off;
+    int B, H, W, C, stride, act;                // H,W = input extent
+};
+
+const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
+void set_last_kernel_name(const char* n);
+void launch_pw(const GemmArgs& a, hipStream_t s);
+void launch_conv3x3(const GemmArgs& a, hipStream_t s);
+void launch_dw(const DwArgs& a, hipStream_t s);
+void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
+                 int Cout, int act, float* y, hipStream_t s);
+void launch_maxpool(const float* x, int B, int H, int W, int C, float* y, hipStream_t s);
+void launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, hipStream_t s);
+void launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, hipStream_t s);
+
+// ---- weight preparation (BN folding + packing), device side --------------------------------------
+struct FoldArgs {
+    const float* w; const float* b;             // raw conv weight [Cout][per_out], bias or null
+    const float* gamma; const float* beta; const float* mean; const float* var;  // null => no BN
+    float eps;
+    int Cout, Cin, kk;                          // kk = k*k taps; per_out = Cin_per_group*kk
+    int kind;                                   // 0 pw/dense (GEMM pack), 1 depthwise, 2 stem
+    int Kp, Npad;                               // GEMM pack geometry
+    float* w_ref; float* b_ref;                 // folded, reference layout (for yn_get_folded) or null
+    float* w_packed; float* b_packed;
+};
+void launch_fold_pack(const FoldArgs& a, hipStream_t s);
+
+// ---- score head / NMS ---------------------------------------------------------------------------
+struct GridInfo {
+    int S, C, A, N;
+    int hw[3], w[3], off[3];                    // cells per scale, width per scale, candidate offset
+    float anchors[18];
+};
+
+void launch_score_full(const float* const heads[3], const GridInfo& g, int B, float* all_bbox, float* all_class, hipStream_t s);
+void launch_decode_boxes(const float* txtytwth, const GridInfo& g, int B, float* xyxy, hipStream_t s);
+// candidates from raw heads: per candidate best score / class / box
+void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
+                        float* boxes, float* scores, int32_t* cls, hipStream_t s);
+// candidates from (all_local, all_conf): argmax + threshold (models/yolo_nano.py:253-261)
+void launch_argmax_cand(const float* all_local, const float* all_conf, int B, int N, int C, float conf_thresh,
+                        float* boxes, float* scores, int32_t* cls, hipStream_t s);
+struct NmsWork {                                // per-handle scratch, sized for max_batch*N
+    int32_t* seg_count;                         // [B][C]
+    int32_t* seg_off;                           // [B][C]
+    int32_t* bucket;                            // [B][N]  candidate ids grouped by class
+    int32_t* keep;                              // [B][N]  flags
+    int32_t* state;                             // [B][N]  scratch for large segments
+};
+void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
+                         float nms_thresh, int diou, const NmsWork& wk,
+                         float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
+                         hipStream_t s);
+void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
+                       int32_t* state_scratch, int32_t* keep, int32_t* count, hipStream_t s);
+
+}  // namespace ynk

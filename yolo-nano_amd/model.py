@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's ``YOLONano`` (models/yolo_nano.py:12-376).
+
+Same constructor, attributes, helper methods, return types and ``state_dict`` key
+set (469 keys) as the reference, so ``eval.py`` / ``test.py`` / ``benchmark.py``
+style callers drop in; the arithmetic runs in libyolonano_hip.so through the C ABI
+(include/yolonano_hip.h).  torch is plumbing here: parameter storage, device
+memory, streams.  There is no CPU fallback — without the HIP library or a GPU the
+model refuses to run.
+
+Differences from the reference, on purpose:
+  * ``forward_batch(x)`` finishes every image of the batch on the device; the
+    reference's ``forward`` only finishes image 0 (models/yolo_nano.py:365-367) —
+    ``forward`` keeps that behaviour.
+  * ``backbone='0.5x'`` (and 1.5x/2.0x) are accepted; the reference prints and
+    exits (models/yolo_nano.py:35-37) although its backbone supports them.
+  * equal NMS scores inside a class: higher candidate index first (the reference
+    inherits numpy's unstable argsort order).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import arch
+from .capi import Handle, YnError
+
+
+# ---- parameter containers with the reference's module tree (keys must match exactly) -----------
+class Conv(nn.Module):
+    """utils/modules.py:8-18 — Conv2d(bias=True) + BatchNorm2d + LeakyReLU(0.1)."""
+
+    def __init__(self, c1, c2, k, s=1, p=0, d=1, g=1, leaky=True):
+        super().__init__()
+        self.convs = nn.Sequential(
+            nn.Conv2d(c1, c2, k, stride=s, padding=p, dilation=d, groups=g),
+            nn.BatchNorm2d(c2),
+            nn.LeakyReLU(0.1, inplace=True) if leaky else nn.Identity())
+
+    def forward(self, x):
+        raise YnError("sub-modules are parameter containers; run the model through YOLONano.forward (HIP path)")
+
+
+class ShuffleV2Block(nn.Module):
+    """backbone/shufflenetv2.py:31-67 (parameter layout only)."""
+
+    def __init__(self, inp, oup, stride):
+        super().__init__()
+        if not (1 <= stride <= 3):
+            raise ValueError("illegal stride value")
+        self.stride = stride
+        bf = oup // 2
+        assert (stride != 1) or (inp == bf << 1)
+        if stride > 1:
+            self.branch1 = nn.Sequential(
+                nn.Conv2d(inp, inp, 3, stride, 1, bias=False, groups=inp), nn.BatchNorm2d(inp),
+                nn.Conv2d(inp, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True))
+        else:
+            self.branch1 = nn.Sequential()
+        self.branch2 = nn.Sequential(
+            nn.Conv2d(inp if stride > 1 else bf, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True),
+            nn.Conv2d(bf, bf, 3, stride, 1, bias=False, groups=bf), nn.BatchNorm2d(bf),
+            nn.Conv2d(bf, bf, 1, 1, 0, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        raise YnError("sub-modules are parameter containers; run the model through YOLONano.forward (HIP path)")
+
+
+class ShuffleNetV2(nn.Module):
+    """backbone/shufflenetv2.py:81-129 (parameter layout only)."""
+
+    def __init__(self, model_size="1.0x"):
+        super().__init__()
+        if model_size not in arch.STAGE_CH:
+            raise NotImplementedError(model_size)
+        self.model_size = model_size
+        self.stage_repeats = list(arch.STAGE_REPEATS)
+        self._stage_out_channels = [arch.STEM_CH] + list(arch.STAGE_CH[model_size])
+        self.conv1 = nn.Sequential(nn.Conv2d(3, arch.STEM_CH, 3, 2, 1, bias=False), nn.BatchNorm2d(arch.STEM_CH), nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        cin = arch.STEM_CH
+        for name, rep, cout in zip(("stage2", "stage3", "stage4"), self.stage_repeats, arch.STAGE_CH[model_size]):
+            seq = [ShuffleV2Block(cin, cout, 2)] + [ShuffleV2Block(cout, cout, 1) for _ in range(rep - 1)]
+            setattr(self, name, nn.Sequential(*seq))
+            cin = cout
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        """backbone/shufflenetv2.py:131-154"""
+        for name, m in self.named_modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, 0, 0.01 if "first" in name else 1.0 / m.weight.shape[1])
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0.0001)
+                nn.init.constant_(m.running_mean, 0)
+
+    def forward(self, x):
+        raise YnError("sub-modules are parameter containers; run the model through YOLONano.forward (HIP path)")
+
+
+def shufflenetv2(model_size="1.0x", pretrained=False, **kwargs):
+    """backbone/shufflenetv2.py:170-182.  There is no network here, so `pretrained` weights cannot
+    be downloaded; load a state dict instead."""
+    if pretrained:
+        raise YnError("pretrained ImageNet weights need a download; load_state_dict() a checkpoint instead")
+    return ShuffleNetV2(model_size=model_size)
+
+
+def fuse_conv_bn(module):
+    """utils/fuse_conv_bn.py:25-53 — fold each BN into the Conv2d that precedes it among its siblings and
+    replace the BN by Identity.  The native path folds on the device anyway (yn_fold_bn); this keeps the
+    reference's API and produces the same fused state dict."""
+    last_conv, last_name = None, None
+    for name, child in module.named_children():
+        if isinstance(child, (nn.modules.batchnorm._BatchNorm, nn.SyncBatchNorm)):
+            if last_conv is None:
+                continue
+            with torch.no_grad():
+                w = last_conv.weight
+                b = last_conv.bias if last_conv.bias is not None else torch.zeros_like(child.running_mean)
+                f = child.weight / torch.sqrt(child.running_var + child.eps)
+                last_conv.weight = nn.Parameter(w * f.reshape([last_conv.out_channels, 1, 1, 1]))
+                last_conv.bias = nn.Parameter((b - child.running_mean) * f + child.bias)
+            module._modules[last_name] = last_conv
+            module._modules[name] = nn.Identity()
+            last_conv = None
+        elif isinstance(child, nn.Conv2d):
+            last_conv, last_name = child, name
+        else:
+            fuse_conv_bn(child)
+    return module
+
+
+class YOLONano(nn.Module):
+    def __init__(self, device, input_size=None, num_classes=20, trainable=False, conf_thresh=0.001, nms_thresh=0.50,
+                 anchor_size=None, backbone="1.0x", diou_nms=False):
+        super().__init__()
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.input_size = input_size
+        self.num_classes = num_classes
+        self.trainable = trainable
+        self.conf_thresh = conf_thresh
+        self.nms_thresh = nms_thresh
+        self.use_diou_nms = bool(diou_nms)
+        self.nms_processor = self.diou_nms if diou_nms else self.nms
+        self.bk = backbone
+        self.stride = [8, 16, 32]
+        self.anchor_list = [[float(a), float(b)] for a, b in anchor_size]
+        self.anchor_size = torch.tensor(anchor_size).view(3, len(anchor_size) // 3, 2)
+        self.num_anchors = self.anchor_size.size(1)
+        if backbone not in arch.STAGE_CH:
+            raise YnError("unknown backbone %r; supported: %s" % (backbone, sorted(arch.STAGE_CH)))
+        self.grid_cell, self.stride_tensor, self.all_anchors_wh = self.create_grid(input_size)
+
+        self.backbone = shufflenetv2(model_size=backbone, pretrained=False)
+        c3, c4, c5 = arch.STAGE_CH[backbone]
+        self.conv1x1_0 = Conv(c3, 96, k=1)
+        self.conv1x1_1 = Conv(c4, 96, k=1)
+        self.conv1x1_2 = Conv(c5, 96, k=1)
+        self.smooth_0 = Conv(96, 96, k=3, p=1)
+        self.smooth_1 = Conv(96, 96, k=3, p=1)
+        self.smooth_2 = Conv(96, 96, k=3, p=1)
+        self.smooth_3 = Conv(96, 96, k=3, p=1)
+        hc = self.num_anchors * (1 + self.num_classes + 4)
+        for i in (1, 2, 3):
+            setattr(self, "head_det_%d" % i, nn.Sequential(
+                Conv(96, 96, k=3, p=1, g=96), Conv(96, 96, k=1), Conv(96, 96, k=3, p=1, g=96), Conv(96, 96, k=1),
+                nn.Conv2d(96, hc, 1)))
+        if self.trainable:
+            self.init_bias()
+        self._handle = None
+        self._handle_keys = None
+        self._sig = None
+        self._graph = False
+
+    def __deepcopy__(self, memo):
+        """deepcopy (utils/misc.py:70 ModelEMA) must not clone the native handle; the copy builds its own."""
+        import copy
+        saved = (self._handle, self._handle_keys, self._sig)
+        self._handle, self._handle_keys, self._sig = None, None, None
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                setattr(new, k, copy.deepcopy(v, memo))
+        finally:
+            self._handle, self._handle_keys, self._sig = saved
+        return new
+
+    # ---- reference helpers ------------------------------------------------------------------------
+    def init_bias(self):
+        """models/yolo_nano.py:77-83"""
+        bias_value = -torch.log(torch.tensor((1. - 0.01) / 0.01))
+        with torch.no_grad():
+            for i in (1, 2, 3):
+                getattr(self, "head_det_%d" % i)[-1].bias[..., :self.num_anchors].fill_(float(bias_value))
+
+    def create_grid(self, input_size):
+        """models/yolo_nano.py:86-112 -> (grid [1,HW,1,2], stride [1,HW,A,2], anchors [1,HW,A,2])"""
+        A = self.num_anchors
+        g, st, aw = [], [], []
+        for ind, s in enumerate(self.stride):
+            ws = hs = input_size // s
+            gy, gx = torch.meshgrid(torch.arange(hs), torch.arange(ws), indexing="ij")
+            g.append(torch.stack([gx, gy], dim=-1).float().view(1, hs * ws, 1, 2))
+            st.append(torch.ones([1, hs * ws, A, 2]) * s)
+            aw.append(self.anchor_size[ind].repeat(hs * ws, 1, 1))
+        dev = self.device if (self.device.type != "cuda" or torch.cuda.is_available()) else torch.device("cpu")
+        return (torch.cat(g, dim=1).to(dev), torch.cat(st, dim=1).to(dev), torch.cat(aw, dim=0).to(dev).unsqueeze(0))
+
+    def set_grid(self, input_size):
+        """models/yolo_nano.py:115-117"""
+        self.input_size = input_size
+        self.grid_cell, self.stride_tensor, self.all_anchors_wh = self.create_grid(input_size)
+        if self._handle is not None:
+            self._handle.set_grid(input_size)
+
+    # ---- native handle ------------------------------------------------------------------------------
+    def use_graph(self, on=True):
+        """hipGraph-capture the fixed-shape inference pipeline (BASELINE config 5)."""
+        self._graph = bool(on)
+        if self._handle is not None:
+            self._handle.use_graph(on)
+
+    def _state_signature(self, sd):
+        return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in sd.items())
+
+    def handle(self, batch=1):
+        """The yn_handle with the module's current weights loaded and folded."""
+        sd = self.state_dict()
+        first = next(iter(sd.values()))
+        if not first.is_cuda:
+            raise YnError("YOLONano parameters are on %s: the HIP path needs them on the GPU (model.to('cuda')); "
+                          "there is no CPU fallback" % first.device)
+        sig = self._state_signature(sd)
+        keys = tuple(sd.keys())
+        if self._handle is None or self._handle_keys != keys or self._handle.device != first.device:
+            if self._handle is not None:
+                self._handle.close()
+            self._handle = Handle(self.input_size, self.num_classes, self.anchor_list, self.bk, self.conf_thresh, self.nms_thresh,
+                                  self.use_diou_nms, max_batch=batch, device=first.device)
+            self._handle_keys = keys
+            self._handle.use_graph(self._graph)
+            self._sig = None
+        h = self._handle
+        if h.S != self.input_size:
+            h.set_grid(self.input_size)
+        h.set_thresholds(self.conf_thresh, self.nms_thresh, self.use_diou_nms)
+        if sig != self._sig:
+            for k, v in sd.items():
+                if not k.endswith("num_batches_tracked"):
+                    h.load_param(k, v)
+            h.fold_bn()
+            self._sig = sig
+        return h
+
+    # ---- decode / NMS helpers with the reference's signatures -----------------------------------------
+    def decode_xywh(self, txtytwth_pred):
+        """models/yolo_nano.py:120-136 (derived from the native xyxy decode)."""
+        xyxy = self.decode_boxes(txtytwth_pred)
+        cxy = (xyxy[..., :2] + xyxy[..., 2:]) / 2
+        wh = xyxy[..., 2:] - xyxy[..., :2]
+        return torch.cat([cxy, wh], -1)
+
+    def decode_boxes(self, txtytwth_pred):
+        """models/yolo_nano.py:139-156 : [B, HW, A, 4] -> [B, HW*A, 4] xyxy in pixels (yn_decode_boxes)."""
+        t = torch.as_tensor(txtytwth_pred)
+        h = self.handle()
+        return h.decode_boxes(t.to(h.device))
+
+    def nms(self, dets, scores):
+        """models/yolo_nano.py:159-188 : numpy [n,4], [n] -> list of kept indices in pick order (yn_nms)."""
+        return self._nms(dets, scores, False)
+
+    def diou_nms(self, dets, scores):
+        """models/yolo_nano.py:191-242"""
+        return self._nms(dets, scores, True)
+
+    def _nms(self, dets, scores, diou):
+        h = self.handle()
+        d = torch.as_tensor(np.ascontiguousarray(dets, dtype=np.float32)).to(h.device)
+        s = torch.as_tensor(np.ascontiguousarray(scores, dtype=np.float32)).to(h.device)
+        return h.nms(d, s, self.nms_thresh, diou).cpu().numpy().astype(np.int64).tolist()
+
+    def postprocess(self, all_local, all_conf):
+        """models/yolo_nano.py:245-279 : numpy [N,4], [N,C] -> (bboxes [K,4] f32, scores [K] f32, cls_inds [K] i64)."""
+        h = self.handle()
+        b = torch.as_tensor(np.ascontiguousarray(all_local, dtype=np.float32)).to(h.device)[None]
+        c = torch.as_tensor(np.ascontiguousarray(all_conf, dtype=np.float32)).to(h.device)[None]
+        out = h.postprocess(b, c)
+        return self._to_host(out, 0)
+
+    @staticmethod
+    def _to_host(out, b, k=None):
+        boxes, scores, cls, _, count = out
+        k = int(count[b].item()) if k is None else k
+        # fresh, writable, caller-owned arrays: callers rescale them in place (benchmark.py:69-71)
+        return (boxes[b, :k].cpu().numpy().copy(), scores[b, :k].cpu().numpy().copy(),
+                cls[b, :k].cpu().numpy().astype(np.int64))
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def forward_raw(self, x):
+        """Raw head tensors as the reference's hooks see them: three NCHW views [B, A(5+C), H, W]."""
+        h = self.handle(x.shape[0])
+        return [t.permute(0, 3, 1, 2) for t in h.forward_raw(x.float())]
+
+    def forward_batch(self, x):
+        """Eval-mode forward for EVERY image: list of (bboxes, scores, cls_inds) numpy triples."""
+        h = self.handle(x.shape[0])
+        out = h.infer(x.float())
+        counts = out[4].cpu().tolist()
+        return [self._to_host(out, b, counts[b]) for b in range(x.shape[0])]
+
+    def forward(self, x, target=None):
+        if self.trainable:
+            raise YnError("training step (models/yolo_nano.py:332-358) is not built yet in this round; "
+                          "set model.trainable = False for inference")
+        h = self.handle(x.shape[0])
+        out = h.infer(x.float())
+        return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
