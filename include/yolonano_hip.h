@@ -54,7 +54,7 @@ int  yn_create(const yn_config* cfg, yn_handle** out);          /* YOLONano.__in
 void yn_destroy(yn_handle* h);
 const char* yn_last_error(yn_handle* h);
 int  yn_set_grid(yn_handle* h, int input_size);                 /* YOLONano.set_grid            :115 */
-int  yn_set_stream(yn_handle* h, void* stream);
+int  yn_set_stream(yn_handle* h, void* stream);                /* drains the previous stream first  */
 int  yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int diou_nms);
 int  yn_num_predictions(yn_handle* h);                          /* N for the current grid            */
 int  yn_use_graph(yn_handle* h, int enable);                    /* hipGraph-capture yn_infer/forward */

@@ -317,35 +317,162 @@ __device__ void nms_segment_mem(const float* __restrict__ boxes, const float* __
     (void)sh;
 }
 
-__device__ void nms_segment(const float* boxes, const float* scores, const int32_t* ids, int n, float thresh, int diou,
-                            int32_t* keep_flags, int32_t* pick_list, int32_t* pick_count, int32_t* state, float* sh)
+// -------------------------------------------------------------------------------------------------
+// Greedy NMS for one segment by ONE workgroup (256 threads): sort + 64-wide chunk resolve.
+//   1. keys (score bits << 32 | id) are bitonic-sorted in LDS, descending  => pick order.
+//   2. chunk c = sorted items [64c, 64c+64): wave 0 builds the 64x64 suppression bit-matrix of the
+//      chunk (lane i vs lanes t > i), then resolves it serially with scalar readlanes — exactly the
+//      reference's while-loop restricted to the chunk;
+//   3. every thread tests the not-yet-removed items behind the chunk against the chunk's kept boxes.
+// The serial depth is n/64 chunk rounds instead of one round per kept box.
+// LDS carve (dynamic): keys[P] u64 | removed[P] u8 | cbox[64] float4 | carea[64] | kbox[64] float4 | karea[64] | misc
+// -------------------------------------------------------------------------------------------------
+__device__ void nms_sorted_block(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ ids,
+                                 int n, int P, float thresh, int diou, int32_t* __restrict__ keep_flags,
+                                 int32_t* __restrict__ pick_list, int32_t* __restrict__ pick_count, unsigned char* lds)
 {
-    if (n <= 64) nms_segment_regs<1>(boxes, scores, ids, n, thresh, diou, keep_flags, pick_list, pick_count, sh);
-    else if (n <= 256) nms_segment_regs<4>(boxes, scores, ids, n, thresh, diou, keep_flags, pick_list, pick_count, sh);
-    else nms_segment_mem(boxes, scores, ids, n, thresh, diou, keep_flags, pick_list, pick_count, state, sh);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds);
+    unsigned char* removed = lds + (size_t)P * 8;
+    float4* cbox = reinterpret_cast<float4*>(lds + (size_t)P * 9);
+    float* carea = reinterpret_cast<float*>(cbox + 64);
+    float4* kbox = reinterpret_cast<float4*>(carea + 64);
+    float* karea = reinterpret_cast<float*>(kbox + 64);
+    int* misc = reinterpret_cast<int*>(karea + 64);          // [0] = kept in this chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int j = tid; j < P; j += 256) {
+        unsigned long long k = 0;                             // padding sorts to the end
+        if (j < n) {
+            const int id = ids ? ids[j] : j;
+            k = ((unsigned long long)order_bits(scores[id]) << 32) | (unsigned)id;
+        }
+        keys[j] = k;
+        removed[j] = 0;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += 256) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a + j;
+                const unsigned long long x = keys[a], y = keys[b];
+                const bool desc = (a & k) == 0;
+                if ((x < y) == desc) { keys[a] = y; keys[b] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    int picked = 0;
+    const int nchunks = (n + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        const int base = c << 6;
+        if (wave == 0) {
+            const int j = base + lane;
+            const bool in = j < n;
+            const bool valid = in && !removed[j];
+            const int id = in ? (int)(unsigned)(keys[j] & 0xffffffffu) : 0;
+            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) bx = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
+            const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+            cbox[lane] = bx;
+            carea[lane] = ar;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long alive0 = __ballot(valid);
+            unsigned long long mask = 0;
+            if (valid) {
+                for (int t = lane + 1; t < 64; ++t) {
+                    if (!((alive0 >> t) & 1ull)) continue;
+                    if (suppressed(bx, ar, cbox[t], carea[t], thresh, diou)) mask |= 1ull << t;
+                }
+            }
+            const unsigned mlo = (unsigned)(mask & 0xffffffffu), mhi = (unsigned)(mask >> 32);
+            unsigned long long alive = alive0, keepm = 0;
+            for (int i = 0; i < 64; ++i) {
+                if ((alive >> i) & 1ull) {
+                    keepm |= 1ull << i;
+                    const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)mlo, i);     // (unsigned): no sign extension
+                    const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)mhi, i);
+                    const unsigned long long mi = ((unsigned long long)hi_i << 32) | (unsigned long long)lo_i;
+                    alive &= ~mi;
+                }
+            }
+            const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
+            if ((keepm >> lane) & 1ull) {
+                kbox[rank] = bx;
+                karea[rank] = ar;
+                if (keep_flags) keep_flags[id] = 1;
+                if (pick_list) pick_list[picked + rank] = id;
+            }
+            if (lane == 0) misc[0] = __popcll(keepm);
+        }
+        __syncthreads();
+        const int nk = misc[0];
+        picked += nk;
+        if (nk > 0) {
+            for (int j = base + 64 + tid; j < n; j += 256) {
+                if (removed[j]) continue;
+                const int id = (int)(unsigned)(keys[j] & 0xffffffffu);
+                const float4 bj = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
+                const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+                for (int k = 0; k < nk; ++k)
+                    if (suppressed(kbox[k], karea[k], bj, aj, thresh, diou)) { removed[j] = 1; break; }
+            }
+        }
+        __syncthreads();
+    }
+    if (pick_count && tid == 0) *pick_count = picked;
 }
 
-__global__ __launch_bounds__(64) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                  const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
-                                                  const int32_t* __restrict__ bucket, int N, int C, float thresh, int diou,
-                                                  int32_t* __restrict__ keep, int32_t* __restrict__ state)
+__host__ __device__ inline int nms_pow2(int n) { int p = 64; while (p < n) p <<= 1; return p; }
+__host__ __device__ inline size_t nms_lds_bytes(int P) { return (size_t)P * 9 + 64 * 16 * 2 + 64 * 4 * 2 + 64; }
+
+#define YN_NMS_SMALL 1024
+#define YN_NMS_LARGE 8192
+
+// grid (C, B); handles the segments with n_lo < n <= n_hi (LDS sized for n_hi)
+__global__ __launch_bounds__(256) void nms_sorted_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                          const int32_t* __restrict__ bucket, int N, int C, float thresh, int diou,
+                                                          int32_t* __restrict__ keep, int n_lo, int n_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int n = seg_count[(size_t)b * C + c];
+    if (n <= n_lo || n > n_hi) return;
+    const int off = seg_off[(size_t)b * C + c];
+    nms_sorted_block(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, n, nms_pow2(n), thresh, diou,
+                     keep + (size_t)b * N, nullptr, nullptr, nms_lds);
+}
+
+// segments too large for LDS (n > YN_NMS_LARGE): one wavefront, state in global scratch (correct, slow, rare)
+__global__ __launch_bounds__(64) void nms_huge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                       const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                       const int32_t* __restrict__ bucket, int N, int C, float thresh, int diou,
+                                                       int32_t* __restrict__ keep, int32_t* __restrict__ state)
 {
     __shared__ float sh[8];
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
-    if (n == 0) return;
+    if (n <= YN_NMS_LARGE) return;
     const int off = seg_off[(size_t)b * C + c];
-    nms_segment(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, n, thresh, diou,
-                keep + (size_t)b * N, nullptr, nullptr, state + (size_t)b * N + off, sh);
+    nms_segment_mem(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, n, thresh, diou,
+                    keep + (size_t)b * N, nullptr, nullptr, state + (size_t)b * N + off, sh);
 }
 
-__global__ __launch_bounds__(64) void nms_single_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
-                                                         float thresh, int diou, int32_t* __restrict__ state,
-                                                         int32_t* __restrict__ keep, int32_t* __restrict__ count)
+__global__ __launch_bounds__(256) void nms_single_sorted_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
+                                                                 float thresh, int diou, int32_t* __restrict__ keep, int32_t* __restrict__ count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    if (n <= 0) { if (threadIdx.x == 0) *count = 0; return; }
+    nms_sorted_block(dets, scores, nullptr, n, nms_pow2(n), thresh, diou, nullptr, keep, count, nms_lds);
+}
+
+__global__ __launch_bounds__(64) void nms_single_huge_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
+                                                              float thresh, int diou, int32_t* __restrict__ state,
+                                                              int32_t* __restrict__ keep, int32_t* __restrict__ count)
 {
     __shared__ float sh[8];
-    if (n <= 0) { if (threadIdx.x == 0) *count = 0; return; }
-    nms_segment(dets, scores, nullptr, n, thresh, diou, nullptr, keep, count, state, sh);
+    nms_segment_mem(dets, scores, nullptr, n, thresh, diou, nullptr, keep, count, state, sh);
 }
 
 // kept candidates of image b, ascending candidate index (np.where(keep > 0), models/yolo_nano.py:274-277)
@@ -390,15 +517,36 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
                          hipStream_t s)
 {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_single_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
+        attr_set = true;
+    }
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.bucket, wk.keep);
-    hipLaunchKernelGGL(nms_kernel, dim3(C, B), dim3(64), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, diou, wk.keep, wk.state);
+    hipLaunchKernelGGL(nms_sorted_kernel, dim3(C, B), dim3(256), nms_lds_bytes(YN_NMS_SMALL), s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket,
+                       N, C, nms_thresh, diou, wk.keep, 0, YN_NMS_SMALL);
+    if (N > YN_NMS_SMALL)
+        hipLaunchKernelGGL(nms_sorted_kernel, dim3(C, B), dim3(256), nms_lds_bytes(YN_NMS_LARGE), s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket,
+                           N, C, nms_thresh, diou, wk.keep, YN_NMS_SMALL, YN_NMS_LARGE);
+    if (N > YN_NMS_LARGE)
+        hipLaunchKernelGGL(nms_huge_kernel, dim3(C, B), dim3(64), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, diou,
+                           wk.keep, wk.state);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
 
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
                        int32_t* state_scratch, int32_t* keep, int32_t* count, hipStream_t s)
 {
-    hipLaunchKernelGGL(nms_single_kernel, dim3(1), dim3(64), 0, s, dets, scores, n, thresh, diou, state_scratch, keep, count);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_single_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
+        attr_set = true;
+    }
+    if (n <= YN_NMS_LARGE)
+        hipLaunchKernelGGL(nms_single_sorted_kernel, dim3(1), dim3(256), nms_lds_bytes(nms_pow2(n > 0 ? n : 1)), s, dets, scores, n, thresh, diou, keep, count);
+    else
+        hipLaunchKernelGGL(nms_single_huge_kernel, dim3(1), dim3(64), 0, s, dets, scores, n, thresh, diou, state_scratch, keep, count);
 }
 
 }  // namespace ynk

@@ -528,6 +528,7 @@ int yn_set_stream(yn_handle* h, void* stream)
 {
     if (!h) return 1;
     if ((hipStream_t)stream != h->stream) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));        // the arena is shared: drain the old stream first
         for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         h->graphs.clear();
     }
