@@ -7,10 +7,7 @@
 //                        + :253-261 (argmax, threshold) fused: raw NHWC heads -> (box, best score, class)
 //   score_full_kernel    same front end, writing the reference's all_bbox [N,4] / all_class [N,C]
 //   argmax_cand_kernel   :253-261 from caller-provided (all_local, all_conf)
-//   bucket_kernel        groups the surviving candidates of one image by class (LDS histogram + scatter)
-//   nms_kernel           one wavefront per (image, class): greedy NMS by repeated wave-wide arg-max —
-//                        no sort; pick order == descending score, equal scores: higher index first
-//   compact_kernel       kept candidates in ascending candidate order (:274-277)
+//   bucket / sort / matrix / resolve / compact : exact per-class greedy NMS (see the block comment below)
 #include "yn_internal.h"
 
 namespace ynk {
@@ -43,55 +40,126 @@ __device__ __forceinline__ void decode_one(const GridInfo& g, int s, int cell, i
     }
 }
 
-template <bool FULL>
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned f32_order_bits(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One wavefront per grid cell: the cell's row of A*(1+C+4) logits is read once, coalesced (lane = class),
+// softmax max / sum / arg-max are wave reductions.  KMAX*64 >= C.
+template <bool FULL, int KMAX>
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
                                                       GridInfo g, int B, float conf_thresh,
                                                       float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
                                                       float* __restrict__ all_class)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * g.N) return;
-    const int b = (int)(i / g.N), n = (int)(i - (long)b * g.N);
-    int s, cell, a;
-    cand_location(g, n, s, cell, a);
-    const float* head = s == 0 ? h0 : (s == 1 ? h1 : h2);
+    const int lane = threadIdx.x & 63;
+    const int cells_per_image = g.N / g.A;
+    const long total_cells = (long)B * cells_per_image;
     const int HC = g.A * (5 + g.C);
-    const float* row = head + ((size_t)b * g.hw[s] + cell) * HC;
-    const float obj = sigmoid_f(row[a]);
-    const float* cl = row + g.A + a * g.C;
-    float mx = -INFINITY;
-    for (int c = 0; c < g.C; ++c) mx = fmaxf(mx, cl[c]);
-    float sum = 0.0f;
-    for (int c = 0; c < g.C; ++c) sum += expf(cl[c] - mx);
-    float best = -INFINITY;
-    int bi = 0;
-    for (int c = 0; c < g.C; ++c) {
-        const float p = expf(cl[c] - mx) / sum * obj;
-        if (FULL) all_class[(size_t)i * g.C + c] = p;
-        if (p > best) { best = p; bi = c; }
+    for (long wc = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wc < total_cells; wc += (long)gridDim.x * 4) {
+        const int b = (int)(wc / cells_per_image);
+        const int cg = (int)(wc - (long)b * cells_per_image);            // cell index over the three scales
+        const int s = (cg >= g.hw[0] + g.hw[1]) ? 2 : ((cg >= g.hw[0]) ? 1 : 0);
+        const int cell = cg - (s == 2 ? g.hw[0] + g.hw[1] : (s == 1 ? g.hw[0] : 0));
+        const float* head = s == 0 ? h0 : (s == 1 ? h1 : h2);
+        const float* row = head + ((size_t)b * g.hw[s] + cell) * HC;
+        for (int a = 0; a < g.A; ++a) {
+            const long i = (long)b * g.N + g.off[s] + cell * g.A + a;   // candidate index (models/yolo_nano.py:308-330)
+            const float obj = sigmoid_f(row[a]);
+            const float* cl = row + g.A + a * g.C;
+            float v[KMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = lane + 64 * k;
+                v[k] = c < g.C ? cl[c] : -INFINITY;
+                mx = fmaxf(mx, v[k]);
+            }
+            mx = wave_max_f(mx);
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = lane + 64 * k;
+                v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
+                sum += v[k];
+            }
+            sum = wave_sum_f(sum);
+            unsigned long long best = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int c = lane + 64 * k;
+                if (c < g.C) {
+                    const float p = v[k] / sum * obj;
+                    if (FULL) all_class[(size_t)i * g.C + c] = p;
+                    const unsigned long long key = ((unsigned long long)f32_order_bits(p) << 32) | (unsigned)(0x7fffffff - c);   // first max wins ties
+                    best = key > best ? key : best;
+                }
+            }
+            if (!FULL) best = wave_max_u64(best);
+            if (lane == 0) {
+                float box[4];
+                decode_one(g, s, cell, a, row + g.A * (1 + g.C) + a * 4, (float)g.S, box, true);
+                *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
+                if (!FULL) {
+                    const unsigned ub = (unsigned)(best >> 32);
+                    const float sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
+                    scores[i] = sc;
+                    cls[i] = (sc >= conf_thresh) ? (int)(0x7fffffff - (unsigned)(best & 0xffffffffu)) : -1;
+                }
+            }
+        }
     }
-    float box[4];
-    decode_one(g, s, cell, a, row + g.A * (1 + g.C) + a * 4, (float)g.S, box, true);
-    *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
-    if (!FULL) {
-        scores[i] = best;
-        cls[i] = (best >= conf_thresh) ? bi : -1;
-    }
+}
+
+template <bool FULL>
+static void launch_decode(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
+                          float* boxes, float* scores, int32_t* cls, float* all_class, hipStream_t s)
+{
+    const long cells = (long)B * (g.N / g.A);
+    long blocks = (cells + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (g.C <= 64) hipLaunchKernelGGL((decode_kernel<FULL, 1>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else if (g.C <= 128) hipLaunchKernelGGL((decode_kernel<FULL, 2>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else if (g.C <= 256) hipLaunchKernelGGL((decode_kernel<FULL, 4>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else hipLaunchKernelGGL((decode_kernel<FULL, 16>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
 }
 
 void launch_score_full(const float* const heads[3], const GridInfo& g, int B, float* all_bbox, float* all_class, hipStream_t s)
 {
-    const long total = (long)B * g.N;
-    hipLaunchKernelGGL(decode_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       heads[0], heads[1], heads[2], g, B, 0.0f, all_bbox, (float*)nullptr, (int32_t*)nullptr, all_class);
+    launch_decode<true>(heads, g, B, 0.0f, all_bbox, nullptr, nullptr, all_class, s);
 }
 
 void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
                         float* boxes, float* scores, int32_t* cls, hipStream_t s)
 {
-    const long total = (long)B * g.N;
-    hipLaunchKernelGGL(decode_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, (float*)nullptr);
+    launch_decode<false>(heads, g, B, conf_thresh, boxes, scores, cls, nullptr, s);
 }
 
 // YOLONano.decode_boxes: txtytwth [B, sumHW, A, 4] -> xyxy pixels [B, N, 4]
@@ -137,12 +205,27 @@ void launch_argmax_cand(const float* all_local, const float* all_conf, int B, in
                        all_local, all_conf, total, C, conf_thresh, boxes, scores, cls);
 }
 
-// -------------------------------------------------------------------------------------------------
-// Bucket the valid candidates of image b by class.  One workgroup per image; histogram and cursors in LDS.
-// -------------------------------------------------------------------------------------------------
+// =================================================================================================
+// Per-class greedy NMS (models/yolo_nano.py:159-188, 263-272), exact, in five kernels:
+//   bucket   per image: class histogram -> segment offsets, scatter candidate ids, tile offsets
+//   sort     per (image, class) segment: bitonic sort of (score, id) keys, descending
+//            == the reference's `scores.argsort()[::-1]` with the tie rule "higher index first";
+//            gathers the boxes into sorted order
+//   matrix   all segments, all 64x64 tiles (row chunk ri <= col chunk ci) in parallel over the whole
+//            chip: bit (r, t) = "sorted item r suppresses sorted item t" (float32 arithmetic == numpy's)
+//   resolve  one wavefront per segment walks the chunks in order: 64-step scalar resolve of the
+//            diagonal tile, then ORs the kept rows' words into the removed mask of later chunks
+//   compact  kept candidates in ascending candidate order (:274-277)
+// The O(n^2) IoU work is spread over all CUs; the serial part is n/64 short rounds per segment.
+// =================================================================================================
+typedef unsigned long long u64;
+
+__host__ __device__ inline int nms_pow2(int n) { int p = 64; while (p < n) p <<= 1; return p; }
+
 __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict__ cls, int N, int C,
                                                        int32_t* __restrict__ seg_count, int32_t* __restrict__ seg_off,
-                                                       int32_t* __restrict__ bucket, int32_t* __restrict__ keep)
+                                                       int32_t* __restrict__ tile_off, int32_t* __restrict__ bucket,
+                                                       int32_t* __restrict__ keep)
 {
     extern __shared__ int32_t lds[];            // hist[C], cursor[C]
     int32_t* hist = lds;
@@ -158,14 +241,18 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0;
+        int run = 0, tiles = 0;
         for (int c = 0; c < C; ++c) {
             const int h = hist[c];
             seg_count[(size_t)b * C + c] = h;
             seg_off[(size_t)b * C + c] = run;
+            tile_off[(size_t)b * (C + 1) + c] = tiles;
             cursor[c] = run;
             run += h;
+            const int T = (h + 63) >> 6;
+            tiles += T * (T + 1) / 2;
         }
+        tile_off[(size_t)b * (C + 1) + C] = tiles;
     }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -177,25 +264,10 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Greedy NMS for one segment, executed by ONE wavefront.
-// -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned order_bits(float f)
 {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // unsigned order == float order
-}
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
 }
 
 // true when box j must be REMOVED given kept box i  (reference keeps `ovr <= thresh`; NaN -> removed)
@@ -223,131 +295,34 @@ __device__ __forceinline__ bool suppressed(const float4 bi, float ai, const floa
     return !(ovr <= thresh);
 }
 
-// ids == nullptr: the segment is items 0..n-1 of (boxes, scores) themselves (yn_nms single-class entry)
-template <int T>
-__device__ void nms_segment_regs(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ ids,
-                                 int n, float thresh, int diou, int32_t* __restrict__ keep_flags,
-                                 int32_t* __restrict__ pick_list, int32_t* __restrict__ pick_count, float* sh)
+// ---- sort ------------------------------------------------------------------------------------------
+// keys live in LDS (KEYS_IN_LDS) or, for segments beyond the LDS capacity, in a global scratch that only
+// this workgroup touches (agent-scope relaxed accesses so that the CU's L1 never serves a stale key).
+template <bool KEYS_IN_LDS>
+__device__ __forceinline__ u64 key_load(u64* k, int i)
 {
-    const int lane = threadIdx.x & 63;
-    float4 bx[T];
-    float ar[T];
-    unsigned long long key[T];
-    int id[T];
-    bool alive[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int j = lane + 64 * t;
-        alive[t] = j < n;
-        id[t] = 0; key[t] = 0; ar[t] = 0.0f; bx[t] = make_float4(0, 0, 0, 0);
-        if (alive[t]) {
-            id[t] = ids ? ids[j] : j;
-            bx[t] = *reinterpret_cast<const float4*>(boxes + (size_t)id[t] * 4);
-            ar[t] = (bx[t].z - bx[t].x) * (bx[t].w - bx[t].y);
-            key[t] = ((unsigned long long)order_bits(scores[id[t]]) << 32) | (unsigned)id[t];
-        }
-    }
-    int picked = 0;
-    while (true) {
-        unsigned long long m = 0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) if (alive[t] && key[t] > m) m = key[t];
-        m = wave_max_u64(m);
-        if (m == 0) break;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (alive[t] && key[t] == m) {
-                sh[0] = bx[t].x; sh[1] = bx[t].y; sh[2] = bx[t].z; sh[3] = bx[t].w; sh[4] = ar[t];
-                alive[t] = false;
-                if (keep_flags) keep_flags[id[t]] = 1;
-                if (pick_list) pick_list[picked] = id[t];
-            }
-        }
-        ++picked;
-        __syncthreads();
-        const float4 bi = make_float4(sh[0], sh[1], sh[2], sh[3]);
-        const float ai = sh[4];
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-            if (alive[t] && suppressed(bi, ai, bx[t], ar[t], thresh, diou)) alive[t] = false;
-    }
-    if (pick_count && lane == 0) *pick_count = picked;
+    if (KEYS_IN_LDS) return k[i];
+    return __hip_atomic_load(k + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool KEYS_IN_LDS>
+__device__ __forceinline__ void key_store(u64* k, int i, u64 v)
+{
+    if (KEYS_IN_LDS) k[i] = v;
+    else __hip_atomic_store(k + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// arbitrary n: alive flags live in `state` (global scratch, n ints), data re-read each round (L2-resident)
-__device__ void nms_segment_mem(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ ids,
-                                int n, float thresh, int diou, int32_t* __restrict__ keep_flags,
-                                int32_t* __restrict__ pick_list, int32_t* __restrict__ pick_count,
-                                int32_t* __restrict__ state, float* sh)
+template <bool KEYS_IN_LDS>
+__device__ void sort_segment(const float* __restrict__ boxes, const float* __restrict__ scores, int32_t* __restrict__ ids, bool ids_valid,
+                             int n, int P, u64* keys, float4* __restrict__ sbox)
 {
-    const int lane = threadIdx.x & 63;
-    for (int j = lane; j < n; j += 64) state[j] = 1;
-    int picked = 0;
-    while (true) {
-        unsigned long long m = 0;
-        for (int j = lane; j < n; j += 64) {
-            if (state[j]) {
-                const int idj = ids ? ids[j] : j;
-                const unsigned long long k = ((unsigned long long)order_bits(scores[idj]) << 32) | (unsigned)idj;
-                if (k > m) m = k;
-            }
-        }
-        m = wave_max_u64(m);
-        if (m == 0) break;
-        const int win = (int)(unsigned)(m & 0xffffffffu);
-        const float4 bi = *reinterpret_cast<const float4*>(boxes + (size_t)win * 4);
-        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-        if (lane == 0) {
-            if (keep_flags) keep_flags[win] = 1;
-            if (pick_list) pick_list[picked] = win;
-        }
-        ++picked;
-        for (int j = lane; j < n; j += 64) {
-            if (state[j]) {
-                const int idj = ids ? ids[j] : j;
-                if (idj == win) { state[j] = 0; continue; }
-                const float4 bj = *reinterpret_cast<const float4*>(boxes + (size_t)idj * 4);
-                const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-                if (suppressed(bi, ai, bj, aj, thresh, diou)) state[j] = 0;
-            }
-        }
-    }
-    if (pick_count && lane == 0) *pick_count = picked;
-    (void)sh;
-}
-
-// -------------------------------------------------------------------------------------------------
-// Greedy NMS for one segment by ONE workgroup (256 threads): sort + 64-wide chunk resolve.
-//   1. keys (score bits << 32 | id) are bitonic-sorted in LDS, descending  => pick order.
-//   2. chunk c = sorted items [64c, 64c+64): wave 0 builds the 64x64 suppression bit-matrix of the
-//      chunk (lane i vs lanes t > i), then resolves it serially with scalar readlanes — exactly the
-//      reference's while-loop restricted to the chunk;
-//   3. every thread tests the not-yet-removed items behind the chunk against the chunk's kept boxes.
-// The serial depth is n/64 chunk rounds instead of one round per kept box.
-// LDS carve (dynamic): keys[P] u64 | removed[P] u8 | cbox[64] float4 | carea[64] | kbox[64] float4 | karea[64] | misc
-// -------------------------------------------------------------------------------------------------
-__device__ void nms_sorted_block(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ ids,
-                                 int n, int P, float thresh, int diou, int32_t* __restrict__ keep_flags,
-                                 int32_t* __restrict__ pick_list, int32_t* __restrict__ pick_count, unsigned char* lds)
-{
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds);
-    unsigned char* removed = lds + (size_t)P * 8;
-    float4* cbox = reinterpret_cast<float4*>(lds + (size_t)P * 9);
-    float* carea = reinterpret_cast<float*>(cbox + 64);
-    float4* kbox = reinterpret_cast<float4*>(carea + 64);
-    float* karea = reinterpret_cast<float*>(kbox + 64);
-    int* misc = reinterpret_cast<int*>(karea + 64);          // [0] = kept in this chunk
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
+    const int tid = threadIdx.x;
     for (int j = tid; j < P; j += 256) {
-        unsigned long long k = 0;                             // padding sorts to the end
+        u64 k = 0;                                          // padding sorts to the end
         if (j < n) {
-            const int id = ids ? ids[j] : j;
-            k = ((unsigned long long)order_bits(scores[id]) << 32) | (unsigned)id;
+            const int id = ids_valid ? ids[j] : j;
+            k = ((u64)order_bits(scores[id]) << 32) | (unsigned)id;
         }
-        keys[j] = k;
-        removed[j] = 0;
+        key_store<KEYS_IN_LDS>(keys, j, k);
     }
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
@@ -355,124 +330,187 @@ __device__ void nms_sorted_block(const float* __restrict__ boxes, const float* _
             for (int i = tid; i < (P >> 1); i += 256) {
                 const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int b = a + j;
-                const unsigned long long x = keys[a], y = keys[b];
+                const u64 x = key_load<KEYS_IN_LDS>(keys, a), y = key_load<KEYS_IN_LDS>(keys, b);
                 const bool desc = (a & k) == 0;
-                if ((x < y) == desc) { keys[a] = y; keys[b] = x; }
+                if ((x < y) == desc) { key_store<KEYS_IN_LDS>(keys, a, y); key_store<KEYS_IN_LDS>(keys, b, x); }
             }
             __syncthreads();
         }
     }
-    int picked = 0;
-    const int nchunks = (n + 63) >> 6;
-    for (int c = 0; c < nchunks; ++c) {
-        const int base = c << 6;
-        if (wave == 0) {
-            const int j = base + lane;
-            const bool in = j < n;
-            const bool valid = in && !removed[j];
-            const int id = in ? (int)(unsigned)(keys[j] & 0xffffffffu) : 0;
-            float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in) bx = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
-            const float ar = (bx.z - bx.x) * (bx.w - bx.y);
-            cbox[lane] = bx;
-            carea[lane] = ar;
-            __builtin_amdgcn_wave_barrier();
-            const unsigned long long alive0 = __ballot(valid);
-            unsigned long long mask = 0;
-            if (valid) {
-                for (int t = lane + 1; t < 64; ++t) {
-                    if (!((alive0 >> t) & 1ull)) continue;
-                    if (suppressed(bx, ar, cbox[t], carea[t], thresh, diou)) mask |= 1ull << t;
-                }
-            }
-            const unsigned mlo = (unsigned)(mask & 0xffffffffu), mhi = (unsigned)(mask >> 32);
-            unsigned long long alive = alive0, keepm = 0;
-            for (int i = 0; i < 64; ++i) {
-                if ((alive >> i) & 1ull) {
-                    keepm |= 1ull << i;
-                    const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)mlo, i);     // (unsigned): no sign extension
-                    const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)mhi, i);
-                    const unsigned long long mi = ((unsigned long long)hi_i << 32) | (unsigned long long)lo_i;
-                    alive &= ~mi;
-                }
-            }
-            const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
-            if ((keepm >> lane) & 1ull) {
-                kbox[rank] = bx;
-                karea[rank] = ar;
-                if (keep_flags) keep_flags[id] = 1;
-                if (pick_list) pick_list[picked + rank] = id;
-            }
-            if (lane == 0) misc[0] = __popcll(keepm);
-        }
-        __syncthreads();
-        const int nk = misc[0];
-        picked += nk;
-        if (nk > 0) {
-            for (int j = base + 64 + tid; j < n; j += 256) {
-                if (removed[j]) continue;
-                const int id = (int)(unsigned)(keys[j] & 0xffffffffu);
-                const float4 bj = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
-                const float aj = (bj.z - bj.x) * (bj.w - bj.y);
-                for (int k = 0; k < nk; ++k)
-                    if (suppressed(kbox[k], karea[k], bj, aj, thresh, diou)) { removed[j] = 1; break; }
-            }
-        }
-        __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        const int id = (int)(unsigned)(key_load<KEYS_IN_LDS>(keys, j) & 0xffffffffu);
+        ids[j] = id;
+        sbox[j] = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
     }
-    if (pick_count && tid == 0) *pick_count = picked;
 }
 
-__host__ __device__ inline int nms_pow2(int n) { int p = 64; while (p < n) p <<= 1; return p; }
-__host__ __device__ inline size_t nms_lds_bytes(int P) { return (size_t)P * 9 + 64 * 16 * 2 + 64 * 4 * 2 + 64; }
+#define YN_SORT_SMALL 1024
+#define YN_SORT_LARGE 16384
 
-#define YN_NMS_SMALL 1024
-#define YN_NMS_LARGE 8192
-
-// grid (C, B); handles the segments with n_lo < n <= n_hi (LDS sized for n_hi)
-__global__ __launch_bounds__(256) void nms_sorted_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                          const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
-                                                          const int32_t* __restrict__ bucket, int N, int C, float thresh, int diou,
-                                                          int32_t* __restrict__ keep, int n_lo, int n_hi)
+// grid (C, B): segments with n_lo < n <= n_hi
+__global__ __launch_bounds__(256) void sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                    const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                    int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C,
+                                                    int n_lo, int n_hi, u64* __restrict__ gscratch, size_t gscratch_stride)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
     if (n <= n_lo || n > n_hi) return;
     const int off = seg_off[(size_t)b * C + c];
-    nms_sorted_block(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, n, nms_pow2(n), thresh, diou,
-                     keep + (size_t)b * N, nullptr, nullptr, nms_lds);
+    const int P = nms_pow2(n);
+    if (gscratch)
+        sort_segment<false>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, true, n, P,
+                            gscratch + (size_t)b * gscratch_stride, sbox + (size_t)b * N + off);
+    else
+        sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, true, n, P,
+                           reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
 }
 
-// segments too large for LDS (n > YN_NMS_LARGE): one wavefront, state in global scratch (correct, slow, rare)
-__global__ __launch_bounds__(64) void nms_huge_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                       const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
-                                                       const int32_t* __restrict__ bucket, int N, int C, float thresh, int diou,
-                                                       int32_t* __restrict__ keep, int32_t* __restrict__ state)
+// ---- suppression bit-matrix ------------------------------------------------------------------------
+// Segment with T = ceil(n/64) chunks owns T(T+1)/2 tiles, stored by bands: band ri holds 64 rows x (T-ri) words,
+// word (row, ci-ri) at  band_off(ri) + row*(T-ri) + (ci-ri),  band_off(ri) = 64*(ri*T - ri*(ri-1)/2).
+__device__ __forceinline__ size_t band_off(int ri, int T) { return (size_t)64 * ((size_t)ri * T - (size_t)ri * (ri - 1) / 2); }
+
+__device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh, int diou,
+                                            u64* __restrict__ M, float4* cbox)
 {
-    __shared__ float sh[8];
+    const int lane = threadIdx.x & 63;
+    const int jc = ci * 64 + lane;
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jc < n) cb = sb[jc];
+    cbox[lane] = cb;
+    __syncthreads();
+    const int jr = ri * 64 + lane;
+    u64 mask = 0;
+    if (jr < n) {
+        const float4 bx = sb[jr];
+        const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+        const int t0 = (ri == ci) ? lane + 1 : 0;
+        const int t1 = min(64, n - ci * 64);
+        for (int t = t0; t < t1; ++t) {
+            const float4 bt = cbox[t];
+            const float at = (bt.z - bt.x) * (bt.w - bt.y);
+            if (suppressed(bx, ar, bt, at, thresh, diou)) mask |= 1ull << t;
+        }
+    }
+    M[band_off(ri, T) + (size_t)lane * (T - ri) + (ci - ri)] = mask;
+    __syncthreads();
+}
+
+// grid (G, B), block 64: block g of image b walks tiles g, g+G, ... of that image
+__global__ __launch_bounds__(64) void matrix_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
+                                                     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ tile_off,
+                                                     int N, int C, float thresh, int diou, u64* __restrict__ M, size_t m_stride)
+{
+    __shared__ float4 cbox[64];
+    const int b = blockIdx.y;
+    const int32_t* toff = tile_off + (size_t)b * (C + 1);
+    const int total = toff[C];
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        int lo = 0, hi = C;                                 // largest c with toff[c] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
+        const int c = lo;
+        const int n = seg_count[(size_t)b * C + c];
+        const int T = (n + 63) >> 6;
+        int rem = t - toff[c], ri = 0;
+        while (rem >= T - ri) { rem -= T - ri; ++ri; }
+        const int ci = ri + rem;
+        matrix_tile(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh, diou,
+                    M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox);
+    }
+}
+
+// ---- resolve ---------------------------------------------------------------------------------------
+// One wavefront.  rem[w] (LDS) = removed mask of chunk w.  Returns the number of kept boxes.
+__device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, u64* rem)
+{
+    const int lane = threadIdx.x & 63;
+    const int T = (n + 63) >> 6;
+    for (int w = lane; w < T; w += 64) rem[w] = 0;
+    __syncthreads();
+    int picked = 0;
+    for (int ri = 0; ri < T; ++ri) {
+        const size_t boff = band_off(ri, T);
+        const int W = T - ri;
+        const int cnt = min(64, n - ri * 64);
+        const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        const u64 diag = M[boff + (size_t)lane * W];
+        const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+        u64 alive = validm & ~rem[ri];
+        u64 keepm = 0;
+        for (int i = 0; i < 64; ++i) {
+            if ((alive >> i) & 1ull) {
+                keepm |= 1ull << i;
+                const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
+                const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+                alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+            }
+        }
+        if ((keepm >> lane) & 1ull) {
+            const int id = ids[ri * 64 + lane];
+            if (keep_flags) keep_flags[id] = 1;
+            if (pick_list) pick_list[picked + __popcll(keepm & ((1ull << lane) - 1ull))] = id;
+        }
+        picked += __popcll(keepm);
+        // later chunks: removed |= OR of the kept rows' words (lanes = column chunks => coalesced rows)
+        for (int w = 1 + lane; w < W; w += 64) {
+            u64 acc = rem[ri + w];
+            u64 km = keepm;
+            while (km) {
+                const int i = __ffsll((long long)km) - 1;
+                km &= km - 1;
+                acc |= M[boff + (size_t)i * W + w];
+            }
+            rem[ri + w] = acc;
+        }
+        __syncthreads();
+    }
+    return picked;
+}
+
+#define YN_RESOLVE_MAX_T 512            /* n <= 32768 per segment */
+
+__global__ __launch_bounds__(64) void resolve_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                      const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
+                                                      int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep)
+{
+    __shared__ u64 rem[YN_RESOLVE_MAX_T];
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
-    if (n <= YN_NMS_LARGE) return;
-    const int off = seg_off[(size_t)b * C + c];
-    nms_segment_mem(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, n, thresh, diou,
-                    keep + (size_t)b * N, nullptr, nullptr, state + (size_t)b * N + off, sh);
+    if (n == 0) return;
+    resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
+                    M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, rem);
 }
 
-__global__ __launch_bounds__(256) void nms_single_sorted_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
-                                                                 float thresh, int diou, int32_t* __restrict__ keep, int32_t* __restrict__ count)
+// ---- single-class entry (YOLONano.nms): one segment = items 0..n-1 ------------------------------------
+__global__ __launch_bounds__(256) void single_sort_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
+                                                           int32_t* __restrict__ ids, float4* __restrict__ sbox, u64* __restrict__ gscratch)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
-    if (n <= 0) { if (threadIdx.x == 0) *count = 0; return; }
-    nms_sorted_block(dets, scores, nullptr, n, nms_pow2(n), thresh, diou, nullptr, keep, count, nms_lds);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    if (gscratch) sort_segment<false>(dets, scores, ids, false, n, nms_pow2(n), gscratch, sbox);
+    else sort_segment<true>(dets, scores, ids, false, n, nms_pow2(n), reinterpret_cast<u64*>(sort_lds), sbox);
 }
 
-__global__ __launch_bounds__(64) void nms_single_huge_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
-                                                              float thresh, int diou, int32_t* __restrict__ state,
-                                                              int32_t* __restrict__ keep, int32_t* __restrict__ count)
+__global__ __launch_bounds__(64) void single_matrix_kernel(const float4* __restrict__ sbox, int n, float thresh, int diou, u64* __restrict__ M)
 {
-    __shared__ float sh[8];
-    nms_segment_mem(dets, scores, nullptr, n, thresh, diou, nullptr, keep, count, state, sh);
+    __shared__ float4 cbox[64];
+    const int T = (n + 63) >> 6;
+    const int total = T * (T + 1) / 2;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        int rem = t, ri = 0;
+        while (rem >= T - ri) { rem -= T - ri; ++ri; }
+        matrix_tile(sbox, n, T, ri, ri + rem, thresh, diou, M, cbox);
+    }
+}
+
+__global__ __launch_bounds__(64) void single_resolve_kernel(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                                             int32_t* __restrict__ pick_list, int32_t* __restrict__ count)
+{
+    __shared__ u64 rem[YN_RESOLVE_MAX_T];
+    const int picked = n > 0 ? resolve_segment(ids, n, M, nullptr, pick_list, rem) : 0;
+    if (threadIdx.x == 0) *count = picked;
 }
 
 // kept candidates of image b, ascending candidate index (np.where(keep > 0), models/yolo_nano.py:274-277)
@@ -512,41 +550,63 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
     if (threadIdx.x == 0) count[b] = base;
 }
 
+size_t nms_matrix_words_per_image(int N, int C)
+{
+    const size_t Tsum = (size_t)(N + 63) / 64 + C;          // sum_c ceil(n_c/64) <= N/64 + C
+    return 64 * (Tsum * (Tsum + 1) / 2);
+}
+
+static void set_sort_attr()
+{
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(single_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
+    done = true;
+}
+
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
                          float nms_thresh, int diou, const NmsWork& wk,
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
                          hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_single_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.bucket, wk.keep);
-    hipLaunchKernelGGL(nms_sorted_kernel, dim3(C, B), dim3(256), nms_lds_bytes(YN_NMS_SMALL), s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket,
-                       N, C, nms_thresh, diou, wk.keep, 0, YN_NMS_SMALL);
-    if (N > YN_NMS_SMALL)
-        hipLaunchKernelGGL(nms_sorted_kernel, dim3(C, B), dim3(256), nms_lds_bytes(YN_NMS_LARGE), s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket,
-                           N, C, nms_thresh, diou, wk.keep, YN_NMS_SMALL, YN_NMS_LARGE);
-    if (N > YN_NMS_LARGE)
-        hipLaunchKernelGGL(nms_huge_kernel, dim3(C, B), dim3(64), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, diou,
-                           wk.keep, wk.state);
+    set_sort_attr();
+    hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep);
+    float4* sbox = reinterpret_cast<float4*>(wk.sbox);
+    u64* M = reinterpret_cast<u64*>(wk.matrix);
+    hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                       N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0);
+    if (N > YN_SORT_SMALL)
+        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0);
+    if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
+        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride);
+    int G = 8192 / (B > 0 ? B : 1);
+    if (G < 64) G = 64;
+    if (G > 4096) G = 4096;
+    hipLaunchKernelGGL(matrix_kernel, dim3(G, B), dim3(64), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, diou, M, wk.matrix_stride);
+    hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(64), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
 
+// scratch: ids[n] int32, sbox[n] float4, M[nms_matrix_words_per_image(n,1)] u64 — all provided by the handle
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
-                       int32_t* state_scratch, int32_t* keep, int32_t* count, hipStream_t s)
+                       int32_t* ids_scratch, float* sbox_scratch, void* matrix_scratch, int32_t* keep, int32_t* count, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_single_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_lds_bytes(YN_NMS_LARGE));
-        attr_set = true;
+    set_sort_attr();
+    float4* sbox = reinterpret_cast<float4*>(sbox_scratch);
+    u64* M = reinterpret_cast<u64*>(matrix_scratch);
+    if (n > 0) {
+        const int P = nms_pow2(n);
+        if (P <= YN_SORT_LARGE) hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(256), (size_t)P * 8, s, dets, scores, n, ids_scratch, sbox, (u64*)nullptr);
+        else hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(256), 0, s, dets, scores, n, ids_scratch, sbox, M);
+        const int T = (n + 63) / 64;
+        int G = T * (T + 1) / 2;
+        if (G > 8192) G = 8192;
+        hipLaunchKernelGGL(single_matrix_kernel, dim3(G), dim3(64), 0, s, sbox, n, thresh, diou, M);
     }
-    if (n <= YN_NMS_LARGE)
-        hipLaunchKernelGGL(nms_single_sorted_kernel, dim3(1), dim3(256), nms_lds_bytes(nms_pow2(n > 0 ? n : 1)), s, dets, scores, n, thresh, diou, keep, count);
-    else
-        hipLaunchKernelGGL(nms_single_huge_kernel, dim3(1), dim3(64), 0, s, dets, scores, n, thresh, diou, state_scratch, keep, count);
+    hipLaunchKernelGGL(single_resolve_kernel, dim3(1), dim3(64), 0, s, ids_scratch, n, M, keep, count);
 }
 
 }  // namespace ynk

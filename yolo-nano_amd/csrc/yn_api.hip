@@ -74,7 +74,8 @@ struct yn_handle {
     float* cand_boxes = nullptr; float* cand_scores = nullptr; int32_t* cand_cls = nullptr;
     NmsWork nms{};
     size_t nms_cap = 0;           // elements B*N currently allocated
-    size_t nms_seg_cap = 0;       // B*C
+    size_t nms_seg_cap = 0;       // B*(C+1)
+    size_t nms_m_cap = 0;         // uint64 words of suppression matrix
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
     // graphs / profiling
@@ -228,30 +229,41 @@ float* arena_take(yn_handle* h, size_t floats)
 
 int ensure_post(yn_handle* h, int B, int N, int C)
 {
-    const size_t need = (size_t)B * N, need_seg = (size_t)B * C;
+    const size_t need = (size_t)B * N, need_seg = (size_t)B * (C + 1);
+    const size_t m_stride = nms_matrix_words_per_image(N, C);
+    const size_t need_m = m_stride * B;
     if (need > h->nms_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         void** ptrs[] = {(void**)&h->cand_boxes, (void**)&h->cand_scores, (void**)&h->cand_cls,
-                         (void**)&h->nms.bucket, (void**)&h->nms.keep, (void**)&h->nms.state};
+                         (void**)&h->nms.bucket, (void**)&h->nms.keep, (void**)&h->nms.sbox};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->cand_boxes, need * 4 * sizeof(float)));
         HIPCHK(h, hipMalloc((void**)&h->cand_scores, need * sizeof(float)));
         HIPCHK(h, hipMalloc((void**)&h->cand_cls, need * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.bucket, need * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.keep, need * sizeof(int32_t)));
-        HIPCHK(h, hipMalloc((void**)&h->nms.state, need * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.sbox, need * 4 * sizeof(float)));
         h->nms_cap = need;
         h->graphs.clear();
     }
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->nms.seg_count) HIPCHK(h, hipFree(h->nms.seg_count));
-        if (h->nms.seg_off) HIPCHK(h, hipFree(h->nms.seg_off));
+        void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off};
+        for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.tile_off, need_seg * sizeof(int32_t)));
         h->nms_seg_cap = need_seg;
         h->graphs.clear();
     }
+    if (need_m > h->nms_m_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->nms.matrix) { HIPCHK(h, hipFree(h->nms.matrix)); h->nms.matrix = nullptr; }
+        HIPCHK(h, hipMalloc(&h->nms.matrix, need_m * sizeof(unsigned long long)));
+        h->nms_m_cap = need_m;
+        h->graphs.clear();
+    }
+    h->nms.matrix_stride = m_stride;
     return 0;
 }
 
@@ -508,8 +520,8 @@ void yn_destroy(yn_handle* h)
         if (l.w_ref) (void)hipFree(l.w_ref);
         if (l.b_ref) (void)hipFree(l.b_ref);
     }
-    void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.state,
-                    h->nms.seg_count, h->nms.seg_off, h->heads_int[0]};
+    void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
+                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.matrix, h->heads_int[0]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -723,7 +735,7 @@ int yn_nms(yn_handle* h, const float* dets, const float* scores, int n, float nm
     if (!h) return 1;
     if (n < 0) return fail(h, "yn_nms: negative n");
     if (ensure_post(h, 1, n > 0 ? n : 1, 1)) return 1;
-    launch_nms_single(dets, scores, n, nms_thresh, diou, h->nms.state, keep, count, h->stream);
+    launch_nms_single(dets, scores, n, nms_thresh, diou, h->nms.bucket, h->nms.sbox, h->nms.matrix, keep, count, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

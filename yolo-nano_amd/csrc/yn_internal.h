@@ -64,18 +64,22 @@ void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, f
 // candidates from (all_local, all_conf): argmax + threshold (models/yolo_nano.py:253-261)
 void launch_argmax_cand(const float* all_local, const float* all_conf, int B, int N, int C, float conf_thresh,
                         float* boxes, float* scores, int32_t* cls, hipStream_t s);
-struct NmsWork {                                // per-handle scratch, sized for max_batch*N
+struct NmsWork {                                // per-handle scratch, sized for B*N candidates / B*C segments
     int32_t* seg_count;                         // [B][C]
     int32_t* seg_off;                           // [B][C]
-    int32_t* bucket;                            // [B][N]  candidate ids grouped by class
-    int32_t* keep;                              // [B][N]  flags
-    int32_t* state;                             // [B][N]  scratch for large segments
+    int32_t* tile_off;                          // [B][C+1]  first 64x64 tile of each segment, [C] = total
+    int32_t* bucket;                            // [B][N]    candidate ids grouped by class, then sorted by score
+    int32_t* keep;                              // [B][N]    flags
+    float*   sbox;                              // [B][N][4] boxes in sorted order
+    void*    matrix;                            // [B][matrix_stride] uint64 suppression bit-matrix tiles
+    size_t   matrix_stride;                     // words per image
 };
+size_t nms_matrix_words_per_image(int N, int C);
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
                          float nms_thresh, int diou, const NmsWork& wk,
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
                          hipStream_t s);
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
-                       int32_t* state_scratch, int32_t* keep, int32_t* count, hipStream_t s);
+                       int32_t* ids_scratch, float* sbox_scratch, void* matrix_scratch, int32_t* keep, int32_t* count, hipStream_t s);
 
 }  // namespace ynk
