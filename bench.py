@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer HIP-event timings (stderr)")
     return ap.parse_args()
 
 
@@ -160,10 +161,15 @@ def main():
                 h.profile_enable(True)                 # resets the record list
                 h.infer(x, out)
                 stream.synchronize()
-                for layer, kern, ms, fl, by in h.profile_records():
+                recs = h.profile_records()
+                for layer, kern, ms, fl, by in recs:
                     a = agg.setdefault(kern, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
                     a["ms"] += ms; a["launches"] += 1; a["flops"] += fl; a["bytes"] += by
             h.profile_enable(False)
+            if args.layers:
+                for layer, kern, ms, fl, by in recs:
+                    print("%-28s %-28s %8.1f us  %7.2f GFLOP %7.1f MB  %6.1f TF/s %7.1f GB/s" % (
+                        layer, kern, ms * 1e3, fl / 1e9, by / 1e6, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
             ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
             tot_ms = sum(a["ms"] for a in agg.values())
             for kern, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):

@@ -29,6 +29,7 @@ def _deps():
 
 def _compile(item):
     src, extra = item
+    extra = extra + os.environ.get("YN_EXTRA_FLAGS", "").split()      # experiment switches (-DYN_EXP_*)
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
     cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.check_call(cmd)

@@ -156,13 +156,42 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
         const int nq = krem >= 32 ? 8 : ((krem + 3) >> 2);
         const float* Ab = As + buf * KP * AS + (wm * 32 + l31) * 2;
         const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2;
-        for (int q = 0; q < nq; ++q) {
-            const float2 av = *reinterpret_cast<const float2*>(Ab + (2 * q + h) * AS);
+        if (nq == 8) {
+            // full chunk: fragments of step q+1 are read before the MFMAs of step q are issued
+            float2 av = *reinterpret_cast<const float2*>(Ab + h * AS);
+            float2 bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float2 bv = *reinterpret_cast<const float2*>(Bb + (2 * q + h) * BS + nt * 64);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + h * BS + nt * 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float2 av_n = av, bv_n[NT];
+                if (q + 1 < 8) {
+                    av_n = *reinterpret_cast<const float2*>(Ab + (2 * (q + 1) + h) * AS);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + (2 * (q + 1) + h) * BS + nt * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < 8) {
+                    av = av_n;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+                }
+            }
+        } else {
+            for (int q = 0; q < nq; ++q) {
+                const float2 av = *reinterpret_cast<const float2*>(Ab + (2 * q + h) * AS);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float2 bv = *reinterpret_cast<const float2*>(Bb + (2 * q + h) * BS + nt * 64);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                }
             }
         }
         if (c + 1 < nchunks) stage(buf ^ 1);
@@ -191,22 +220,223 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Dense 3x3 (stride 1, pad 1) on the MFMA with the input tile resident in LDS.
+// A block owns 128 consecutive output pixels (flat NHW order) and stages, ONCE, the flat pixel range
+// [p0 - W - 1, p0 + 128 + W + 1) x Cin — with the FPN/PAN `+ up2(x2)` / `+ down(x2)` add fused in — into
+// LDS.  All 9 taps x Cin/32 K-chunks then read their A fragments straight from that halo (the tap is an
+// address offset; image-border taps are predicated to zero per lane), so the K loop only streams the
+// packed weights (double-buffered).  Pixel stride Cin+2 floats makes the fragment ds_read_b64 conflict-free.
+// -------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmArgs a)
+{
+    constexpr int BM = 128, BN = 32 * NT, KP = 16, BS = BN * 2, B_PER = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float c3_smem[];
+    const int Cin = a.K, CS = Cin + 2;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int npix = BM + 2 * W + 2;
+    float* halo = c3_smem;                                   // [npix][CS]
+    float* Bs = c3_smem + ((npix * CS + 3) & ~3);            // [2][KP][BS]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int p0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int base = p0 - W - 1;
+    const int cpt = Cin >> 5;                               // K-chunks per tap
+    const int nchunks = 9 * cpt;
+    const int kp_total = (9 * Cin) >> 1;
+
+#ifdef YN_EXP_TIMING
+    const long long T0 = __builtin_readcyclecounter();
+#endif
+    float4 b_reg[B_PER];
+    auto prefetch_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            const int kpg = c * KP + kp;
+            const int n = n0 + c4 * 2;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (kpg < kp_total && n < a.Npad) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + n) * 2);
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = b_reg[i];
+        }
+    };
+    prefetch_b(0);
+
+    // ---- stage the halo (fused resample-add), thread = (channel pair, pixel lane) ----
+    // U pixels per batch: all global loads of a batch are issued before the first LDS store waits on them.
+    {
+        constexpr int U = 8;
+        const int cpn = Cin >> 1;
+        const int ppl = 256 / cpn;                           // pixels per pass
+        const int cp = t % cpn, pl = t / cpn;
+        if (pl < ppl) {
+            for (int i0 = pl; i0 < npix; i0 += ppl * U) {
+                float2 v[U], u2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * ppl;
+                    const int q = base + i;
+                    v[u] = make_float2(0.0f, 0.0f);
+                    u2[u] = make_float2(0.0f, 0.0f);
+                    if (i < npix && q >= 0 && q < a.M) {
+                        v[u] = *reinterpret_cast<const float2*>(a.in + (size_t)q * a.in_ld + a.in_off + 2 * cp);
+                        if (a.resample) {
+                            const int b = q / HW, rem = q - b * HW;
+                            const int y = rem / W, x = rem - y * W;
+                            size_t p2;
+                            if (a.resample == 1) p2 = ((size_t)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                            else                 p2 = ((size_t)b * (H << 1) + (y << 1)) * (W << 1) + (x << 1);
+                            u2[u] = *reinterpret_cast<const float2*>(a.in2 + p2 * Cin + 2 * cp);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * ppl;
+                    if (i < npix) *reinterpret_cast<float2*>(halo + i * CS + 2 * cp) = make_float2(v[u].x + u2[u].x, v[u].y + u2[u].y);
+                }
+            }
+        }
+    }
+    stage_b(0);
+
+    // ---- per-lane tap validity of this lane's output pixel ----
+    const int r = wave * 32 + l31;                           // row of the tile owned by this lane
+    const int m = p0 + r;
+    unsigned tapmask = 0;
+    if (m < a.M) {
+        const int rem = m % HW;
+        const int y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) tapmask |= 1u << tap;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
+#ifdef YN_EXP_TIMING
+    const long long T1 = __builtin_readcyclecounter();
+#endif
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+#ifndef YN_EXP_NOSTAGE
+        if (c + 1 < nchunks) prefetch_b(c + 1);
+#endif
+        const int tap = c / cpt;
+        const int ck = (c - tap * cpt) << 5;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const bool ok = (tapmask >> tap) & 1u;
+        const float* Ab = halo + (W + 1 + r + dy * W + dx) * CS + ck + 2 * h;
+        const float* Bb = Bs + buf * KP * BS + l31 * 2;
+        // fragments of step q+1 are read from LDS before the MFMAs of step q are issued, so the ds_read
+        // latency hides behind 2*NT MFMAs (the compiler otherwise sinks each read next to its first use)
+        float2 av = *reinterpret_cast<const float2*>(Ab);
+        float2 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + h * BS + nt * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float2 av_n = av, bv_n[NT];
+            if (q + 1 < 8) {
+                av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + (2 * (q + 1) + h) * BS + nt * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float ax = ok ? av.x : 0.0f, ay = ok ? av.y : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bv[nt].y, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < 8) {
+                av = av_n;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+            }
+        }
+#ifndef YN_EXP_NOSTAGE
+        if (c + 1 < nchunks) stage_b(buf ^ 1);
+        __syncthreads();
+#endif
+    }
+#ifdef YN_EXP_TIMING
+    const long long T2 = __builtin_readcyclecounter();
+    if (blockIdx.x == 1 && blockIdx.y == 0 && (t & 63) == 0)
+        printf("c3 W=%d wave %d: prologue %lld  loop %lld (%lld/chunk)  [cycles]\n", W, wave, T1 - T0, T2 - T1, (T2 - T1) / nchunks);
+#endif
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+            const int mm = p0 + wave * 32 + row;
+            if (mm >= a.M) continue;
+            a.out[(size_t)mm * a.out_ld + a.out_off + n] = apply_act(acc[nt][k] + bias, a.act);
+        }
+    }
+}
+
+static size_t conv3x3_halo_lds(int W, int Cin, int NT)
+{
+    const int npix = 128 + 2 * W + 2;
+    return ((size_t)((npix * (Cin + 2) + 3) & ~3) + 2 * 16 * (32 * NT * 2)) * sizeof(float);
+}
+
 struct TileCfg { int WM, WN, NT; };
 
 static TileCfg choose_tile(int M, int Npad)
 {
-    static const TileCfg cands[] = {{4, 1, 4}, {4, 1, 3}, {4, 1, 2}, {4, 1, 1}, {2, 2, 2}, {2, 2, 1}, {1, 4, 2}, {1, 4, 1}};
-    TileCfg best = cands[0];
-    double best_cost = 1e30;
-    for (const TileCfg& c : cands) {
-        const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
-        const long gx = (M + BM - 1) / BM, gy = (Npad + BN - 1) / BN;
-        const long blocks = gx * gy;
-        const long rounds = (blocks + 511) / 512;          // ~2 resident blocks on each of 256 CUs
-        const double cost = (double)rounds * BM * BN * (1.0 + 0.02 * (128 / BM - 1));
-        if (cost < best_cost) { best_cost = cost; best = c; }
+    // Prefer one block column covering all of N (A is then read exactly once); split N or shrink BM
+    // only when the grid would leave most of the 256 CUs idle.
+    const int nt32 = Npad / 32;
+    auto pick_nt = [&](int wn, int maxnt) {
+        int need = (nt32 + wn - 1) / wn;                   // n-tiles per wave to cover N in one column
+        if (need <= maxnt) return need;
+        for (int nt = maxnt; nt >= 1; --nt) if (nt32 % (nt * wn) == 0) return nt;
+        return maxnt;
+    };
+    TileCfg c{4, 1, pick_nt(1, 4)};
+    auto blocks = [&](const TileCfg& t) {
+        const long BM = 32 * t.WM, BN = 32 * t.NT * t.WN;
+        return ((M + BM - 1) / BM) * ((Npad + BN - 1) / BN);
+    };
+    if (blocks(c) >= 384) return c;
+    TileCfg c2{2, 2, pick_nt(2, 2)};
+    if (blocks(c2) >= 384 || c.NT == 1) { if (blocks(c2) > blocks(c)) c = c2; }
+    if (blocks(c) >= 256) return c;
+    TileCfg c3{1, 4, pick_nt(4, 2)};
+    if (blocks(c3) > blocks(c)) c = c3;
+    if (blocks(c) < 256 && c.NT > 1) {                      // still tiny: split N further
+        TileCfg c4 = c; c4.NT = 1;
+        if (blocks(c4) > blocks(c)) c = c4;
     }
-    return best;
+    return c;
 }
 
 template <int MODE>
@@ -227,7 +457,28 @@ static void launch_gemm(const GemmArgs& a, hipStream_t s)
 }
 
 void launch_pw(const GemmArgs& a, hipStream_t s) { launch_gemm<0>(a, s); }
-void launch_conv3x3(const GemmArgs& a, hipStream_t s) { launch_gemm<1>(a, s); }
+void launch_conv3x3(const GemmArgs& a, hipStream_t s)
+{
+    // LDS-resident halo kernel when the tile fits (always true for the 96-channel neck up to W ~ 150)
+    const int nt32 = a.Npad / 32;
+    const int NT = nt32 >= 3 && nt32 % 3 == 0 ? 3 : (nt32 % 2 == 0 ? 2 : 1);
+    const size_t lds = (a.K % 32 == 0 && a.in_off == 0) ? conv3x3_halo_lds(a.W, a.K, NT) : (size_t)1 << 30;
+    if (lds <= 160 * 1024 && a.K / 2 <= 256) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        dim3 grid((a.M + 127) / 128, a.Npad / (32 * NT));
+        if (NT == 3) { g_last_kernel = "conv3x3_halo_kernel<3>"; hipLaunchKernelGGL(conv3x3_halo_kernel<3>, grid, dim3(256), lds, s, a); }
+        else if (NT == 2) { g_last_kernel = "conv3x3_halo_kernel<2>"; hipLaunchKernelGGL(conv3x3_halo_kernel<2>, grid, dim3(256), lds, s, a); }
+        else { g_last_kernel = "conv3x3_halo_kernel<1>"; hipLaunchKernelGGL(conv3x3_halo_kernel<1>, grid, dim3(256), lds, s, a); }
+        return;
+    }
+    launch_gemm<1>(a, s);
+}
 
 // -------------------------------------------------------------------------------------------------
 // Depthwise 3x3, pad 1, stride 1 or 2.  Thread = (output pixel, channel pair); consecutive threads walk
@@ -290,46 +541,71 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                                                     const float* __restrict__ w, const float* __restrict__ bias,
                                                     int act, float* __restrict__ y)
 {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * Ho * Wo;
+    // weights [27][COUT] + bias in LDS (all lanes read the same address => broadcast); a thread owns two
+    // horizontally adjacent output pixels so every weight fetched from LDS feeds two FMAs.
+    __shared__ __attribute__((aligned(16))) float ws[28 * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) ws[27 * COUT + i] = bias[i];
+    __syncthreads();
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Wp = (Wo + 1) / 2;
+    const long total = (long)B * Ho * Wp;
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
-    const int ox = (int)(p % Wo);
-    const long q = p / Wo;
+    const int opx = (int)(p % Wp);
+    const long q = p / Wp;
     const int oy = (int)(q % Ho);
     const int b = (int)(q / Ho);
-    float acc[COUT];
+    const int ox0 = opx * 2;
+    const bool has1 = ox0 + 1 < Wo;
+    float acc0[COUT], acc1[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
+    for (int co = 0; co < COUT; ++co) { acc0[co] = ws[27 * COUT + co]; acc1[co] = acc0[co]; }
+    // (ci, ky) is a real loop on purpose: fully unrolled, the compiler hoists all 162 LDS weight reads to the top
+    // (648 VGPRs) and spills; per iteration it needs 18 reads / 72 VGPRs.
+#pragma unroll 1
+    for (int cy = 0; cy < 9; ++cy) {
+        const int ci = cy / 3, ky = cy - ci * 3;
         const float* xp = x + ((size_t)b * 3 + ci) * H * W;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
+        {
             const int iy = oy * 2 - 1 + ky;
+            const bool rowok = iy >= 0 && iy < H;
+            float in[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int ix = ox0 * 2 - 1 + j;
+                in[j] = (rowok && ix >= 0 && ix < W) ? xp[(size_t)iy * W + ix] : 0.0f;
+            }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * 2 - 1 + kx;
-                float v = 0.0f;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xp[(size_t)iy * W + ix];
-                const float* wr = w + ((ci * 3 + ky) * 3 + kx) * COUT;
+                const float4* wr = reinterpret_cast<const float4*>(ws + ((ci * 3 + ky) * 3 + kx) * COUT);
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] += v * wr[co];
+                for (int c4 = 0; c4 < COUT / 4; ++c4) {
+                    const float4 wv = wr[c4];
+                    acc0[c4 * 4 + 0] += in[kx] * wv.x; acc0[c4 * 4 + 1] += in[kx] * wv.y;
+                    acc0[c4 * 4 + 2] += in[kx] * wv.z; acc0[c4 * 4 + 3] += in[kx] * wv.w;
+                    acc1[c4 * 4 + 0] += in[kx + 2] * wv.x; acc1[c4 * 4 + 1] += in[kx + 2] * wv.y;
+                    acc1[c4 * 4 + 2] += in[kx + 2] * wv.z; acc1[c4 * 4 + 3] += in[kx + 2] * wv.w;
+                }
             }
         }
     }
-    float* yo = y + (size_t)p * COUT;
+    float* yo = y + (((size_t)b * Ho + oy) * Wo + ox0) * COUT;
 #pragma unroll
-    for (int co = 0; co < COUT; co += 4) {
-        float4 o = make_float4(apply_act(acc[co], act), apply_act(acc[co + 1], act), apply_act(acc[co + 2], act), apply_act(acc[co + 3], act));
-        *reinterpret_cast<float4*>(yo + co) = o;
+    for (int co = 0; co < COUT; co += 4)
+        *reinterpret_cast<float4*>(yo + co) = make_float4(apply_act(acc0[co], act), apply_act(acc0[co + 1], act),
+                                                          apply_act(acc0[co + 2], act), apply_act(acc0[co + 3], act));
+    if (has1) {
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4)
+            *reinterpret_cast<float4*>(yo + COUT + co) = make_float4(apply_act(acc1[co], act), apply_act(acc1[co + 1], act),
+                                                                     apply_act(acc1[co + 2], act), apply_act(acc1[co + 3], act));
     }
 }
 
 void launch_stem(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* y, hipStream_t s)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * Ho * Wo;
+    const long total = (long)B * Ho * ((Wo + 1) / 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     g_last_kernel = "stem_kernel<24>";
     if (Cout == 24) hipLaunchKernelGGL(stem_kernel<24>, dim3(blocks), dim3(256), 0, s, x, B, H, W, w, bias, act, y);

@@ -279,7 +279,18 @@ __device__ __forceinline__ bool suppressed(const float4 bi, float ai, const floa
     const float h = fmaxf(1e-28f, yy2 - yy1);
     const float inter = w * h;
     const float t0 = ai + aj;
-    float ovr = inter / (t0 - inter);
+    const float un = t0 - inter;
+    if (!diou) {
+        // Division-free early outs that cannot change the result: rounding is monotonic, so
+        // inter/un < thresh (real arithmetic, with a 1e-5 guard band for the rounding of thresh*un)
+        // implies fl(inter/un) <= thresh, and inter/un > thresh*(1+1e-5) implies fl(inter/un) > thresh.
+        const float p = thresh * un;
+        if (un > 0.0f && p > 1e-30f) {
+            if (inter < p * 0.99999f) return false;
+            if (inter > p * 1.00001f) return true;
+        }
+    }
+    float ovr = inter / un;
     if (diou) {                                            // models/yolo_nano.py:216-236
         const float mxx = fmaxf(fmaxf(bi.x, bi.z), fmaxf(bj.x, bj.z)), mnx = fminf(fminf(bi.x, bi.z), fminf(bj.x, bj.z));
         const float mxy = fmaxf(fmaxf(bi.y, bi.w), fmaxf(bj.y, bj.w)), mny = fminf(fminf(bi.y, bi.w), fminf(bj.y, bj.w));
@@ -315,8 +326,8 @@ template <bool KEYS_IN_LDS>
 __device__ void sort_segment(const float* __restrict__ boxes, const float* __restrict__ scores, int32_t* __restrict__ ids, bool ids_valid,
                              int n, int P, u64* keys, float4* __restrict__ sbox)
 {
-    const int tid = threadIdx.x;
-    for (int j = tid; j < P; j += 256) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int j = tid; j < P; j += nthr) {
         u64 k = 0;                                          // padding sorts to the end
         if (j < n) {
             const int id = ids_valid ? ids[j] : j;
@@ -327,7 +338,7 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (P >> 1); i += 256) {
+            for (int i = tid; i < (P >> 1); i += nthr) {
                 const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int b = a + j;
                 const u64 x = key_load<KEYS_IN_LDS>(keys, a), y = key_load<KEYS_IN_LDS>(keys, b);
@@ -337,7 +348,7 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
             __syncthreads();
         }
     }
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += nthr) {
         const int id = (int)(unsigned)(key_load<KEYS_IN_LDS>(keys, j) & 0xffffffffu);
         ids[j] = id;
         sbox[j] = *reinterpret_cast<const float4*>(boxes + (size_t)id * 4);
@@ -348,7 +359,7 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
 #define YN_SORT_LARGE 16384
 
 // grid (C, B): segments with n_lo < n <= n_hi
-__global__ __launch_bounds__(256) void sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+__global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                     const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                     int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C,
                                                     int n_lo, int n_hi, u64* __restrict__ gscratch, size_t gscratch_stride)
@@ -422,70 +433,80 @@ __global__ __launch_bounds__(64) void matrix_kernel(const float4* __restrict__ s
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
-// One wavefront.  rem[w] (LDS) = removed mask of chunk w.  Returns the number of kept boxes.
+// One workgroup (256 threads) per segment.  rem[w] (LDS) = removed mask of chunk w.  Per chunk: wave 0
+// resolves the diagonal tile serially (scalar readlanes; the next diagonal is prefetched meanwhile), then
+// all threads OR the kept rows' words of the band into rem[] (independent loads, LDS atomics on the few
+// non-zero words).  Returns the number of kept boxes.
+struct ResolveLds { u64 rem[512]; int kidx[64]; int nk; };
+#define YN_RESOLVE_MAX_T 512            /* n <= 32768 per segment */
+
 __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
-                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, u64* rem)
+                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int T = (n + 63) >> 6;
-    for (int w = lane; w < T; w += 64) rem[w] = 0;
+    for (int w = tid; w < T; w += nthr) L.rem[w] = 0;
+    u64 diag_next = 0;
+    if (wave == 0) diag_next = M[(size_t)lane * T];
     __syncthreads();
     int picked = 0;
     for (int ri = 0; ri < T; ++ri) {
         const size_t boff = band_off(ri, T);
         const int W = T - ri;
-        const int cnt = min(64, n - ri * 64);
-        const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-        const u64 diag = M[boff + (size_t)lane * W];
-        const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
-        u64 alive = validm & ~rem[ri];
-        u64 keepm = 0;
-        for (int i = 0; i < 64; ++i) {
-            if ((alive >> i) & 1ull) {
-                keepm |= 1ull << i;
-                const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
-                const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-                alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+        if (wave == 0) {
+            const u64 diag = diag_next;
+            if (ri + 1 < T) diag_next = M[band_off(ri + 1, T) + (size_t)lane * (W - 1)];
+            const int cnt = min(64, n - ri * 64);
+            const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+            u64 alive = validm & ~L.rem[ri];
+            u64 keepm = 0;
+            for (int i = 0; i < 64; ++i) {
+                if ((alive >> i) & 1ull) {
+                    keepm |= 1ull << i;
+                    const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
+                    const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+                    alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+                }
             }
-        }
-        if ((keepm >> lane) & 1ull) {
-            const int id = ids[ri * 64 + lane];
-            if (keep_flags) keep_flags[id] = 1;
-            if (pick_list) pick_list[picked + __popcll(keepm & ((1ull << lane) - 1ull))] = id;
-        }
-        picked += __popcll(keepm);
-        // later chunks: removed |= OR of the kept rows' words (lanes = column chunks => coalesced rows)
-        for (int w = 1 + lane; w < W; w += 64) {
-            u64 acc = rem[ri + w];
-            u64 km = keepm;
-            while (km) {
-                const int i = __ffsll((long long)km) - 1;
-                km &= km - 1;
-                acc |= M[boff + (size_t)i * W + w];
+            if ((keepm >> lane) & 1ull) {
+                const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
+                const int id = ids[ri * 64 + lane];
+                L.kidx[rank] = lane;
+                if (keep_flags) keep_flags[id] = 1;
+                if (pick_list) pick_list[picked + rank] = id;
             }
-            rem[ri + w] = acc;
+            if (lane == 0) L.nk = __popcll(keepm);
+        }
+        __syncthreads();
+        const int nk = L.nk;
+        picked += nk;
+        const int Wr = W - 1;                               // later chunks of this band
+        const int total = nk * Wr;
+        for (int p = tid; p < total; p += nthr) {
+            const int k = p / Wr, w = 1 + (p - k * Wr);
+            const u64 v = M[boff + (size_t)L.kidx[k] * W + w];
+            if (v) atomicOr(&L.rem[ri + w], v);
         }
         __syncthreads();
     }
     return picked;
 }
 
-#define YN_RESOLVE_MAX_T 512            /* n <= 32768 per segment */
-
-__global__ __launch_bounds__(64) void resolve_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
-                                                      const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
-                                                      int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep)
+__global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                       const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
+                                                       int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep)
 {
-    __shared__ u64 rem[YN_RESOLVE_MAX_T];
+    __shared__ ResolveLds L;
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
     if (n == 0) return;
     resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
-                    M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, rem);
+                    M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
 
 // ---- single-class entry (YOLONano.nms): one segment = items 0..n-1 ------------------------------------
-__global__ __launch_bounds__(256) void single_sort_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
+__global__ __launch_bounds__(1024) void single_sort_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
                                                            int32_t* __restrict__ ids, float4* __restrict__ sbox, u64* __restrict__ gscratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
@@ -505,11 +526,11 @@ __global__ __launch_bounds__(64) void single_matrix_kernel(const float4* __restr
     }
 }
 
-__global__ __launch_bounds__(64) void single_resolve_kernel(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
-                                                             int32_t* __restrict__ pick_list, int32_t* __restrict__ count)
+__global__ __launch_bounds__(256) void single_resolve_kernel(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                                              int32_t* __restrict__ pick_list, int32_t* __restrict__ count)
 {
-    __shared__ u64 rem[YN_RESOLVE_MAX_T];
-    const int picked = n > 0 ? resolve_segment(ids, n, M, nullptr, pick_list, rem) : 0;
+    __shared__ ResolveLds L;
+    const int picked = n > 0 ? resolve_segment(ids, n, M, nullptr, pick_list, L) : 0;
     if (threadIdx.x == 0) *count = picked;
 }
 
@@ -577,16 +598,16 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                        N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0);
     if (N > YN_SORT_SMALL)
-        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0);
     if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
-        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride);
     int G = 8192 / (B > 0 ? B : 1);
     if (G < 64) G = 64;
     if (G > 4096) G = 4096;
     hipLaunchKernelGGL(matrix_kernel, dim3(G, B), dim3(64), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, diou, M, wk.matrix_stride);
-    hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(64), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
+    hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
 
@@ -599,14 +620,15 @@ void launch_nms_single(const float* dets, const float* scores, int n, float thre
     u64* M = reinterpret_cast<u64*>(matrix_scratch);
     if (n > 0) {
         const int P = nms_pow2(n);
-        if (P <= YN_SORT_LARGE) hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(256), (size_t)P * 8, s, dets, scores, n, ids_scratch, sbox, (u64*)nullptr);
-        else hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(256), 0, s, dets, scores, n, ids_scratch, sbox, M);
+        const int thr = P >= 2048 ? 1024 : 256;
+        if (P <= YN_SORT_LARGE) hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(thr), (size_t)P * 8, s, dets, scores, n, ids_scratch, sbox, (u64*)nullptr);
+        else hipLaunchKernelGGL(single_sort_kernel, dim3(1), dim3(1024), 0, s, dets, scores, n, ids_scratch, sbox, M);
         const int T = (n + 63) / 64;
         int G = T * (T + 1) / 2;
         if (G > 8192) G = 8192;
         hipLaunchKernelGGL(single_matrix_kernel, dim3(G), dim3(64), 0, s, sbox, n, thresh, diou, M);
     }
-    hipLaunchKernelGGL(single_resolve_kernel, dim3(1), dim3(64), 0, s, ids_scratch, n, M, keep, count);
+    hipLaunchKernelGGL(single_resolve_kernel, dim3(1), dim3(256), 0, s, ids_scratch, n, M, keep, count);
 }
 
 }  // namespace ynk
