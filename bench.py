@@ -83,20 +83,15 @@ def cpu_baseline(args, sd, anchors):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from yolo_nano_amd import arch, capi, parallel, weights
+    rank, local_rank, world = parallel.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL; used only for the barrier / max-over-ranks
+    parallel.init("nccl", dev)                               # RCCL; used only for the barrier / max-over-ranks
+    dist = torch.distributed if world > 1 else None
 
-    from yolo_nano_amd import arch, capi, weights
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
     sd = weights.make_state_dict(args.backbone, args.classes)
     B, S = args.batch, args.size
@@ -130,10 +125,7 @@ def main():
             step()
         sync_all()
         elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = parallel.max_over_ranks(elapsed, dev)
         kept = int(counts_host.sum().item())
 
         # PCIe-inclusive variant (not `value`): also bring the kept rows of every image to the host
