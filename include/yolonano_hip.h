@@ -59,6 +59,10 @@ int  yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int di
 int  yn_num_predictions(yn_handle* h);                          /* N for the current grid            */
 int  yn_use_graph(yn_handle* h, int enable);                    /* hipGraph-capture yn_infer/forward */
 int  yn_synchronize(yn_handle* h);
+/* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
+ * shape times every instantiated tile configuration on the handle's stream and caches the fastest.  All
+ * configurations produce bit-identical results; disabling falls back to a static heuristic. */
+int  yn_autotune(yn_handle* h, int enable);
 
 /* ---- weights ------------------------------------------------------------------------------- */
 /* nn.Module.load_state_dict (eval.py:127, benchmark.py:132): one call per state-dict entry, using

@@ -40,6 +40,7 @@ SIGNATURES = {
     "yn_num_predictions": (_i32, [_vp]),
     "yn_use_graph": (_i32, [_vp, _i32]),
     "yn_synchronize": (_i32, [_vp]),
+    "yn_autotune": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -164,6 +165,9 @@ class Handle:
 
     def use_graph(self, on=True):
         self._ck(self.lib.yn_use_graph(self.h, int(bool(on))), "yn_use_graph")
+
+    def autotune(self, on=True):
+        self._ck(self.lib.yn_autotune(self.h, int(bool(on))), "yn_autotune")
 
     def synchronize(self):
         self._ck(self.lib.yn_synchronize(self.h), "yn_synchronize")

@@ -29,23 +29,29 @@ __device__ __forceinline__ float apply_act(float v, int act)
 
 // -------------------------------------------------------------------------------------------------
 // GEMM convolution.  Block = 4 waves laid out WM x WN; each wave owns a 32 x (32*NT) output tile and
-// keeps it in NT 32x32 f32 MFMA accumulators.  K is consumed in chunks of 32 through two LDS buffers:
+// keeps it in NT 32x32 f32 MFMA accumulators.  K is consumed in chunks of 2*KP through NBUF LDS buffers:
 //   As[kp][row] float2  (k-pair major; +1 float2 pad per kp row => conflict-free ds_write_b64)
 //   Bs[kp][n]   float2  (straight copy of the packed weights)
 // One ds_read_b64 of A and of B per lane feeds two MFMAs: lanes 0-31 carry k = 4q, 4q+1 and lanes
-// 32-63 carry k = 4q+2, 4q+3 (the order of the k-sum inside a chunk is free as long as A and B agree).
+// 32-63 carry k = 4q+2, 4q+3 (the order of the k-sum inside a chunk is free as long as A and B agree;
+// it is the same for every tile configuration, so all configurations are bit-identical).
+// NBUF = 2: one barrier per chunk, the next chunk's global loads fly during the MFMAs.
+// NBUF = 1: half the LDS (more blocks per CU); K <= 2*KP needs no loop at all.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT, int MODE>
+template <int WM, int WN, int NT, int MODE, int KP, int NBUF>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 {
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KP = 16;
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     constexpr int AS = BM * 2 + 2;              // floats per kp row of A
     constexpr int BS = BN * 2;                  // floats per kp row of B
-    constexpr int A_PER = BM / 16;              // float2 per thread per chunk
-    constexpr int B_PER = BN / 32;              // float4 per thread per chunk
-    __shared__ __attribute__((aligned(16))) float smem[2 * KP * (AS + BS)];
+    constexpr int A_PER = BM * KP / 256;        // float2 per thread per chunk
+    constexpr int B_PER = KP * BN / 512;        // float4 per thread per chunk
+    constexpr int RPP = 256 / KP;               // A rows per pass
+    constexpr int NQ = KP / 2;                  // MFMA k-steps (of 4 k) per chunk
+    static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * KP * (AS + BS)];
     float* As = smem;
-    float* Bs = smem + 2 * KP * AS;
+    float* Bs = smem + NBUF * KP * AS;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -54,24 +60,23 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     const int n0 = blockIdx.y * BN;
 
     const int Ktot = (MODE == 1) ? 9 * a.K : a.K;          // MODE 1: a.K = Cin
-    const int nchunks = (Ktot + 31) >> 5;
+    const int nchunks = (Ktot + 2 * KP - 1) / (2 * KP);
     const int kp_total = (Ktot + 1) >> 1;
 
     // ---- per-thread A row bookkeeping ----
-    const int a_kp = t & 15;
+    const int a_kp = t % KP;
     int a_m[A_PER];
-    int a_yx[A_PER];                                       // MODE 1: (y << 16) | x, or -1 if row invalid
+    int a_yx[A_PER];                                       // MODE 1: (y << 16) | x
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int r = (t >> 4) + 16 * i;
+        const int r = t / KP + RPP * i;
         const int m = m0 + r;
         a_m[i] = (m < a.M) ? m : -1;
-        if (MODE == 1) {
-            if (m < a.M) {
-                const int hw = a.H * a.W;
-                const int rem = m % hw;
-                a_yx[i] = ((rem / a.W) << 16) | (rem % a.W);
-            } else a_yx[i] = 0;
+        a_yx[i] = 0;
+        if (MODE == 1 && m < a.M) {
+            const int hw = a.H * a.W;
+            const int rem = m % hw;
+            a_yx[i] = ((rem / a.W) << 16) | (rem % a.W);
         }
     }
 
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     float4 b_reg[B_PER];
 
     auto prefetch = [&](int c) {
-        const int k0 = c << 5;
+        const int k0 = c * 2 * KP;
         if (MODE == 0) {
             const int k = k0 + 2 * a_kp;
             const bool kv = k < a.K;
@@ -90,14 +95,14 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
                 a_reg[i] = v;
             }
         } else {
-            const int cpt = a.K >> 5;                       // chunks per tap
-            const int tap = c / cpt;
-            const int ci = ((c - tap * cpt) << 5) + 2 * a_kp;
+            const int kk = k0 + 2 * a_kp;                   // global k = tap*Cin + ci
+            const int tap = kk / a.K;
+            const int ci = kk - tap * a.K;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 float2 v = make_float2(0.0f, 0.0f);
-                if (a_m[i] >= 0) {
+                if (a_m[i] >= 0 && tap < 9) {
                     const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
                     if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
                         const int src = a_m[i] + dy * a.W + dx;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            const int r = (t >> 4) + 16 * i;
+            const int r = t / KP + RPP * i;
             *reinterpret_cast<float2*>(As + buf * KP * AS + a_kp * AS + r * 2) = a_reg[i];
         }
 #pragma unroll
@@ -150,25 +155,27 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     stage(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+        const int buf = (NBUF == 2) ? (c & 1) : 0;
         if (c + 1 < nchunks) prefetch(c + 1);
-        const int krem = Ktot - (c << 5);
-        const int nq = krem >= 32 ? 8 : ((krem + 3) >> 2);
-        const float* Ab = As + buf * KP * AS + (wm * 32 + l31) * 2;
-        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2;
-        if (nq == 8) {
-            // full chunk: fragments of step q+1 are read before the MFMAs of step q are issued
-            float2 av = *reinterpret_cast<const float2*>(Ab + h * AS);
-            float2 bv[NT];
+        const int krem = Ktot - c * 2 * KP;
+        const int nq = krem >= 2 * KP ? NQ : ((krem + 3) >> 2);
+        const float* Ab = As + buf * KP * AS + (wm * 32 + l31) * 2 + h * AS;
+        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2 + h * BS;
+        // fragments of step q+1 are read from LDS before the MFMAs of step q are issued
+        float2 av = *reinterpret_cast<const float2*>(Ab);
+        float2 bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + h * BS + nt * 64);
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
+            if (q < nq) {                                   // wave-uniform
                 float2 av_n = av, bv_n[NT];
-                if (q + 1 < 8) {
-                    av_n = *reinterpret_cast<const float2*>(Ab + (2 * (q + 1) + h) * AS);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + (2 * (q + 1) + h) * BS + nt * 64);
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+                if (q + 1 < NQ) {
+                    av_n = *reinterpret_cast<const float2*>(Ab + 2 * (q + 1) * AS);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -177,25 +184,16 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (q + 1 < 8) {
-                    av = av_n;
+                av = av_n;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-                }
-            }
-        } else {
-            for (int q = 0; q < nq; ++q) {
-                const float2 av = *reinterpret_cast<const float2*>(Ab + (2 * q + h) * AS);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float2 bv = *reinterpret_cast<const float2*>(Bb + (2 * q + h) * BS + nt * 64);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
             }
         }
-        if (c + 1 < nchunks) stage(buf ^ 1);
-        __syncthreads();
+        if (c + 1 < nchunks) {
+            if (NBUF == 1) __syncthreads();                 // every wave is done reading the only buffer
+            stage(NBUF == 2 ? (buf ^ 1) : 0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias + activation (+ concat/shuffle interleave with the pass-through half) ----
@@ -219,7 +217,6 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
         }
     }
 }
-
 
 // -------------------------------------------------------------------------------------------------
 // Dense 3x3 (stride 1, pad 1) on the MFMA with the input tile resident in LDS.
@@ -408,55 +405,327 @@ static size_t conv3x3_halo_lds(int W, int Cin, int NT)
     return ((size_t)((npix * (Cin + 2) + 3) & ~3) + 2 * 16 * (32 * NT * 2)) * sizeof(float);
 }
 
-struct TileCfg { int WM, WN, NT; };
-
-static TileCfg choose_tile(int M, int Npad)
+// -------------------------------------------------------------------------------------------------
+// Depthwise 3x3 (stride 1, pad 1) fused into the pointwise conv that consumes it (ShuffleV2 branch2
+// dw -> pw2, head dw -> pw).  The depthwise OUTPUT never exists in memory: a block stages the flat halo
+// [p0 - W - 1, p0 + BM + W + 1) x Cin of the depthwise INPUT once in LDS, and every lane computes its MFMA
+// A fragment (row = output pixel, two consecutive channels) on the fly as the 9-tap weighted sum
+// (+ folded-BN bias, + activation for the heads) right before the MFMAs that consume it.  Per k-step that is
+// 18 ds_read_b64 and ~20 VALU ops hidden behind 2*NT 64-cycle MFMAs.  The pointwise weights stream through a
+// double buffer as in the GEMM kernel; the epilogue is the GEMM's (bias, activation, concat+shuffle).
+// Blocks: WM waves along M (BM = 32*WM), 4/WM waves along N.
+// -------------------------------------------------------------------------------------------------
+template <int WM, int NT>
+__global__ __launch_bounds__(256) void dwpw_halo_kernel(GemmArgs a)
 {
-    // Prefer one block column covering all of N (A is then read exactly once); split N or shrink BM
-    // only when the grid would leave most of the 256 CUs idle.
+    constexpr int WN = 4 / WM, BM = 32 * WM, BN = 32 * NT * WN, KP = 16, BS = BN * 2, B_PER = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float dp_smem[];
+    const int Cin = a.K, CS = Cin + 2;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int npix = BM + 2 * W + 2;
+    float* halo = dp_smem;                                   // [npix][CS]
+    float* Bs = dp_smem + ((npix * CS + 3) & ~3);            // [2][KP][BS]
+    float* wdw = Bs + 2 * KP * BS;                           // [9][CS] taps, then [CS] bias   (CS even => 8-byte aligned rows)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const int p0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int base = p0 - W - 1;
+    const int nchunks = (Cin + 31) >> 5;
+    const int kp_total = (Cin + 1) >> 1;
+
+    float4 b_reg[B_PER];
+    auto prefetch_b = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            const int kpg = c * KP + kp;
+            const int n = n0 + c4 * 2;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (kpg < kp_total && n < a.Npad) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + n) * 2);
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = b_reg[i];
+        }
+    };
+    prefetch_b(0);
+
+    // depthwise taps + bias -> LDS (pad columns zero)
+    for (int i = t; i < 10 * CS; i += 256) {
+        const int row = i / CS, c = i - row * CS;
+        float v = 0.0f;
+        if (c < Cin) v = row < 9 ? a.dw_w[row * Cin + c] : a.dw_b[c];
+        wdw[i] = v;
+    }
+    // halo of the depthwise input; thread = (channel pair incl. the zero pad pair, pixel lane)
+    {
+        constexpr int U = 8;
+        const int cpn = CS >> 1;
+        const int ppl = 256 / cpn;
+        const int cp = t % cpn, pl = t / cpn;
+        if (pl < ppl) {
+            for (int i0 = pl; i0 < npix; i0 += ppl * U) {
+                float2 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * ppl;
+                    const int q = base + i;
+                    v[u] = make_float2(0.0f, 0.0f);
+                    if (i < npix && q >= 0 && q < a.M && 2 * cp < Cin)
+                        v[u] = *reinterpret_cast<const float2*>(a.in + (size_t)q * a.in_ld + a.in_off + 2 * cp);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * ppl;
+                    if (i < npix) *reinterpret_cast<float2*>(halo + i * CS + 2 * cp) = v[u];
+                }
+            }
+        }
+    }
+    stage_b(0);
+
+    // per-lane tap validity of this lane's output pixel
+    const int r = wm * 32 + l31;
+    const int m = p0 + r;
+    unsigned tapmask = 0;
+    if (m < a.M) {
+        const int rem = m % HW;
+        const int y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) tapmask |= 1u << tap;
+        }
+    }
+    __syncthreads();
+
+    // A fragment (two consecutive channels k, k+1 of this lane's pixel) = depthwise output, computed from LDS
+    const float* hp = halo + (W + 1 + r) * CS + 2 * h;
+    auto dw_frag = [&](int k) {
+        float2 acc = *reinterpret_cast<const float2*>(wdw + 9 * CS + k + 2 * h);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int off = (tap / 3 - 1) * W + (tap % 3 - 1);
+            float2 v = *reinterpret_cast<const float2*>(hp + off * CS + k);
+            const float2 w = *reinterpret_cast<const float2*>(wdw + tap * CS + k + 2 * h);
+            if (!((tapmask >> tap) & 1u)) v = make_float2(0.0f, 0.0f);
+            acc.x += v.x * w.x;
+            acc.y += v.y * w.y;
+        }
+        return make_float2(apply_act(acc.x, a.dw_act), apply_act(acc.y, a.dw_act));
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) prefetch_b(c + 1);
+        const int krem = Cin - (c << 5);
+        const int nq = krem >= 32 ? 8 : ((krem + 3) >> 2);
+        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2 + h * BS;
+        float2 av = dw_frag(c << 5);
+        float2 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < nq) {
+                float2 av_n = av, bv_n[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+                if (q + 1 < nq) {
+                    av_n = dw_frag((c << 5) + 4 * (q + 1));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                av = av_n;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+            }
+        }
+        if (c + 1 < nchunks) stage_b(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + (wn * NT + nt) * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+            const int mm = p0 + wm * 32 + row;
+            if (mm >= a.M) continue;
+            const float v = apply_act(acc[nt][k] + bias, a.act);
+            if (a.pass) {
+                const float p = a.pass[(size_t)mm * a.pass_ld + a.pass_off + n];
+                *reinterpret_cast<float2*>(a.out + (size_t)mm * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
+            } else {
+                a.out[(size_t)mm * a.out_ld + a.out_off + n] = v;
+            }
+        }
+    }
+}
+
+static size_t dwpw_lds(int W, int Cin, int BM, int BN)
+{
+    const int npix = BM + 2 * W + 2, CS = Cin + 2;
+    return ((size_t)((npix * CS + 3) & ~3) + 2 * 16 * (BN * 2) + 10 * CS) * sizeof(float);
+}
+
+bool launch_dwpw(const GemmArgs& a, hipStream_t s)
+{
+    if ((a.K & 1) || a.K + 2 > 512) return false;
+    const int nt32 = a.Npad / 32;
+    struct Cand { int wm, nt; };
+    // (WM, NT): BM = 32*WM, BN = 32*NT*(4/WM).  Prefer covering N in one block column with the largest BM that fits LDS.
+    static const Cand cands[] = {{4, 4}, {4, 3}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    int best = -1;
+    long best_blocks = 0;
+    for (int i = 0; i < (int)(sizeof(cands) / sizeof(cands[0])); ++i) {
+        const int BM = 32 * cands[i].wm, BN = 32 * cands[i].nt * (4 / cands[i].wm);
+        if (BN > a.Npad && !(cands[i].nt == 1 && 4 / cands[i].wm == 1)) { if (BN - a.Npad >= 32) continue; }
+        if (a.Npad % BN != 0 && BN < a.Npad) continue;
+        if (dwpw_lds(a.W, a.K, BM, BN) > 160 * 1024) continue;
+        const long blocks = ((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN);
+        if (best < 0 || (best_blocks < 256 && blocks > best_blocks)) { best = i; best_blocks = blocks; }
+    }
+    if (best < 0) return false;
+    const int wm = cands[best].wm, nt = cands[best].nt;
+    const int BM = 32 * wm, BN = 32 * nt * (4 / wm);
+    const size_t lds = dwpw_lds(a.W, a.K, BM, BN);
+    dim3 grid((a.M + BM - 1) / BM, (a.Npad + BN - 1) / BN);
+#define YN_DWPW_CASE(WMv, NTv)                                                                                   \
+    if (wm == WMv && nt == NTv) {                                                                                \
+        static bool attr = false;                                                                                \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_halo_kernel<WMv, NTv>),        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        g_last_kernel = "dwpw_halo_kernel<" #WMv "," #NTv ">";                                                    \
+        hipLaunchKernelGGL((dwpw_halo_kernel<WMv, NTv>), grid, dim3(256), lds, s, a);                            \
+        return true;                                                                                             \
+    }
+    YN_DWPW_CASE(4, 4) YN_DWPW_CASE(4, 3) YN_DWPW_CASE(4, 2) YN_DWPW_CASE(4, 1)
+    YN_DWPW_CASE(2, 4) YN_DWPW_CASE(2, 2) YN_DWPW_CASE(2, 1) YN_DWPW_CASE(1, 2) YN_DWPW_CASE(1, 1)
+#undef YN_DWPW_CASE
+    return false;
+}
+
+struct TileCfg { int WM, WN, NT, KP, NBUF; };
+
+// Every instantiated tile configuration of the pointwise GEMM.  All of them compute bit-identical results,
+// so the per-layer choice (heuristic below, or the handle's autotuner via GemmArgs::cfg) is purely a speed matter.
+#define YN_PW_CONFIGS(X)                                                                             \
+    X(4, 1, 1, 16, 2) X(4, 1, 2, 16, 2) X(4, 1, 3, 16, 2) X(4, 1, 4, 16, 2) X(4, 1, 8, 16, 2)        \
+    X(2, 2, 1, 16, 2) X(2, 2, 2, 16, 2) X(2, 2, 4, 16, 2) X(1, 4, 1, 16, 2) X(1, 4, 2, 16, 2)        \
+    X(4, 1, 1, 32, 1) X(4, 1, 2, 32, 1) X(4, 1, 3, 32, 1) X(4, 1, 4, 32, 1)                          \
+    X(2, 2, 1, 32, 1) X(2, 2, 2, 32, 1) X(1, 4, 1, 32, 1) X(1, 4, 2, 32, 1)                          \
+    X(2, 2, 1, 32, 2) X(2, 2, 2, 32, 2) X(1, 4, 1, 32, 2) X(4, 1, 1, 32, 2) X(4, 1, 2, 32, 2)
+
+static const TileCfg g_pw_cfgs[] = {
+#define X(wm, wn, nt, kp, nb) {wm, wn, nt, kp, nb},
+    YN_PW_CONFIGS(X)
+#undef X
+};
+static const char* const g_pw_names[] = {
+#define X(wm, wn, nt, kp, nb) "gemm_conv_kernel<" #wm "," #wn "," #nt ",0," #kp "," #nb ">",
+    YN_PW_CONFIGS(X)
+#undef X
+};
+constexpr int N_PW_CFGS = (int)(sizeof(g_pw_cfgs) / sizeof(g_pw_cfgs[0]));
+
+int pw_config_count() { return N_PW_CFGS; }
+
+static int find_pw_cfg(int wm, int wn, int nt, int kp, int nb)
+{
+    for (int i = 0; i < N_PW_CFGS; ++i) {
+        const TileCfg& c = g_pw_cfgs[i];
+        if (c.WM == wm && c.WN == wn && c.NT == nt && c.KP == kp && c.NBUF == nb) return i;
+    }
+    return 0;
+}
+
+// heuristic used when no tuned choice is supplied
+static int choose_pw_cfg(int M, int K, int Npad)
+{
     const int nt32 = Npad / 32;
     auto pick_nt = [&](int wn, int maxnt) {
-        int need = (nt32 + wn - 1) / wn;                   // n-tiles per wave to cover N in one column
+        const int need = (nt32 + wn - 1) / wn;             // n-tiles per wave to cover N in one block column
         if (need <= maxnt) return need;
         for (int nt = maxnt; nt >= 1; --nt) if (nt32 % (nt * wn) == 0) return nt;
         return maxnt;
     };
-    TileCfg c{4, 1, pick_nt(1, 4)};
-    auto blocks = [&](const TileCfg& t) {
-        const long BM = 32 * t.WM, BN = 32 * t.NT * t.WN;
+    auto blocks = [&](int wm, int wn, int nt) {
+        const long BM = 32 * wm, BN = 32 * nt * wn;
         return ((M + BM - 1) / BM) * ((Npad + BN - 1) / BN);
     };
-    if (blocks(c) >= 384) return c;
-    TileCfg c2{2, 2, pick_nt(2, 2)};
-    if (blocks(c2) >= 384 || c.NT == 1) { if (blocks(c2) > blocks(c)) c = c2; }
-    if (blocks(c) >= 256) return c;
-    TileCfg c3{1, 4, pick_nt(4, 2)};
-    if (blocks(c3) > blocks(c)) c = c3;
-    if (blocks(c) < 256 && c.NT > 1) {                      // still tiny: split N further
-        TileCfg c4 = c; c4.NT = 1;
-        if (blocks(c4) > blocks(c)) c = c4;
+    int wm = 4, wn = 1, nt = pick_nt(1, 4);
+    if (blocks(wm, wn, nt) < 384) {
+        const int nt2 = pick_nt(2, 2);
+        if (blocks(2, 2, nt2) > blocks(wm, wn, nt)) { wm = 2; wn = 2; nt = nt2; }
+        if (blocks(wm, wn, nt) < 256) {
+            const int nt3 = pick_nt(4, 2);
+            if (blocks(1, 4, nt3) > blocks(wm, wn, nt)) { wm = 1; wn = 4; nt = nt3; }
+            if (blocks(wm, wn, nt) < 256 && nt > 1 && blocks(wm, wn, 1) > blocks(wm, wn, nt)) nt = 1;
+        }
     }
-    return c;
+    const bool one_shot = K <= 64;                          // whole K in one 64-deep chunk, single buffer
+    int idx = find_pw_cfg(wm, wn, nt, one_shot ? 32 : 16, one_shot ? 1 : 2);
+    const TileCfg& c = g_pw_cfgs[idx];
+    if (c.WM != wm || c.WN != wn || c.NT != nt) idx = find_pw_cfg(wm, wn, nt, 16, 2);
+    return idx;
 }
 
-template <int MODE>
-static void launch_gemm(const GemmArgs& a, hipStream_t s)
+void launch_pw(const GemmArgs& a, hipStream_t s)
 {
-    const TileCfg c = choose_tile(a.M, a.Npad);
+    int idx = a.cfg;
+    if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
+    const TileCfg& c = g_pw_cfgs[idx];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
     dim3 grid((a.M + BM - 1) / BM, (a.Npad + BN - 1) / BN);
-#define YN_GEMM_CASE(wm, wn, nt)                                                                     \
-    if (c.WM == wm && c.WN == wn && c.NT == nt) {                                                    \
-        g_last_kernel = MODE ? "gemm_conv_kernel<" #wm "," #wn "," #nt ",1>" : "gemm_conv_kernel<" #wm "," #wn "," #nt ",0>"; \
-        hipLaunchKernelGGL((gemm_conv_kernel<wm, wn, nt, MODE>), grid, dim3(256), 0, s, a);          \
-        return;                                                                                      \
-    }
-    YN_GEMM_CASE(4, 1, 4) YN_GEMM_CASE(4, 1, 3) YN_GEMM_CASE(4, 1, 2) YN_GEMM_CASE(4, 1, 1)
-    YN_GEMM_CASE(2, 2, 2) YN_GEMM_CASE(2, 2, 1) YN_GEMM_CASE(1, 4, 2) YN_GEMM_CASE(1, 4, 1)
-#undef YN_GEMM_CASE
+    g_last_kernel = g_pw_names[idx];
+    int i = 0;
+#define X(wm, wn, nt, kp, nb)                                                                              \
+    if (i++ == idx) { hipLaunchKernelGGL((gemm_conv_kernel<wm, wn, nt, 0, kp, nb>), grid, dim3(256), 0, s, a); return; }
+    YN_PW_CONFIGS(X)
+#undef X
 }
 
-void launch_pw(const GemmArgs& a, hipStream_t s) { launch_gemm<0>(a, s); }
+// generic (non-LDS-halo) dense 3x3: only two tile shapes are kept
+static void launch_gemm_3x3(const GemmArgs& a, hipStream_t s)
+{
+    const int nt32 = a.Npad / 32;
+    if (nt32 % 3 == 0) {
+        dim3 grid((a.M + 127) / 128, a.Npad / 96);
+        g_last_kernel = "gemm_conv_kernel<4,1,3,1,16,2>";
+        hipLaunchKernelGGL((gemm_conv_kernel<4, 1, 3, 1, 16, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.M + 127) / 128, nt32);
+        g_last_kernel = "gemm_conv_kernel<4,1,1,1,16,2>";
+        hipLaunchKernelGGL((gemm_conv_kernel<4, 1, 1, 1, 16, 2>), grid, dim3(256), 0, s, a);
+    }
+}
+
 void launch_conv3x3(const GemmArgs& a, hipStream_t s)
 {
     // LDS-resident halo kernel when the tile fits (always true for the 96-channel neck up to W ~ 150)
@@ -477,7 +746,7 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
         else { g_last_kernel = "conv3x3_halo_kernel<1>"; hipLaunchKernelGGL(conv3x3_halo_kernel<1>, grid, dim3(256), lds, s, a); }
         return;
     }
-    launch_gemm<1>(a, s);
+    launch_gemm_3x3(a, s);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -485,21 +754,31 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
 // the channel pairs of one pixel and then the next pixel, so loads and stores are fully coalesced in
 // NHWC.  The nine taps of neighbouring pixels overlap in L1/L2.
 // -------------------------------------------------------------------------------------------------
-template <int STRIDE>
+template <int V> struct VecT;
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef float4 type; };
+__device__ __forceinline__ void vfma(float2& acc, const float2 v, const float2 w) { acc.x += v.x * w.x; acc.y += v.y * w.y; }
+__device__ __forceinline__ void vfma(float4& acc, const float4 v, const float4 w) { acc.x += v.x * w.x; acc.y += v.y * w.y; acc.z += v.z * w.z; acc.w += v.w * w.w; }
+__device__ __forceinline__ float2 vact(float2 v, int act) { return make_float2(apply_act(v.x, act), apply_act(v.y, act)); }
+__device__ __forceinline__ float4 vact(float4 v, int act) { return make_float4(apply_act(v.x, act), apply_act(v.y, act), apply_act(v.z, act), apply_act(v.w, act)); }
+
+// VEC channels per thread: 4 (16-byte accesses) whenever C, the row strides and the channel offsets allow it
+template <int STRIDE, int VEC>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
 {
+    typedef typename VecT<VEC>::type vec;
     const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
-    const int cp_n = a.C >> 1;
-    const long total = (long)a.B * Ho * Wo * cp_n;
+    const int cv_n = a.C / VEC;
+    const long total = (long)a.B * Ho * Wo * cv_n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cp = (int)(i % cp_n);
-        const long p = i / cp_n;
+        const int cv = (int)(i % cv_n);
+        const long p = i / cv_n;
         const int ox = (int)(p % Wo);
         const long q = p / Wo;
         const int oy = (int)(q % Ho);
         const int b = (int)(q / Ho);
-        const int c = cp * 2;
-        float2 acc = *reinterpret_cast<const float2*>(a.bias + c);
+        const int c = cv * VEC;
+        vec acc = *reinterpret_cast<const vec*>(a.bias + c);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * STRIDE - 1 + ky;
@@ -508,28 +787,31 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * STRIDE - 1 + kx;
                 if (ix < 0 || ix >= a.W) continue;
-                const float2 v = *reinterpret_cast<const float2*>(a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + c);
-                const float2 w = *reinterpret_cast<const float2*>(a.w + (ky * 3 + kx) * a.C + c);
-                acc.x += v.x * w.x;
-                acc.y += v.y * w.y;
+                const vec v = *reinterpret_cast<const vec*>(a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + c);
+                const vec w = *reinterpret_cast<const vec*>(a.w + (ky * 3 + kx) * a.C + c);
+                vfma(acc, v, w);
             }
         }
-        acc.x = apply_act(acc.x, a.act);
-        acc.y = apply_act(acc.y, a.act);
-        *reinterpret_cast<float2*>(a.out + (size_t)p * a.out_ld + a.out_off + c) = acc;
+        *reinterpret_cast<vec*>(a.out + (size_t)p * a.out_ld + a.out_off + c) = vact(acc, a.act);
     }
 }
 
 void launch_dw(const DwArgs& a, hipStream_t s)
 {
     const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
-    const long total = (long)a.B * Ho * Wo * (a.C >> 1);
+    const bool v4 = (a.C % 4 == 0) && (a.in_ld % 4 == 0) && (a.in_off % 4 == 0) && (a.out_ld % 4 == 0) && (a.out_off % 4 == 0);
+    const long total = (long)a.B * Ho * Wo * (a.C / (v4 ? 4 : 2));
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
-    g_last_kernel = a.stride == 1 ? "dwconv3x3_kernel<1>" : "dwconv3x3_kernel<2>";
-    if (a.stride == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else               hipLaunchKernelGGL(dwconv3x3_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const dim3 g((unsigned)blocks), blk(256);
+    if (a.stride == 1) {
+        if (v4) { g_last_kernel = "dwconv3x3_kernel<1,4>"; hipLaunchKernelGGL((dwconv3x3_kernel<1, 4>), g, blk, 0, s, a); }
+        else    { g_last_kernel = "dwconv3x3_kernel<1,2>"; hipLaunchKernelGGL((dwconv3x3_kernel<1, 2>), g, blk, 0, s, a); }
+    } else {
+        if (v4) { g_last_kernel = "dwconv3x3_kernel<2,4>"; hipLaunchKernelGGL((dwconv3x3_kernel<2, 4>), g, blk, 0, s, a); }
+        else    { g_last_kernel = "dwconv3x3_kernel<2,2>"; hipLaunchKernelGGL((dwconv3x3_kernel<2, 2>), g, blk, 0, s, a); }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -225,7 +225,8 @@ __host__ __device__ inline int nms_pow2(int n) { int p = 64; while (p < n) p <<=
 __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict__ cls, int N, int C,
                                                        int32_t* __restrict__ seg_count, int32_t* __restrict__ seg_off,
                                                        int32_t* __restrict__ tile_off, int32_t* __restrict__ bucket,
-                                                       int32_t* __restrict__ keep)
+                                                       int32_t* __restrict__ keep, int32_t* __restrict__ large_list,
+                                                       int large_cap, int large_thresh)
 {
     extern __shared__ int32_t lds[];            // hist[C], cursor[C]
     int32_t* hist = lds;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0, tiles = 0;
+        int run = 0, tiles = 0, nlarge = 0;
         for (int c = 0; c < C; ++c) {
             const int h = hist[c];
             seg_count[(size_t)b * C + c] = h;
@@ -251,8 +252,10 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
             run += h;
             const int T = (h + 63) >> 6;
             tiles += T * (T + 1) / 2;
+            if (h > large_thresh && nlarge < large_cap) large_list[(size_t)b * (large_cap + 1) + 1 + nlarge++] = c;
         }
         tile_off[(size_t)b * (C + 1) + C] = tiles;
+        large_list[(size_t)b * (large_cap + 1)] = nlarge;
     }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -275,10 +278,11 @@ __device__ __forceinline__ bool suppressed(const float4 bi, float ai, const floa
 {
     const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
     const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-    const float w = fmaxf(1e-28f, xx2 - xx1);
-    const float h = fmaxf(1e-28f, yy2 - yy1);
-    const float inter = w * h;
+    const float dw = xx2 - xx1, dh = yy2 - yy1;
     const float t0 = ai + aj;
+    const float w = fmaxf(1e-28f, dw);
+    const float h = fmaxf(1e-28f, dh);
+    const float inter = w * h;
     const float un = t0 - inter;
     if (!diou) {
         // Division-free early outs that cannot change the result: rounding is monotonic, so
@@ -345,7 +349,11 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
                 const bool desc = (a & k) == 0;
                 if ((x < y) == desc) { key_store<KEYS_IN_LDS>(keys, a, y); key_store<KEYS_IN_LDS>(keys, b, x); }
             }
-            __syncthreads();
+            // pairs with j < 64 stay inside the 128-key block this wavefront also owned in the previous
+            // sub-stage (i -> block i/64), and a wavefront's LDS accesses are executed in order: no
+            // workgroup barrier is needed until j wraps around to k/2 >= 64 again.
+            if (KEYS_IN_LDS && j > 1 && j <= 64) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();
         }
     }
     for (int j = tid; j < n; j += nthr) {
@@ -362,10 +370,17 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
 __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                     const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                     int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C,
-                                                    int n_lo, int n_hi, u64* __restrict__ gscratch, size_t gscratch_stride)
+                                                    int n_lo, int n_hi, u64* __restrict__ gscratch, size_t gscratch_stride,
+                                                    const int32_t* __restrict__ large_list, int large_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    const int c = blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.y;
+    int c = blockIdx.x;
+    if (large_list) {                                       // grid.x indexes the image's list of large segments
+        const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+        if (c >= ll[0]) return;
+        c = ll[1 + c];
+    }
     const int n = seg_count[(size_t)b * C + c];
     if (n <= n_lo || n > n_hi) return;
     const int off = seg_off[(size_t)b * C + c];
@@ -383,42 +398,89 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
 // word (row, ci-ri) at  band_off(ri) + row*(T-ri) + (ci-ri),  band_off(ri) = 64*(ri*T - ri*(ri-1)/2).
 __device__ __forceinline__ size_t band_off(int ri, int T) { return (size_t)64 * ((size_t)ri * T - (size_t)ri * (ri - 1) / 2); }
 
-__device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh, int diou,
-                                            u64* __restrict__ M, float4* cbox)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// "plain" box: finite-ish coordinates and a non-negative area, so that for a DISJOINT pair with a plain row box of
+// area > 1e-10 the reference's arithmetic is decided without evaluating it: one clamped side is 1e-28, the other
+// at most 2e7, hence inter <= 2e-21, union >= 1e-10 - 2e-21 > 0 and inter/union <= 2e-11 <= thresh (thresh >= 1e-9):
+// `ovr <= thresh` holds, the pair is NOT suppressed.  Everything else takes the exact path (suppressed()).
+__device__ __forceinline__ bool plain_box(const float4 b)
+{
+    return fabsf(b.x) < 1e7f && fabsf(b.y) < 1e7f && fabsf(b.z) < 1e7f && fabsf(b.w) < 1e7f;
+}
+
+template <bool DIOU>
+__device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh,
+                                            u64* __restrict__ M, float4* cbox, float* carea)
 {
     const int lane = threadIdx.x & 63;
     const int jc = ci * 64 + lane;
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (jc < n) cb = sb[jc];
+    const float ca = (cb.z - cb.x) * (cb.w - cb.y);
     cbox[lane] = cb;
-    __syncthreads();
+    carea[lane] = ca;
+    const u64 col_plain = __ballot(plain_box(cb) && ca >= 0.0f);       // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // cbox/carea are private to this wavefront:
+    __builtin_amdgcn_wave_barrier();                                   // its LDS accesses execute in order
     const int jr = ri * 64 + lane;
     u64 mask = 0;
     if (jr < n) {
         const float4 bx = sb[jr];
         const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+        const bool fast_ok = !DIOU && thresh >= 1e-9f && plain_box(bx) && ar > 1e-10f;
+        const f32x2 ilo = {bx.x, bx.y}, ihi = {bx.z, bx.w};
         const int t0 = (ri == ci) ? lane + 1 : 0;
         const int t1 = min(64, n - ci * 64);
-        for (int t = t0; t < t1; ++t) {
+        u64 valid = (t1 == 64 ? ~0ull : ((1ull << t1) - 1ull));
+        valid &= (t0 >= 64) ? 0ull : ~((1ull << t0) - 1ull);
+        // phase 1, branch-free: which columns are geometrically disjoint from this row's box
+        unsigned dlo = 0, dhi = 0;
+#ifdef YN_EXP_NOFILTER
+        dlo = dhi = 0xffffffffu;
+#else
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
             const float4 bt = cbox[t];
-            const float at = (bt.z - bt.x) * (bt.w - bt.y);
-            if (suppressed(bx, ar, bt, at, thresh, diou)) mask |= 1ull << t;
+            const f32x2 jlo = {bt.x, bt.y}, jhi = {bt.z, bt.w};
+            const f32x2 d = __builtin_elementwise_min(ihi, jhi) - __builtin_elementwise_max(ilo, jlo);
+            const unsigned bit = fminf(d.x, d.y) <= 0.0f ? (1u << (t & 31)) : 0u;
+            if (t < 32) dlo |= bit; else dhi |= bit;
+        }
+#endif
+        const u64 disjoint = ((u64)dhi << 32) | dlo;
+        // phase 2, exact arithmetic only for the pairs the filter cannot decide (overlapping or non-plain boxes)
+        u64 slow = fast_ok ? (valid & ~(disjoint & col_plain)) : valid;
+#ifdef YN_EXP_NOSLOW
+        mask = slow; slow = 0;
+#endif
+        while (slow) {
+            const int t = __ffsll((long long)slow) - 1;
+            slow &= slow - 1;
+            const float4 bt = cbox[t];
+            if (suppressed(bx, ar, bt, carea[t], thresh, DIOU ? 1 : 0)) mask |= 1ull << t;
         }
     }
     M[band_off(ri, T) + (size_t)lane * (T - ri) + (ci - ri)] = mask;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 }
 
 // grid (G, B), block 64: block g of image b walks tiles g, g+G, ... of that image
-__global__ __launch_bounds__(64) void matrix_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
-                                                     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ tile_off,
-                                                     int N, int C, float thresh, int diou, u64* __restrict__ M, size_t m_stride)
+// grid (G, B), block 256 = 4 independent wavefronts: wavefront w of block g of image b walks tiles 4g+w, +4G, ...
+template <bool DIOU>
+__global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
+                                                      const int32_t* __restrict__ seg_off, const int32_t* __restrict__ tile_off,
+                                                      int N, int C, float thresh, u64* __restrict__ M, size_t m_stride)
 {
-    __shared__ float4 cbox[64];
+    __shared__ float4 cbox_all[4][64];
+    __shared__ float carea_all[4][64];
+    const int wave = threadIdx.x >> 6;
+    float4* cbox = cbox_all[wave];
+    float* carea = carea_all[wave];
     const int b = blockIdx.y;
     const int32_t* toff = tile_off + (size_t)b * (C + 1);
     const int total = toff[C];
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    for (int t = blockIdx.x * 4 + wave; t < total; t += gridDim.x * 4) {
         int lo = 0, hi = C;                                 // largest c with toff[c] <= t
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
         const int c = lo;
@@ -427,8 +489,8 @@ __global__ __launch_bounds__(64) void matrix_kernel(const float4* __restrict__ s
         int rem = t - toff[c], ri = 0;
         while (rem >= T - ri) { rem -= T - ri; ++ri; }
         const int ci = ri + rem;
-        matrix_tile(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh, diou,
-                    M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox);
+        matrix_tile<DIOU>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
+                          M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
     }
 }
 
@@ -437,17 +499,33 @@ __global__ __launch_bounds__(64) void matrix_kernel(const float4* __restrict__ s
 // resolves the diagonal tile serially (scalar readlanes; the next diagonal is prefetched meanwhile), then
 // all threads OR the kept rows' words of the band into rem[] (independent loads, LDS atomics on the few
 // non-zero words).  Returns the number of kept boxes.
-struct ResolveLds { u64 rem[512]; int kidx[64]; int nk; };
+struct ResolveLds { u64 rem[512]; u64 keepm; int kidx[64]; int nk; };
 #define YN_RESOLVE_MAX_T 512            /* n <= 32768 per segment */
 
 __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
                                int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
+    constexpr int NB = 16;                                  // prefetched band words per thread: covers T <= 64 (n <= 4096)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int T = (n + 63) >> 6;
     for (int w = tid; w < T; w += nthr) L.rem[w] = 0;
     u64 diag_next = 0;
     if (wave == 0) diag_next = M[(size_t)lane * T];
+    // band words of chunk 0 (row = p / Wr, col = 1 + p % Wr), issued now, consumed after the diagonal is resolved
+    u64 nb[NB];
+    // thread -> row r = tid/4, columns w = 1 + (tid&3) + 4u  (no integer divisions on the serial path)
+    const int pr = tid >> 2, pc = tid & 3;
+    auto prefetch_band = [&](int ri) {
+        const int W = T - ri;
+        const size_t boff = band_off(ri, T) + (size_t)pr * W;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int w = 1 + pc + 4 * u;
+            nb[u] = (w < W) ? M[boff + w] : 0ull;
+        }
+    };
+    const bool fits = (T - 1) <= NB * 4 && nthr == 256;
+    if (fits) prefetch_band(0);
     __syncthreads();
     int picked = 0;
     for (int ri = 0; ri < T; ++ri) {
@@ -458,15 +536,19 @@ __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64
             if (ri + 1 < T) diag_next = M[band_off(ri + 1, T) + (size_t)lane * (W - 1)];
             const int cnt = min(64, n - ri * 64);
             const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-            const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
-            u64 alive = validm & ~L.rem[ri];
-            u64 keepm = 0;
-            for (int i = 0; i < 64; ++i) {
-                if ((alive >> i) & 1ull) {
+            const u64 alive0 = validm & ~L.rem[ri];
+            u64 keepm = alive0;
+            // rows that are alive and suppress an alive column; none (the common case) => everything alive is kept
+            if (__ballot(((alive0 >> lane) & 1ull) && (diag & alive0)) != 0ull) {
+                const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+                u64 alive = alive0;
+                keepm = 0;
+                while (alive) {
+                    const int i = __ffsll((long long)alive) - 1;
                     keepm |= 1ull << i;
                     const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
                     const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-                    alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+                    alive &= ~((((u64)hi_i << 32) | (u64)lo_i) | (1ull << i));
                 }
             }
             if ((keepm >> lane) & 1ull) {
@@ -476,17 +558,26 @@ __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64
                 if (keep_flags) keep_flags[id] = 1;
                 if (pick_list) pick_list[picked + rank] = id;
             }
-            if (lane == 0) L.nk = __popcll(keepm);
+            if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; }
         }
         __syncthreads();
         const int nk = L.nk;
         picked += nk;
         const int Wr = W - 1;                               // later chunks of this band
-        const int total = nk * Wr;
-        for (int p = tid; p < total; p += nthr) {
-            const int k = p / Wr, w = 1 + (p - k * Wr);
-            const u64 v = M[boff + (size_t)L.kidx[k] * W + w];
-            if (v) atomicOr(&L.rem[ri + w], v);
+        if (fits) {
+            if ((L.keepm >> pr) & 1ull) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (nb[u]) atomicOr(&L.rem[ri + 1 + pc + 4 * u], nb[u]);
+            }
+            if (ri + 1 < T) prefetch_band(ri + 1);
+        } else {
+            const int total = nk * Wr;
+            for (int p = tid; p < total; p += nthr) {
+                const int k = p / Wr, w = 1 + (p - k * Wr);
+                const u64 v = M[boff + (size_t)L.kidx[k] * W + w];
+                if (v) atomicOr(&L.rem[ri + w], v);
+            }
         }
         __syncthreads();
     }
@@ -514,15 +605,17 @@ __global__ __launch_bounds__(1024) void single_sort_kernel(const float* __restri
     else sort_segment<true>(dets, scores, ids, false, n, nms_pow2(n), reinterpret_cast<u64*>(sort_lds), sbox);
 }
 
-__global__ __launch_bounds__(64) void single_matrix_kernel(const float4* __restrict__ sbox, int n, float thresh, int diou, u64* __restrict__ M)
+template <bool DIOU>
+__global__ __launch_bounds__(64) void single_matrix_kernel(const float4* __restrict__ sbox, int n, float thresh, u64* __restrict__ M)
 {
     __shared__ float4 cbox[64];
+    __shared__ float carea[64];
     const int T = (n + 63) >> 6;
     const int total = T * (T + 1) / 2;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         int rem = t, ri = 0;
         while (rem >= T - ri) { rem -= T - ri; ++ri; }
-        matrix_tile(sbox, n, T, ri, ri + rem, thresh, diou, M, cbox);
+        matrix_tile<DIOU>(sbox, n, T, ri, ri + rem, thresh, M, cbox, carea);
     }
 }
 
@@ -592,21 +685,24 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                          hipStream_t s)
 {
     set_sort_attr();
-    hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep);
+    const int large_cap = wk.large_cap;
+    hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
+                       wk.large_list, large_cap, YN_SORT_SMALL);
     float4* sbox = reinterpret_cast<float4*>(wk.sbox);
     u64* M = reinterpret_cast<u64*>(wk.matrix);
     hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                       N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0);
-    if (N > YN_SORT_SMALL)
-        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                           N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0);
+                       N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0);
+    if (N > YN_SORT_SMALL)                                  // only the (few) listed large segments get a 128 KB-LDS workgroup
+        hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)wk.large_list, large_cap);
     if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
-        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                           N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride);
-    int G = 8192 / (B > 0 ? B : 1);
-    if (G < 64) G = 64;
-    if (G > 4096) G = 4096;
-    hipLaunchKernelGGL(matrix_kernel, dim3(G, B), dim3(64), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, diou, M, wk.matrix_stride);
+        hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap);
+    int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
+    if (G < 32) G = 32;
+    if (G > 2048) G = 2048;
+    if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
+    else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
     hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
@@ -626,7 +722,8 @@ void launch_nms_single(const float* dets, const float* scores, int n, float thre
         const int T = (n + 63) / 64;
         int G = T * (T + 1) / 2;
         if (G > 8192) G = 8192;
-        hipLaunchKernelGGL(single_matrix_kernel, dim3(G), dim3(64), 0, s, sbox, n, thresh, diou, M);
+        if (diou) hipLaunchKernelGGL(single_matrix_kernel<true>, dim3(G), dim3(64), 0, s, sbox, n, thresh, M);
+        else      hipLaunchKernelGGL(single_matrix_kernel<false>, dim3(G), dim3(64), 0, s, sbox, n, thresh, M);
     }
     hipLaunchKernelGGL(single_resolve_kernel, dim3(1), dim3(256), 0, s, ids_scratch, n, M, keep, count);
 }

@@ -57,6 +57,11 @@ struct GraphEntry {
 struct yn_handle {
     yn_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t cur = nullptr;            // stream the launch helpers currently target (main or a side stream)
+    hipStream_t side[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> fj_events;    // fork/join events (rotating pool)
+    size_t fj_next = 0;
+    bool multi_stream = true;
     std::string err;
     std::map<std::string, Param> params;
     std::vector<Layer> layers;
@@ -80,6 +85,10 @@ struct yn_handle {
     size_t heads_cap = 0;
     // graphs / profiling
     bool use_graph = false;
+    bool autotune = true;
+    bool fuse_dwpw = false;        // measured slower than dw + pw as two kernels (halo staging dominates thin-K layers)
+    std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
+    hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -203,7 +212,7 @@ size_t network_arena_bytes(yn_handle* h, int B, int S)
     }
     const size_t p3 = (size_t)B * (S / 8) * (S / 8), p4 = p3 / 4, p5 = p4 / 4;
     fl += (p3 + p4 + p5) * NECK * 2 + p4 * NECK;      // laterals, smoothed (p4 twice)
-    fl += p3 * NECK * 2;                               // head ping-pong (largest scale)
+    fl += (p3 + p4 + p5) * NECK * 3;                   // head scratch, one set per (concurrent) head
     return fl * sizeof(float) + 64 * 256;
 }
 
@@ -248,11 +257,12 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     }
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off};
+        void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off, (void**)&h->nms.large_list};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.large_list, need_seg * sizeof(int32_t)));
         h->nms_seg_cap = need_seg;
         h->graphs.clear();
     }
@@ -264,6 +274,7 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         h->graphs.clear();
     }
     h->nms.matrix_stride = m_stride;
+    h->nms.large_cap = (N / 1024 + 1) < C ? (N / 1024 + 1) : C;       // at most N/1024 segments can exceed 1024 items
     return 0;
 }
 
@@ -306,19 +317,49 @@ struct Bracket {
         ProfRec r;
         r.name = name; r.flops = flops; r.bytes = bytes;
         r.e0 = take_event(h); r.e1 = take_event(h);
-        (void)hipEventRecord(r.e0, h->stream);
+        (void)hipEventRecord(r.e0, h->cur);
         h->prof.push_back(r);
     }
+    void cancel() { if (on) { h->prof.pop_back(); h->event_next -= 2; on = false; } }
     ~Bracket()
     {
         if (!on) return;
-        (void)hipEventRecord(h->prof.back().e1, h->stream);
+        (void)hipEventRecord(h->prof.back().e1, h->cur);
         h->prof.back().kernel = last_kernel_name();
     }
 };
 
 // ---- layer launchers ------------------------------------------------------------------------------
 const Layer& L(yn_handle* h, const std::string& name) { return h->layers[h->by_name.at(name)]; }
+
+// Pick the fastest tile configuration for this (shape, strides) by timing every instantiated one on the
+// handle's stream (all configurations are bit-identical, so this only affects speed).  Never runs during capture.
+int tune_pw(yn_handle* h, GemmArgs a)
+{
+    const std::vector<int> key = {a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
+    auto it = h->pw_tuned.find(key);
+    if (it != h->pw_tuned.end()) return it->second;
+    if (!h->autotune || h->profiling) return -1;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->cur, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
+    if (!h->tune_e0) { (void)hipEventCreate(&h->tune_e0); (void)hipEventCreate(&h->tune_e1); }
+    int best = -1;
+    float best_ms = 1e30f;
+    for (int c = 0; c < pw_config_count(); ++c) {
+        a.cfg = c;
+        launch_pw(a, h->cur);                               // warm-up
+        (void)hipEventRecord(h->tune_e0, h->cur);
+        for (int r = 0; r < 3; ++r) launch_pw(a, h->cur);
+        (void)hipEventRecord(h->tune_e1, h->cur);
+        if (hipEventSynchronize(h->tune_e1) != hipSuccess) return -1;
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, h->tune_e0, h->tune_e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    if (hipGetLastError() != hipSuccess) return -1;
+    h->pw_tuned[key] = best;
+    return best;
+}
 
 void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
             float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
@@ -329,9 +370,11 @@ void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     a.out = out; a.out_ld = out_ld; a.out_off = out_off;
     a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    a.cfg = -1;
+    a.cfg = tune_pw(h, a);
     Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
                4.0 * (M * (double)(l.cin + l.cout + (pass ? 2 * l.cout : 0)) + (double)l.cin * l.cout));
-    launch_pw(a, h->stream);
+    launch_pw(a, h->cur);
 }
 
 void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, int B, int H, int W,
@@ -343,7 +386,30 @@ void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     a.B = B; a.H = H; a.W = W; a.C = l.cout; a.stride = l.stride; a.act = l.act;
     const double Mi = (double)B * H * W, Mo = (double)B * ((H - 1) / l.stride + 1) * ((W - 1) / l.stride + 1);
     Bracket br(h, l.name, 2.0 * Mo * 9 * l.cout, 4.0 * (Mi + Mo) * l.cout);
-    launch_dw(a, h->stream);
+    launch_dw(a, h->cur);
+}
+
+// depthwise 3x3 (stride 1) + the pointwise conv that consumes it, fused (launch_dwpw); falls back to the two
+// separate kernels through `tmp` when the shape does not fit the fused kernel's LDS budget
+void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
+              float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
+{
+    const long M = (long)B * H * W;
+    if (dw.stride == 1 && h->fuse_dwpw) {
+        GemmArgs a{};
+        a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
+        a.Wp = pw.w_packed; a.bias = pw.b_packed;
+        a.out = out; a.out_ld = out_ld; a.out_off = out_off;
+        a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
+        a.M = (int)M; a.K = pw.cin; a.N = pw.cout; a.Npad = pw.Npad; a.act = pw.act; a.cfg = -1;
+        a.dw_w = dw.w_packed; a.dw_b = dw.b_packed; a.dw_act = dw.act;
+        Bracket br(h, dw.name + "+" + pw.name, 2.0 * M * (9.0 * dw.cout + (double)pw.cin * pw.cout),
+                   4.0 * (M * (double)(pw.cin + pw.cout + (pass ? 2 * pw.cout : 0)) + (double)pw.cin * pw.cout));
+        if (launch_dwpw(a, h->cur)) return;
+        br.cancel();
+    }
+    run_dw(h, dw, in, in_ld, in_off, B, H, W, tmp, dw.cout, 0);
+    run_pw(h, pw, tmp, dw.cout, 0, M, out, out_ld, out_off, pass, pass_ld, pass_off);
 }
 
 void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int resample, int B, int H, int W, float* out)
@@ -352,10 +418,48 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
     a.in = in; a.in_ld = l.cin; a.in_off = 0; a.in2 = in2; a.resample = resample; a.H = H; a.W = W;
     a.Wp = l.w_packed; a.bias = l.b_packed; a.out = out; a.out_ld = l.cout; a.out_off = 0;
     a.M = B * H * W; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    a.cfg = -1;
     const double M = (double)a.M;
     const double in2px = resample == 1 ? M / 4 : (resample == 2 ? M * 4 : 0);
     Bracket br(h, l.name, 2.0 * M * 9 * l.cin * l.cout, 4.0 * ((M + in2px) * l.cin + M * l.cout + 9.0 * l.cin * l.cout));
-    launch_conv3x3(a, h->stream);
+    launch_conv3x3(a, h->cur);
+}
+
+// ---- fork / join of independent kernel chains onto side streams (also legal inside stream capture) ----
+hipEvent_t fj_event(yn_handle* h)
+{
+    if (h->fj_events.size() < 32) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        h->fj_events.push_back(e);
+        return e;
+    }
+    return h->fj_events[h->fj_next++ % h->fj_events.size()];
+}
+bool side_ok(yn_handle* h)
+{
+    if (!h->multi_stream || h->profiling || h->stream == nullptr) return false;
+    for (int k = 0; k < 2; ++k)
+        if (!h->side[k] && hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) return false;
+    return true;
+}
+// side stream k picks up after everything issued so far on the main stream; subsequent run_* target it
+void fork_to(yn_handle* h, int k)
+{
+    if (!side_ok(h)) return;
+    hipEvent_t e = fj_event(h);
+    (void)hipEventRecord(e, h->stream);
+    (void)hipStreamWaitEvent(h->side[k], e, 0);
+    h->cur = h->side[k];
+}
+void back_to_main(yn_handle* h) { h->cur = h->stream; }
+// the main stream waits for everything issued so far on side stream k
+void join_from(yn_handle* h, int k)
+{
+    if (!h->side[k] || !side_ok(h)) return;
+    hipEvent_t e = fj_event(h);
+    (void)hipEventRecord(e, h->side[k]);
+    (void)hipStreamWaitEvent(h->stream, e, 0);
 }
 
 // The network: x NCHW [B,3,S,S] -> three NHWC head tensors.
@@ -363,6 +467,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
 {
     const int S = h->grid.S;
     h->arena_used = 0;
+    h->cur = h->stream;
 #define TAKE(var, floats)                                                                   \
     float* var = arena_take(h, (size_t)(floats));                                           \
     if (!var) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes)
@@ -373,11 +478,11 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
         const Layer& l = L(h, "stem");
         const double Mo = (double)B * H1 * H1;
         Bracket br(h, "stem", 2.0 * Mo * 27 * 24, 4.0 * ((double)B * 3 * S * S + Mo * 24));
-        launch_stem(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a0, h->stream);
+        launch_stem(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a0, h->cur);
     }
     {
         Bracket br(h, "maxpool", 0.0, 4.0 * 24 * ((double)B * H1 * H1 + (double)B * H2 * H2));
-        launch_maxpool(a0, B, H1, H1, 24, a1, h->stream);
+        launch_maxpool(a0, B, H1, H1, 24, a1, h->cur);
     }
     const float* cur = a1;
     int curC = 24, curH = H2;
@@ -395,10 +500,13 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
         snprintf(nm, sizeof nm, "backbone.stage%d.0", si + 2);
         const std::string P0 = nm;
         // stride-2 block: backbone/shufflenetv2.py:73-74
+        fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
         run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
         run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+        back_to_main(h);
         run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
         run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
+        join_from(h, 0);
         run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
         float* o_cur = oA;
         float* o_nxt = oB;
@@ -407,8 +515,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
             const std::string P = nm;
             // stride-1 block: backbone/shufflenetv2.py:70-72 — x1 = ch [0,bf) passes through, x2 = ch [bf,C)
             run_pw(h, L(h, P + ".b2.pw1"), o_cur, C, bf, Mo, t1, bf, 0, nullptr, 0, 0);
-            run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, Ho, Ho, t2, bf, 0);
-            run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, o_nxt, C, 0, o_cur, C, 0);
+            run_dwpw(h, L(h, P + ".b2.dw"), L(h, P + ".b2.pw2"), t1, bf, 0, B, Ho, Ho, t2, o_nxt, C, 0, o_cur, C, 0);
             float* tmp = o_cur; o_cur = o_nxt; o_nxt = tmp;
         }
         cfeat[si] = o_cur;
@@ -418,28 +525,44 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
     const int W3 = S / 8, W4 = S / 16, W5 = S / 32;
     const long M3 = (long)B * W3 * W3, M4 = (long)B * W4 * W4, M5 = (long)B * W5 * W5;
     TAKE(p3, M3 * NECK); TAKE(p4, M4 * NECK); TAKE(p5, M5 * NECK);
+    // the three laterals are independent; p3 is only needed by smooth_1
+    fork_to(h, 0);
     run_pw(h, L(h, "conv1x1_0"), cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0);
+    back_to_main(h);
     run_pw(h, L(h, "conv1x1_1"), cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0);
     run_pw(h, L(h, "conv1x1_2"), cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0);
     TAKE(p4a, M4 * NECK); TAKE(p3a, M3 * NECK); TAKE(p4b, M4 * NECK); TAKE(p5a, M5 * NECK);
     run_c3(h, L(h, "smooth_0"), p4, p5, 1, B, W4, W4, p4a);        // p4 + up2(p5)
+    join_from(h, 0);
     run_c3(h, L(h, "smooth_1"), p3, p4a, 1, B, W3, W3, p3a);       // p3 + up2(p4)
-    run_c3(h, L(h, "smooth_2"), p4a, p3a, 2, B, W4, W4, p4b);      // p4 + down(p3)
-    run_c3(h, L(h, "smooth_3"), p5, p4b, 2, B, W5, W5, p5a);       // p5 + down(p4)
-    // heads: models/yolo_nano.py:299-301
-    TAKE(hA, M3 * NECK); TAKE(hB, M3 * NECK);
+    // heads: models/yolo_nano.py:299-301.  head k only needs its own pyramid level, so head 1 (the big one) starts on a
+    // side stream as soon as smooth_1 is enqueued, head 2 after smooth_2, head 3 stays on the main stream.
     const float* feats[3] = {p3a, p4b, p5a};
     const int Ws[3] = {W3, W4, W5};
-    for (int hd = 0; hd < 3; ++hd) {
+    auto run_head = [&](int hd) {
         const long M = (long)B * Ws[hd] * Ws[hd];
+        float* hA = arena_take(h, (size_t)M * NECK);
+        float* hB = arena_take(h, (size_t)M * NECK);
+        float* hC = arena_take(h, (size_t)M * NECK);
+        if (!hA || !hB || !hC) return 1;
         snprintf(nm, sizeof nm, "head_det_%d", hd + 1);
         const std::string P = nm;
-        run_dw(h, L(h, P + ".0"), feats[hd], NECK, 0, B, Ws[hd], Ws[hd], hA, NECK, 0);
-        run_pw(h, L(h, P + ".1"), hA, NECK, 0, M, hB, NECK, 0, nullptr, 0, 0);
-        run_dw(h, L(h, P + ".2"), hB, NECK, 0, B, Ws[hd], Ws[hd], hA, NECK, 0);
-        run_pw(h, L(h, P + ".3"), hA, NECK, 0, M, hB, NECK, 0, nullptr, 0, 0);
-        run_pw(h, L(h, P + ".4"), hB, NECK, 0, M, heads[hd], h->head_ch, 0, nullptr, 0, 0);
-    }
+        run_dwpw(h, L(h, P + ".0"), L(h, P + ".1"), feats[hd], NECK, 0, B, Ws[hd], Ws[hd], hA, hB, NECK, 0, nullptr, 0, 0);
+        run_dwpw(h, L(h, P + ".2"), L(h, P + ".3"), hB, NECK, 0, B, Ws[hd], Ws[hd], hA, hC, NECK, 0, nullptr, 0, 0);
+        run_pw(h, L(h, P + ".4"), hC, NECK, 0, M, heads[hd], h->head_ch, 0, nullptr, 0, 0);
+        return 0;
+    };
+    fork_to(h, 0);
+    if (run_head(0)) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
+    back_to_main(h);
+    run_c3(h, L(h, "smooth_2"), p4a, p3a, 2, B, W4, W4, p4b);      // p4 + down(p3)
+    fork_to(h, 1);
+    if (run_head(1)) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
+    back_to_main(h);
+    run_c3(h, L(h, "smooth_3"), p5, p4b, 2, B, W5, W5, p5a);       // p5 + down(p4)
+    if (run_head(2)) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
+    join_from(h, 0);
+    join_from(h, 1);
 #undef TAKE
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -459,6 +582,7 @@ int run_maybe_graph(yn_handle* h, const std::vector<uintptr_t>& key, F body)
     if (!h->use_graph || h->profiling) return body();
     for (GraphEntry& g : h->graphs)
         if (g.key == key) { HIPCHK(h, hipGraphLaunch(g.exec, h->stream)); return 0; }
+    if (h->autotune) { const int rc0 = body(); if (rc0) return rc0; }      // eager pass: tunes tile configurations, warms up
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     const int rc = body();
@@ -503,6 +627,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->cfg = *cfg;
     if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
     h->stream = (hipStream_t)cfg->stream;
+    h->cur = h->stream;
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
     *out = h;
@@ -521,10 +646,13 @@ void yn_destroy(yn_handle* h)
         if (l.b_ref) (void)hipFree(l.b_ref);
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
-                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.matrix, h->heads_int[0]};
+                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->tune_e0) { (void)hipEventDestroy(h->tune_e0); (void)hipEventDestroy(h->tune_e1); }
+    for (hipEvent_t e : h->fj_events) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     delete h;
 }
 
@@ -545,6 +673,7 @@ int yn_set_stream(yn_handle* h, void* stream)
         h->graphs.clear();
     }
     h->stream = (hipStream_t)stream;
+    h->cur = h->stream;
     return 0;
 }
 
@@ -562,6 +691,14 @@ int yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int dio
 int yn_num_predictions(yn_handle* h) { return h ? h->grid.N : -1; }
 
 int yn_use_graph(yn_handle* h, int enable) { if (!h) return 1; h->use_graph = enable != 0; return 0; }
+
+int yn_autotune(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    h->autotune = enable != 0;
+    if (!enable) h->pw_tuned.clear();
+    return 0;
+}
 
 int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 
@@ -791,6 +928,7 @@ struct TmpLayer {
     int rc = 0;
     TmpLayer(yn_handle* h_, int kind, int cin, int cout, int stride, int act, const float* w, const float* bias) : h(h_)
     {
+        h->cur = h->stream;
         l.name = "op"; l.kind = kind; l.cin = cin; l.cout = cout; l.stride = stride; l.act = act;
         FoldArgs a{};
         a.w = w; a.b = bias; a.eps = 1e-5f; a.Cout = cout; a.Cin = cin;
@@ -874,6 +1012,7 @@ int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, 
 {
     if (!h) return 1;
     if (!h->folded) return fail(h, "yn_op_shuffle_block before yn_fold_bn");
+    h->cur = h->stream;
     const std::string P = block;
     if (!h->by_name.count(P + ".b2.pw1")) return fail(h, "unknown block '%s'", block);
     const bool s2 = h->by_name.count(P + ".b1.dw") != 0;
@@ -895,8 +1034,7 @@ int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, 
         run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, y, C, 0, tb1, bf, 0);
     } else {
         run_pw(h, pw1, x, C, bf, Mi, t1, bf, 0, nullptr, 0, 0);
-        run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, H, W, t2, bf, 0);
-        run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, y, C, 0, x, C, 0);
+        run_dwpw(h, L(h, P + ".b2.dw"), L(h, P + ".b2.pw2"), t1, bf, 0, B, H, W, t2, y, C, 0, x, C, 0);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));

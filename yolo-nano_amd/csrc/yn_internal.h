@@ -16,6 +16,9 @@ struct GemmArgs {
     float* out;        int out_ld;  int out_off;
     const float* pass; int pass_ld; int pass_off; // shuffle mode: out[m][2n] = pass[m][n], out[m][2n+1] = res
     int M, K, N, Npad, act;
+    int cfg;                                    // pointwise tile configuration index, -1 = heuristic
+    const float* dw_w; const float* dw_b;       // fused depthwise prologue (dwpw kernel): [9][K], [K]
+    int dw_act;                                 // activation between the depthwise and the pointwise conv
 };
 
 struct DwArgs {
@@ -27,8 +30,11 @@ struct DwArgs {
 
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
 void set_last_kernel_name(const char* n);
+int  pw_config_count();
 void launch_pw(const GemmArgs& a, hipStream_t s);
 void launch_conv3x3(const GemmArgs& a, hipStream_t s);
+// depthwise 3x3 (stride 1, pad 1) + pointwise 1x1 in one kernel; returns false when the shape does not fit
+bool launch_dwpw(const GemmArgs& a, hipStream_t s);
 void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
                  int Cout, int act, float* y, hipStream_t s);
@@ -73,6 +79,8 @@ struct NmsWork {                                // per-handle scratch, sized for
     float*   sbox;                              // [B][N][4] boxes in sorted order
     void*    matrix;                            // [B][matrix_stride] uint64 suppression bit-matrix tiles
     size_t   matrix_stride;                     // words per image
+    int32_t* large_list;                        // [B][large_cap+1]  count, then class ids of segments with n > 1024
+    int      large_cap;
 };
 size_t nms_matrix_words_per_image(int N, int C);
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
