@@ -177,8 +177,18 @@ def main():
                                 "share": round(a["ms"] / tot_ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
                                 "unit": unit, "frac": round(ach / peak, 4)})
             d = kernels[0]
+            traffic = None                 # HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE, KiB)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                key = d["kernel"].replace(",", ", ") if d["kernel"] not in pmc else d["kernel"]
+                if key in pmc and B == 32 and S == 416:
+                    traffic = round(pmc[key]["avg_hbm_mb_per_launch"] * 1e6)
+            except Exception:
+                traffic = None
             roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": None, "avg_us": d["avg_us"], "share_of_step": d["share"]}
+                    "frac": d["frac"], "traffic": traffic, "alg_bytes_per_launch": round(agg[d["kernel"]]["bytes"] / agg[d["kernel"]]["launches"]),
+                    "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
+                    "avg_us": d["avg_us"], "share_of_step": d["share"]}
             fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
             by = sum(a["bytes"] for a in agg.values()) / args.profile_steps
             floor_ms = max(fl / (PEAK_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3

@@ -82,10 +82,26 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 
     float2 a_reg[A_PER];
     float4 b_reg[B_PER];
+    static_assert(A_PER % 2 == 0, "vec4 A path needs an even number of k-pairs per thread");
+    // 16-byte global accesses whenever the layer's channel counts / offsets are multiples of 4 floats (wave-uniform)
+    const bool vecA = (MODE == 0) && ((a.K | a.in_ld | a.in_off) & 3) == 0;
+    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
 
     auto prefetch = [&](int c) {
         const int k0 = c * 2 * KP;
-        if (MODE == 0) {
+        if (MODE == 0 && vecA) {
+            // 16-byte loads: thread = (row, k-quad); a_reg[2i], a_reg[2i+1] = the quad's two k-pairs
+            const int k = k0 + 4 * (t % (KP / 2));
+            const bool kv = k < a.K;
+#pragma unroll
+            for (int i = 0; i < A_PER / 2; ++i) {
+                const int m = m0 + t / (KP / 2) + (512 / KP) * i;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (kv && m < a.M) v = *reinterpret_cast<const float4*>(a.in + (size_t)m * a.in_ld + a.in_off + k);
+                a_reg[2 * i] = make_float2(v.x, v.y);
+                a_reg[2 * i + 1] = make_float2(v.z, v.w);
+            }
+        } else if (MODE == 0) {
             const int k = k0 + 2 * a_kp;
             const bool kv = k < a.K;
 #pragma unroll
@@ -132,10 +148,20 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
         }
     };
     auto stage = [&](int buf) {
+        if (MODE == 0 && vecA) {
+            const int kp = 2 * (t % (KP / 2));
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int r = t / KP + RPP * i;
-            *reinterpret_cast<float2*>(As + buf * KP * AS + a_kp * AS + r * 2) = a_reg[i];
+            for (int i = 0; i < A_PER / 2; ++i) {
+                const int r = t / (KP / 2) + (512 / KP) * i;
+                *reinterpret_cast<float2*>(As + buf * KP * AS + kp * AS + r * 2) = a_reg[2 * i];
+                *reinterpret_cast<float2*>(As + buf * KP * AS + (kp + 1) * AS + r * 2) = a_reg[2 * i + 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int r = t / KP + RPP * i;
+                *reinterpret_cast<float2*>(As + buf * KP * AS + a_kp * AS + r * 2) = a_reg[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
@@ -197,6 +223,44 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     }
 
     // ---- epilogue: bias + activation (+ concat/shuffle interleave with the pass-through half) ----
+    if (vecO) {
+        // 16-byte stores: an accumulator quad (regs 4g..4g+3 = 4 consecutive rows, lanes 4q'..4q'+3 = 4 consecutive
+        // columns) is transposed inside its 4 lanes with two xor-shuffles, so lane j ends up with row j x 4 columns.
+        const int j = lane & 3;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ncol = n0 + (wn * NT + nt) * 32 + l31;            // this lane's column before the transpose
+            const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
+            const int nq = n0 + (wn * NT + nt) * 32 + (l31 & ~3);       // first column of the quad
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
+                float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
+                {   // 2x2 blocks
+                    const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
+                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+                }
+                {   // 4x4
+                    const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
+                    const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                    if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+                }
+                const int m = m0 + wm * 32 + 8 * g + 4 * h + j;
+                if (m < a.M && nq < a.N) {
+                    if (a.pass) {
+                        const float4 p = *reinterpret_cast<const float4*>(a.pass + (size_t)m * a.pass_ld + a.pass_off + nq);
+                        float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
+                        *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
+                        *reinterpret_cast<float4*>(o + 4) = make_float4(p.z, v2, p.w, v3);
+                    } else {
+                        *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + (wn * NT + nt) * 32 + l31;
