@@ -117,6 +117,22 @@ int  yn_infer(yn_handle* h, const float* x_dev, int B,
               float* out_boxes_dev, float* out_scores_dev, int32_t* out_cls_dev,
               int32_t* out_index_dev, int32_t* count_dev);
 
+/* ---- training loss (train.py:219-229, forward value + gradient w.r.t. the raw predictions) ---------- */
+/* models/yolo_nano.py:332-358 + tools.iou_score (tools.py:219-233) + tools.loss (tools.py:236-276).
+ * Predictions in the reference's split layout: conf [B,N] (= [B,N,1]), cls [B,N,C], txtytwth [B,N,4];
+ * target [B,N,11] = [obj, cls, tx,ty,tw,th, weight, x1,y1,x2,y2] as tools.multi_gt_creator builds it (tools.py:108).
+ * losses_dev[4] = conf, cls, bbox (txty+twth), iou — each already divided by B.  The three gradient buffers
+ * (same shapes as the predictions; all or none) receive d(conf+cls+bbox+iou)/d(prediction), i.e. what
+ * `total_loss.backward()` (train.py:222-229) leaves in the prediction tensors; gt_conf = iou.detach(). */
+int  yn_loss(yn_handle* h, const float* conf_dev, const float* cls_dev, const float* txtytwth_dev,
+             const float* target_dev, int B, float* losses_dev,
+             float* g_conf_dev, float* g_cls_dev, float* g_txtytwth_dev);
+/* Same, reading the predictions from / writing the gradients to the three raw NHWC head tensors
+ * (layout of yn_forward_raw), i.e. without the re-layout copies of models/yolo_nano.py:308-330. */
+int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16_dev, const float* head_s32_dev,
+                   const float* target_dev, int B, float* losses_dev,
+                   float* g_s8_dev, float* g_s16_dev, float* g_s32_dev);
+
 /* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
 /* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],
  * dense [Cout,Cin,3,3]; bias [Cout] or NULL. */

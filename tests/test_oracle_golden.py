@@ -189,3 +189,16 @@ def test_oracle_end_to_end_416(golden):
     bbox, cls = orc.score_decode([h[0] for h in heads], S, C, arch.MULTI_ANCHOR_SIZE_COCO)
     b, s, c = orc.postprocess(bbox, cls, float(case["conf_thresh"]), float(case["nms_thresh"]))
     assert abs(len(s) - len(case["scores"])) <= max(2, len(case["scores"]) // 200)
+
+
+def test_loss_oracle_matches_reference_autograd(golden):
+    """tools.iou_score + tools.loss values and gradients (torch autograd) vs the numpy restatement."""
+    from oracle import loss as oloss
+    g = golden("loss.npz")
+    S = int(g["S"])
+    losses, iou, gc, gcl, gt = oloss.loss_and_grads(g["pred_conf"][..., 0], g["pred_cls"], g["pred_txtytwth"], g["target"], S, arch.MULTI_ANCHOR_SIZE)
+    np.testing.assert_allclose(iou, g["iou"][..., 0], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    np.testing.assert_allclose(gc, g["g_conf"][..., 0], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(gcl, g["g_cls"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(gt, g["g_txtytwth"], atol=1e-6, rtol=1e-4)

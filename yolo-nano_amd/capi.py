@@ -52,6 +52,8 @@ SIGNATURES = {
     "yn_nms": (_i32, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _vp]),
     "yn_postprocess": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_infer": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yn_loss_heads": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_conv3x3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -275,6 +277,28 @@ class Handle:
         out = self.alloc_outputs(B, device=x.device) if out is None else out
         self._ck(self.lib.yn_infer(self.h, x.data_ptr(), B, *[o.data_ptr() for o in out]), "yn_infer")
         return out
+
+    # ---- training loss
+    def loss(self, conf, cls, txtytwth, target, grads=True):
+        """tools.loss + iou_score + decode on the reference's split prediction layout.
+        -> (losses [4] device tensor, (g_conf, g_cls, g_txtytwth) or None)"""
+        B = cls.shape[0]
+        conf, cls, t, target = (v.contiguous().float() for v in (conf, cls, txtytwth, target))
+        losses = torch.empty((4,), dtype=torch.float32, device=cls.device)
+        g = (torch.empty_like(conf), torch.empty_like(cls), torch.empty_like(t)) if grads else (None, None, None)
+        self._ck(self.lib.yn_loss(self.h, conf.data_ptr(), cls.data_ptr(), t.data_ptr(), target.data_ptr(), B, losses.data_ptr(),
+                                  _ptr(g[0]), _ptr(g[1]), _ptr(g[2])), "yn_loss")
+        return losses, (g if grads else None)
+
+    def loss_heads(self, heads, target, grads=True):
+        """Same, directly on the three raw NHWC head tensors; gradients come back in the head layout."""
+        B = heads[0].shape[0]
+        target = target.contiguous().float()
+        losses = torch.empty((4,), dtype=torch.float32, device=target.device)
+        g = [torch.empty_like(t) for t in heads] if grads else [None, None, None]
+        self._ck(self.lib.yn_loss_heads(self.h, _ptr(heads[0]), _ptr(heads[1]), _ptr(heads[2]), target.data_ptr(), B, losses.data_ptr(),
+                                        _ptr(g[0]), _ptr(g[1]), _ptr(g[2])), "yn_loss_heads")
+        return losses, (g if grads else None)
 
     # ---- measurement
     def profile_enable(self, on=True):

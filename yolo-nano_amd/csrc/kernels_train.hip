@@ -1,0 +1,174 @@
+// kernels_train.hip — training-side kernels of the YOLO-Nano hot path.
+//
+//   loss_kernel<HEADS>  models/yolo_nano.py:332-358 in one pass over the candidates: box decode (/S, unclamped),
+//                       tools.iou_score (tools.py:219-233), label assembly (gt_conf = iou.detach()), tools.loss
+//                       (tools.py:236-276: objectness MSE-with-logits, class cross-entropy, txty BCE + twth MSE
+//                       weighted+masked, SmoothL1 on iou; every term sum/B) AND the gradient of the SUM of the four
+//                       losses (train.py:222) w.r.t. the raw predictions.  HEADS = false: predictions in the
+//                       reference's split layout conf [B,N], cls [B,N,C], txtytwth [B,N,4]; HEADS = true: read
+//                       from / write gradients to the three raw NHWC head tensors directly (no re-layout pass).
+//   loss_reduce_kernel  deterministic final sum of the per-block partials.
+#include "yn_internal.h"
+
+namespace ynk {
+
+__device__ __forceinline__ float sigmoid_t(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+struct LossArgs {
+    const float* conf; const float* cls; const float* t;          // split layout (HEADS = false)
+    const float* head[3]; float* ghead[3];                        // head layout  (HEADS = true)
+    const float* target;                                          // [B,N,11] = obj, cls, tx,ty,tw,th, weight, x1,y1,x2,y2
+    float* g_conf; float* g_cls; float* g_t;                      // may be null (forward only)
+    float* partial;                                               // [gridDim.x][4]
+    GridInfo g;
+    int B;
+};
+
+template <bool HEADS>
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
+{
+    __shared__ float red[4][4];
+    const GridInfo& g = a.g;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float l_conf = 0.0f, l_cls = 0.0f, l_box = 0.0f, l_iou = 0.0f;
+    if (i < (long)a.B * g.N) {
+        const int b = (int)(i / g.N), n = (int)(i - (long)b * g.N);
+        const int s = (n >= g.off[2]) ? 2 : ((n >= g.off[1]) ? 1 : 0);
+        const int local = n - g.off[s];
+        const int cell = local / g.A, an = local - cell * g.A;
+        const int gy = cell / g.w[s], gx = cell - gy * g.w[s];
+        const float stride = (float)(8 << s), S = (float)g.S, invB = 1.0f / (float)a.B;
+        const int HC = g.A * (5 + g.C);
+        const float* pconf; const float* pcls; const float* pt;
+        float *qconf = nullptr, *qcls = nullptr, *qt = nullptr;
+        if (HEADS) {
+            const size_t row = ((size_t)b * g.hw[s] + cell) * HC;
+            pconf = a.head[s] + row + an; pcls = a.head[s] + row + g.A + an * g.C; pt = a.head[s] + row + g.A * (1 + g.C) + an * 4;
+            if (a.ghead[s]) { qconf = a.ghead[s] + row + an; qcls = a.ghead[s] + row + g.A + an * g.C; qt = a.ghead[s] + row + g.A * (1 + g.C) + an * 4; }
+        } else {
+            pconf = a.conf + i; pcls = a.cls + (size_t)i * g.C; pt = a.t + (size_t)i * 4;
+            if (a.g_conf) { qconf = a.g_conf + i; qcls = a.g_cls + (size_t)i * g.C; qt = a.g_t + (size_t)i * 4; }
+        }
+        const float* tg = a.target + (size_t)i * 11;
+        const float obj = tg[0], wgt = tg[6];
+        const int gcls = (int)tg[1];
+        const float pos = obj == 1.0f ? 1.0f : 0.0f, neg = obj == 0.0f ? 1.0f : 0.0f, mask = obj > 0.0f ? 1.0f : 0.0f;
+        // decode (models/yolo_nano.py:120-156) / S, unclamped
+        const float tx = pt[0], ty = pt[1], tw = pt[2], th = pt[3];
+        const float sx = sigmoid_t(tx), sy = sigmoid_t(ty), ew = expf(tw), eh = expf(th);
+        const float aw = g.anchors[(s * g.A + an) * 2], ah = g.anchors[(s * g.A + an) * 2 + 1];
+        const float cx = (sx + (float)gx) * stride, cy = (sy + (float)gy) * stride, bw = ew * aw, bh = eh * ah;
+        const float ax1 = (cx - bw / 2) / S, ay1 = (cy - bh / 2) / S, ax2 = (cx + bw / 2) / S, ay2 = (cy + bh / 2) / S;
+        const float bx1 = tg[7], by1 = tg[8], bx2 = tg[9], by2 = tg[10];
+        // tools.iou_score
+        const float tlx = fmaxf(ax1, bx1), tly = fmaxf(ay1, by1), brx = fminf(ax2, bx2), bry = fminf(ay2, by2);
+        const float wa = ax2 - ax1, ha = ay2 - ay1;
+        const float Aa = wa * ha, Ab = (bx2 - bx1) * (by2 - by1);
+        const float en = (tlx < brx && tly < bry) ? 1.0f : 0.0f;
+        const float wi = brx - tlx, hi = bry - tly;
+        const float I = wi * hi * en;
+        const float U = Aa + Ab - I;
+        const float iou = I / U;
+        // objectness (tools.py:12-34); gt_conf = iou.detach()
+        const float sg = sigmoid_t(pconf[0]);
+        l_conf = (5.0f * pos * (sg - iou) * (sg - iou) + neg * sg * sg) * invB;
+        if (qconf) qconf[0] = (5.0f * pos * 2.0f * (sg - iou) + neg * 2.0f * sg) * sg * (1.0f - sg) * invB;
+        // class cross-entropy * mask
+        if (mask > 0.0f || qcls) {
+            float mx = -INFINITY;
+            for (int c = 0; c < g.C; ++c) mx = fmaxf(mx, pcls[c]);
+            float sum = 0.0f;
+            for (int c = 0; c < g.C; ++c) sum += expf(pcls[c] - mx);
+            if (mask > 0.0f) l_cls = (mx + logf(sum) - pcls[gcls]) * invB;
+            if (qcls) {
+                const float k = mask * invB / sum;
+                for (int c = 0; c < g.C; ++c) {
+                    float gr = expf(pcls[c] - mx) * k;
+                    if (c == gcls) gr -= mask * invB;
+                    qcls[c] = gr;
+                }
+            }
+        }
+        // box regression: BCE-with-logits on txty, MSE on twth, both * weight * mask
+        const float wm = wgt * mask * invB;
+        {
+            const float g0 = tg[2], g1 = tg[3], g2 = tg[4], g3 = tg[5];
+            const float b0 = fmaxf(tx, 0.0f) - tx * g0 + log1pf(expf(-fabsf(tx)));
+            const float b1 = fmaxf(ty, 0.0f) - ty * g1 + log1pf(expf(-fabsf(ty)));
+            l_box = ((b0 + b1) + ((tw - g2) * (tw - g2) + (th - g3) * (th - g3))) * wm;
+            // SmoothL1(iou, mask)  (beta = 1), over every candidate
+            const float d = iou - mask;
+            l_iou = (fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f) * invB;
+            if (qt) {
+                float gt0 = (sx - g0) * wm, gt1 = (sy - g1) * wm, gt2 = 2.0f * (tw - g2) * wm, gt3 = 2.0f * (th - g3) * wm;
+                // d iou_loss / d box, through iou = I / (Aa + Ab - I); torch.max/min split the gradient on ties
+                const float giou = (fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f)) * invB;
+                const float wx1 = ax1 > bx1 ? 1.0f : (ax1 == bx1 ? 0.5f : 0.0f), wy1 = ay1 > by1 ? 1.0f : (ay1 == by1 ? 0.5f : 0.0f);
+                const float wx2 = ax2 < bx2 ? 1.0f : (ax2 == bx2 ? 0.5f : 0.0f), wy2 = ay2 < by2 ? 1.0f : (ay2 == by2 ? 0.5f : 0.0f);
+                const float dI[4] = {-hi * en * wx1, -wi * en * wy1, hi * en * wx2, wi * en * wy2};
+                const float dA[4] = {-ha, -wa, ha, wa};
+                float gb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = (dI[k] * U - I * (dA[k] - dI[k])) / (U * U);
+                    if (!(v == v) || fabsf(v) == INFINITY) v = 0.0f;      // 0/0 for degenerate pairs carries no gradient
+                    gb[k] = v * giou;
+                }
+                const float dcx = sx * (1.0f - sx) * stride / S, dcy = sy * (1.0f - sy) * stride / S;
+                gt0 += (gb[0] + gb[2]) * dcx;
+                gt1 += (gb[1] + gb[3]) * dcy;
+                gt2 += 0.5f * (gb[2] - gb[0]) * (bw / S);
+                gt3 += 0.5f * (gb[3] - gb[1]) * (bh / S);
+                qt[0] = gt0; qt[1] = gt1; qt[2] = gt2; qt[3] = gt3;
+            }
+        }
+    }
+    // deterministic block reduction: wave shuffle, then 4 waves through LDS
+    float v[4] = {l_conf, l_cls, l_box, l_iou};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = v[0]; red[wave][1] = v[1]; red[wave][2] = v[2]; red[wave][3] = v[3]; }
+    __syncthreads();
+    if (threadIdx.x < 4) a.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out)
+{
+    __shared__ double red[4][4];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblocks; i += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += (double)partial[(size_t)i * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 4; ++k) red[wave][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+int loss_num_blocks(const GridInfo& g, int B) { return (int)(((long)B * g.N + 255) / 256); }
+
+void launch_loss(const float* conf, const float* cls, const float* t, const float* const head[3], float* const ghead[3],
+                 const float* target, const GridInfo& g, int B, float* partial, float* losses,
+                 float* g_conf, float* g_cls, float* g_t, hipStream_t s)
+{
+    LossArgs a{};
+    a.conf = conf; a.cls = cls; a.t = t; a.target = target; a.g_conf = g_conf; a.g_cls = g_cls; a.g_t = g_t;
+    a.partial = partial; a.g = g; a.B = B;
+    const int nb = loss_num_blocks(g, B);
+    if (head) {
+        for (int k = 0; k < 3; ++k) { a.head[k] = head[k]; a.ghead[k] = ghead ? ghead[k] : nullptr; }
+        hipLaunchKernelGGL(loss_kernel<true>, dim3(nb), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(loss_kernel<false>, dim3(nb), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nb, losses);
+}
+
+}  // namespace ynk

@@ -83,6 +83,8 @@ struct yn_handle {
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
+    float* loss_partial = nullptr;
+    size_t loss_partial_cap = 0;
     // graphs / profiling
     bool use_graph = false;
     bool autotune = true;
@@ -646,7 +648,7 @@ void yn_destroy(yn_handle* h)
         if (l.b_ref) (void)hipFree(l.b_ref);
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
-                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0]};
+                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -918,6 +920,46 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
         HIPCHK(h, hipGetLastError());
         return 0;
     });
+}
+
+// ---- training loss ----------------------------------------------------------
+static int ensure_loss(yn_handle* h, int B)
+{
+    const size_t need = (size_t)loss_num_blocks(h->grid, B) * 4;
+    if (need <= h->loss_partial_cap) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->loss_partial) HIPCHK(h, hipFree(h->loss_partial));
+    HIPCHK(h, hipMalloc((void**)&h->loss_partial, need * sizeof(float)));
+    h->loss_partial_cap = need;
+    return 0;
+}
+
+int yn_loss(yn_handle* h, const float* conf, const float* cls, const float* txtytwth, const float* target, int B,
+            float* losses, float* g_conf, float* g_cls, float* g_txtytwth)
+{
+    if (!h) return 1;
+    if (B <= 0) return fail(h, "yn_loss: batch must be positive");
+    if ((g_conf != nullptr) != (g_cls != nullptr) || (g_conf != nullptr) != (g_txtytwth != nullptr))
+        return fail(h, "yn_loss: pass all three gradient buffers or none");
+    if (ensure_loss(h, B)) return 1;
+    launch_loss(conf, cls, txtytwth, nullptr, nullptr, target, h->grid, B, h->loss_partial, losses, g_conf, g_cls, g_txtytwth, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, const float* head_s32, const float* target, int B,
+                  float* losses, float* g_s8, float* g_s16, float* g_s32)
+{
+    if (!h) return 1;
+    if (B <= 0) return fail(h, "yn_loss_heads: batch must be positive");
+    if ((g_s8 != nullptr) != (g_s16 != nullptr) || (g_s8 != nullptr) != (g_s32 != nullptr))
+        return fail(h, "yn_loss_heads: pass all three gradient buffers or none");
+    if (ensure_loss(h, B)) return 1;
+    const float* const head[3] = {head_s8, head_s16, head_s32};
+    float* const ghead[3] = {g_s8, g_s16, g_s32};
+    launch_loss(nullptr, nullptr, nullptr, head, ghead, target, h->grid, B, h->loss_partial, losses, nullptr, nullptr, nullptr, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
 }
 
 // ---- single operators ----------------------------------------------------------------------------

@@ -90,4 +90,10 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
                        int32_t* ids_scratch, float* sbox_scratch, void* matrix_scratch, int32_t* keep, int32_t* count, hipStream_t s);
 
+// ---- training loss (kernels_train.hip) --------------------------------------------------------------
+int  loss_num_blocks(const GridInfo& g, int B);
+void launch_loss(const float* conf, const float* cls, const float* t, const float* const head[3], float* const ghead[3],
+                 const float* target, const GridInfo& g, int B, float* partial, float* losses,
+                 float* g_conf, float* g_cls, float* g_t, hipStream_t s);
+
 }  // namespace ynk
