@@ -957,6 +957,96 @@ void launch_stem(const float* x, int B, int H, int W, const float* w, const floa
     if (Cout == 24) hipLaunchKernelGGL(stem_kernel<24>, dim3(blocks), dim3(256), 0, s, x, B, H, W, w, bias, act, y);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Stem conv (3x3 s2, 3->COUT, +bias+act) fused with the 3x3 s2 max pool that follows it
+// (backbone/shufflenetv2.py:109-116, 159).  A block owns 8x7 pooled pixels: it computes the 17x15 conv
+// pixels they need (255 of 256 threads busy, one conv pixel x COUT channels each) into LDS, then pools from
+// LDS.  The 24 x (S/2)^2 conv activation (133 MB per bs=32 step at 416) never goes to memory.
+// -------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ x, int B, int H, int W,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int act, float* __restrict__ y)
+{
+    constexpr int PR = 8, PC = 7, CR = 2 * PR + 1, CC = 2 * PC + 1;     // pooled tile, conv tile
+    __shared__ __attribute__((aligned(16))) float ws[28 * COUT];
+    __shared__ __attribute__((aligned(16))) float ct[CR * CC * COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) ws[27 * COUT + i] = bias[i];
+    const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;               // conv output extent
+    const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;             // pooled extent
+    const int tiles_x = (Wp + PC - 1) / PC, tiles_y = (Hp + PR - 1) / PR;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int py0 = (tile / tiles_x) * PR, px0 = (tile % tiles_x) * PC;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < CR * CC) {
+        const int r = t / CC, c = t - r * CC;
+        const int cy = 2 * py0 - 1 + r, cx = 2 * px0 - 1 + c;           // conv pixel of this thread
+        float acc[COUT];
+        if (cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = ws[27 * COUT + co];
+#pragma unroll 1
+            for (int q = 0; q < 9; ++q) {
+                const int ci = q / 3, ky = q - ci * 3;
+                const float* xp = x + ((size_t)b * 3 + ci) * H * W;
+                const int iy = cy * 2 - 1 + ky;
+                const bool rowok = iy >= 0 && iy < H;
+                float in[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int ix = cx * 2 - 1 + k;
+                    in[k] = (rowok && ix >= 0 && ix < W) ? xp[(size_t)iy * W + ix] : 0.0f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4* wr = reinterpret_cast<const float4*>(ws + (q * 3 + kx) * COUT);
+#pragma unroll
+                    for (int c4 = 0; c4 < COUT / 4; ++c4) {
+                        const float4 wv = wr[c4];
+                        acc[c4 * 4 + 0] += in[kx] * wv.x; acc[c4 * 4 + 1] += in[kx] * wv.y;
+                        acc[c4 * 4 + 2] += in[kx] * wv.z; acc[c4 * 4 + 3] += in[kx] * wv.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = apply_act(acc[co], act);
+        } else {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = -INFINITY;          // max-pool padding
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4)
+            *reinterpret_cast<float4*>(ct + t * COUT + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+    }
+    __syncthreads();
+    constexpr int C4 = COUT / 4;
+    for (int i = t; i < PR * PC * C4; i += 256) {
+        const int c4 = i % C4, pp = i / C4;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        const int py = py0 + pr, px = px0 + pc;
+        if (py >= Hp || px >= Wp) continue;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float4 v = *reinterpret_cast<const float4*>(ct + ((2 * pr + dy) * CC + 2 * pc + dx) * COUT + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        *reinterpret_cast<float4*>(y + (((size_t)b * Hp + py) * Wp + px) * COUT + c4 * 4) = m;
+    }
+}
+
+void launch_stem_pool(const float* x, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* y, hipStream_t s)
+{
+    const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+    const int tiles = ((Wp + 6) / 7) * ((Hp + 7) / 8);
+    g_last_kernel = "stem_pool_kernel<24>";
+    if (Cout == 24) hipLaunchKernelGGL(stem_pool_kernel<24>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, B, H, W, w, bias, act, y);
+}
+
 // 3x3 stride-2 pad-1 max pool (implicit -inf padding), NHWC, thread = (output pixel, 4 channels).
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ y)
 {

@@ -69,68 +69,87 @@ __device__ __forceinline__ unsigned f32_order_bits(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// One wavefront per grid cell: the cell's row of A*(1+C+4) logits is read once, coalesced (lane = class),
-// softmax max / sum / arg-max are wave reductions.  KMAX*64 >= C.
+__device__ __forceinline__ float group16_max(float v)
+{
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v)
+{
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned long long group16_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// 16 lanes per candidate (4 candidates per wavefront): lane j of a group owns classes j, j+16, ...; the softmax
+// max / sum / arg-max are 4-step reductions inside the 16-lane row (DPP row operations).  KMAX*16 >= C.
 template <bool FULL, int KMAX>
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
                                                       GridInfo g, int B, float conf_thresh,
                                                       float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
                                                       float* __restrict__ all_class)
 {
-    const int lane = threadIdx.x & 63;
-    const int cells_per_image = g.N / g.A;
-    const long total_cells = (long)B * cells_per_image;
-    const int HC = g.A * (5 + g.C);
-    for (long wc = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wc < total_cells; wc += (long)gridDim.x * 4) {
-        const int b = (int)(wc / cells_per_image);
-        const int cg = (int)(wc - (long)b * cells_per_image);            // cell index over the three scales
-        const int s = (cg >= g.hw[0] + g.hw[1]) ? 2 : ((cg >= g.hw[0]) ? 1 : 0);
-        const int cell = cg - (s == 2 ? g.hw[0] + g.hw[1] : (s == 1 ? g.hw[0] : 0));
+    const int j = threadIdx.x & 15;
+    const long total = (long)B * g.N;
+    const int HC = g.head_ld;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; i < total; i += ((long)gridDim.x * 256) >> 4) {
+        const int b = (int)(i / g.N), n = (int)(i - (long)b * g.N);
+        int s, cell, a;
+        cand_location(g, n, s, cell, a);                                  // candidate order of models/yolo_nano.py:308-330
         const float* head = s == 0 ? h0 : (s == 1 ? h1 : h2);
         const float* row = head + ((size_t)b * g.hw[s] + cell) * HC;
-        for (int a = 0; a < g.A; ++a) {
-            const long i = (long)b * g.N + g.off[s] + cell * g.A + a;   // candidate index (models/yolo_nano.py:308-330)
-            const float obj = sigmoid_f(row[a]);
-            const float* cl = row + g.A + a * g.C;
-            float v[KMAX];
-            float mx = -INFINITY;
+        const float obj = sigmoid_f(row[a]);
+        const float* cl = row + g.A + a * g.C;
+        float v[KMAX];
+        float mx = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int c = lane + 64 * k;
-                v[k] = c < g.C ? cl[c] : -INFINITY;
-                mx = fmaxf(mx, v[k]);
-            }
-            mx = wave_max_f(mx);
-            float sum = 0.0f;
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = j + 16 * k;
+            v[k] = c < g.C ? cl[c] : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+        mx = group16_max(mx);
+        float sum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int c = lane + 64 * k;
-                v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
-                sum += v[k];
-            }
-            sum = wave_sum_f(sum);
-            unsigned long long best = 0;
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = j + 16 * k;
+            v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
+            sum += v[k];
+        }
+        sum = group16_sum(sum);
+        unsigned long long best = 0;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int c = lane + 64 * k;
-                if (c < g.C) {
-                    const float p = v[k] / sum * obj;
-                    if (FULL) all_class[(size_t)i * g.C + c] = p;
-                    const unsigned long long key = ((unsigned long long)f32_order_bits(p) << 32) | (unsigned)(0x7fffffff - c);   // first max wins ties
-                    best = key > best ? key : best;
-                }
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = j + 16 * k;
+            if (c < g.C) {
+                const float p = v[k] / sum * obj;
+                if (FULL) all_class[(size_t)i * g.C + c] = p;
+                const unsigned long long key = ((unsigned long long)f32_order_bits(p) << 32) | (unsigned)(0x7fffffff - c);   // first max wins ties
+                best = key > best ? key : best;
             }
-            if (!FULL) best = wave_max_u64(best);
-            if (lane == 0) {
-                float box[4];
-                decode_one(g, s, cell, a, row + g.A * (1 + g.C) + a * 4, (float)g.S, box, true);
-                *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
-                if (!FULL) {
-                    const unsigned ub = (unsigned)(best >> 32);
-                    const float sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
-                    scores[i] = sc;
-                    cls[i] = (sc >= conf_thresh) ? (int)(0x7fffffff - (unsigned)(best & 0xffffffffu)) : -1;
-                }
+        }
+        if (!FULL) best = group16_max_u64(best);
+        if (j == 0) {
+            float box[4];
+            decode_one(g, s, cell, a, row + g.A * (1 + g.C) + a * 4, (float)g.S, box, true);
+            *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
+            if (!FULL) {
+                const unsigned ub = (unsigned)(best >> 32);
+                const float sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
+                scores[i] = sc;
+                cls[i] = (sc >= conf_thresh) ? (int)(0x7fffffff - (unsigned)(best & 0xffffffffu)) : -1;
             }
         }
     }
@@ -140,15 +159,16 @@ template <bool FULL>
 static void launch_decode(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
                           float* boxes, float* scores, int32_t* cls, float* all_class, hipStream_t s)
 {
-    const long cells = (long)B * (g.N / g.A);
-    long blocks = (cells + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const long cands = (long)B * g.N;
+    long blocks = (cands + 15) / 16;                        // 16 candidates per 256-thread block
+    if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
     const dim3 grid((unsigned)blocks), blk(256);
-    if (g.C <= 64) hipLaunchKernelGGL((decode_kernel<FULL, 1>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
-    else if (g.C <= 128) hipLaunchKernelGGL((decode_kernel<FULL, 2>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
-    else if (g.C <= 256) hipLaunchKernelGGL((decode_kernel<FULL, 4>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
-    else hipLaunchKernelGGL((decode_kernel<FULL, 16>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    if (g.C <= 16) hipLaunchKernelGGL((decode_kernel<FULL, 1>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else if (g.C <= 32) hipLaunchKernelGGL((decode_kernel<FULL, 2>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else if (g.C <= 80) hipLaunchKernelGGL((decode_kernel<FULL, 5>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else if (g.C <= 256) hipLaunchKernelGGL((decode_kernel<FULL, 16>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
+    else hipLaunchKernelGGL((decode_kernel<FULL, 64>), grid, blk, 0, s, heads[0], heads[1], heads[2], g, B, conf_thresh, boxes, scores, cls, all_class);
 }
 
 void launch_score_full(const float* const heads[3], const GridInfo& g, int B, float* all_bbox, float* all_class, hipStream_t s)

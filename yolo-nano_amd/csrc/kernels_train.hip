@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
         const int cell = local / g.A, an = local - cell * g.A;
         const int gy = cell / g.w[s], gx = cell - gy * g.w[s];
         const float stride = (float)(8 << s), S = (float)g.S, invB = 1.0f / (float)a.B;
-        const int HC = g.A * (5 + g.C);
+        const int HC = g.head_ld;
         const float* pconf; const float* pcls; const float* pt;
         float *qconf = nullptr, *qcls = nullptr, *qt = nullptr;
         if (HEADS) {

@@ -188,6 +188,7 @@ int set_grid_info(yn_handle* h, int S)
         off += w * w * g.A;
     }
     g.N = off;
+    g.head_ld = g.A * (5 + g.C);
     for (int i = 0; i < 18; ++i) g.anchors[i] = h->cfg.anchors[i];
     return 0;
 }
@@ -282,19 +283,20 @@ int ensure_post(yn_handle* h, int B, int N, int C)
 
 int ensure_heads(yn_handle* h, int B)
 {
-    const size_t need = (size_t)B * (h->grid.hw[0] + h->grid.hw[1] + h->grid.hw[2]) * h->head_ch;
+    const int hld = (h->head_ch + 3) & ~3;                  // internal heads: rows padded to 16 bytes => float4 stores
+    const size_t need = (size_t)B * (h->grid.hw[0] + h->grid.hw[1] + h->grid.hw[2]) * hld;
     if (need <= h->heads_cap) {
         // re-derive the split for the current grid
-        h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * h->head_ch;
-        h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * h->head_ch;
+        h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * hld;
+        h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * hld;
         return 0;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->heads_int[0]) HIPCHK(h, hipFree(h->heads_int[0]));
     HIPCHK(h, hipMalloc((void**)&h->heads_int[0], need * sizeof(float) + 1024));
     h->heads_cap = need;
-    h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * h->head_ch;
-    h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * h->head_ch;
+    h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * hld;
+    h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * hld;
     h->graphs.clear();
     return 0;
 }
@@ -364,7 +366,7 @@ int tune_pw(yn_handle* h, GemmArgs a)
 }
 
 void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
-            float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
+            float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off, int n_store = 0)
 {
     GemmArgs a{};
     a.in = in; a.in_ld = in_ld; a.in_off = in_off;
@@ -372,6 +374,7 @@ void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     a.out = out; a.out_ld = out_ld; a.out_off = out_off;
     a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    if (n_store > l.cout && n_store <= l.Npad) a.N = n_store;     // padded output row: the extra (zero-weight) columns are stored too
     a.cfg = -1;
     a.cfg = tune_pw(h, a);
     Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
@@ -465,7 +468,7 @@ void join_from(yn_handle* h, int k)
 }
 
 // The network: x NCHW [B,3,S,S] -> three NHWC head tensors.
-int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
+int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int head_ld)
 {
     const int S = h->grid.S;
     h->arena_used = 0;
@@ -477,14 +480,11 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
     TAKE(a0, (size_t)B * H1 * H1 * 24);
     TAKE(a1, (size_t)B * H2 * H2 * 24);
     {
+        // stem conv + maxpool in one kernel: the [B,S/2,S/2,24] conv activation stays in LDS (a0 is unused)
         const Layer& l = L(h, "stem");
         const double Mo = (double)B * H1 * H1;
-        Bracket br(h, "stem", 2.0 * Mo * 27 * 24, 4.0 * ((double)B * 3 * S * S + Mo * 24));
-        launch_stem(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a0, h->cur);
-    }
-    {
-        Bracket br(h, "maxpool", 0.0, 4.0 * 24 * ((double)B * H1 * H1 + (double)B * H2 * H2));
-        launch_maxpool(a0, B, H1, H1, 24, a1, h->cur);
+        Bracket br(h, "stem+maxpool", 2.0 * Mo * 27 * 24, 4.0 * ((double)B * 3 * S * S + (double)B * H2 * H2 * 24));
+        launch_stem_pool(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a1, h->cur);
     }
     const float* cur = a1;
     int curC = 24, curH = H2;
@@ -551,7 +551,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3])
         const std::string P = nm;
         run_dwpw(h, L(h, P + ".0"), L(h, P + ".1"), feats[hd], NECK, 0, B, Ws[hd], Ws[hd], hA, hB, NECK, 0, nullptr, 0, 0);
         run_dwpw(h, L(h, P + ".2"), L(h, P + ".3"), hB, NECK, 0, B, Ws[hd], Ws[hd], hA, hC, NECK, 0, nullptr, 0, 0);
-        run_pw(h, L(h, P + ".4"), hC, NECK, 0, M, heads[hd], h->head_ch, 0, nullptr, 0, 0);
+        run_pw(h, L(h, P + ".4"), hC, NECK, 0, M, heads[hd], head_ld, 0, nullptr, 0, 0, head_ld);
         return 0;
     };
     fork_to(h, 0);
@@ -827,7 +827,7 @@ int yn_forward_raw(yn_handle* h, const float* x_dev, int B, float* head_s8, floa
     if (ensure_arena(h, B, h->grid.S)) return 1;
     float* const heads[3] = {head_s8, head_s16, head_s32};
     std::vector<uintptr_t> key = {1, (uintptr_t)B, (uintptr_t)h->grid.S, (uintptr_t)x_dev, (uintptr_t)head_s8, (uintptr_t)head_s16, (uintptr_t)head_s32};
-    return run_maybe_graph(h, key, [&]() { return run_network(h, x_dev, B, heads); });
+    return run_maybe_graph(h, key, [&]() { return run_network(h, x_dev, B, heads, h->head_ch); });
 }
 
 int yn_score_full(yn_handle* h, const float* h8, const float* h16, const float* h32, int B, float* all_bbox, float* all_class)
@@ -898,13 +898,14 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
 {
     if (!h) return 1;
     if (check_ready(h, B)) return 1;
-    const GridInfo g = h->grid;
+    GridInfo g = h->grid;
+    g.head_ld = (h->head_ch + 3) & ~3;
     if (ensure_arena(h, B, g.S) || ensure_post(h, B, g.N, g.C) || ensure_heads(h, B)) return 1;
     std::vector<uintptr_t> key = {2, (uintptr_t)B, (uintptr_t)g.S, (uintptr_t)x_dev, (uintptr_t)out_boxes, (uintptr_t)out_scores,
                                   (uintptr_t)out_cls, (uintptr_t)out_index, (uintptr_t)count};
     return run_maybe_graph(h, key, [&]() {
         float* const heads[3] = {h->heads_int[0], h->heads_int[1], h->heads_int[2]};
-        if (run_network(h, x_dev, B, heads)) return 1;
+        if (run_network(h, x_dev, B, heads, g.head_ld)) return 1;
         const float* const ch[3] = {heads[0], heads[1], heads[2]};
         {
             set_last_kernel_name("decode_kernel<false>");

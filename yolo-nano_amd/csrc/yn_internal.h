@@ -39,6 +39,8 @@ void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
                  int Cout, int act, float* y, hipStream_t s);
 void launch_maxpool(const float* x, int B, int H, int W, int C, float* y, hipStream_t s);
+// stem conv + max pool fused: x NCHW [B,3,H,W] -> y NHWC [B,H/4,W/4,Cout]
+void launch_stem_pool(const float* x_nchw, int B, int H, int W, const float* w, const float* bias, int Cout, int act, float* y, hipStream_t s);
 void launch_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, hipStream_t s);
 void launch_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, hipStream_t s);
 
@@ -59,6 +61,7 @@ void launch_fold_pack(const FoldArgs& a, hipStream_t s);
 struct GridInfo {
     int S, C, A, N;
     int hw[3], w[3], off[3];                    // cells per scale, width per scale, candidate offset
+    int head_ld;                                // row stride (floats) of the raw head tensors: A(5+C), or padded to a multiple of 4
     float anchors[18];
 };
 
