@@ -463,6 +463,180 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmArgs a)
     }
 }
 
+// Same algorithm, specialised for a compile-time Cin: the weight stream is chunked per TAP (Cin k-values, one
+// LDS buffer, next tap prefetched into registers) => 9 chunk boundaries instead of 9*Cin/32, and the halo is
+// staged with 16-byte global loads.
+template <int NT, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
+{
+    constexpr int BM = 128, BN = 32 * NT, BS = BN * 2, KPT = CIN / 2;      // k-pairs per tap
+    constexpr int B_PER = (KPT * BN / 2 + 255) / 256;                      // float4 per thread per tap
+    constexpr int CS = CIN + 2, NQ = CIN / 4;
+    extern __shared__ __attribute__((aligned(16))) float c3t_smem[];
+    const int W = a.W, H = a.H, HW = H * W;
+    const int npix = BM + 2 * W + 2;
+    float* halo = c3t_smem;                                  // [npix][CS]
+    float* Bs = c3t_smem + ((npix * CS + 3) & ~3);           // [KPT][BS]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int p0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int base = p0 - W - 1;
+
+    float4 b_reg[B_PER];
+    auto prefetch_b = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            const int n = n0 + c4 * 2;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (kp < KPT && n < a.Npad) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)(tap * KPT + kp) * a.Npad + n) * 2);
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = t + 256 * i;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            if (kp < KPT) *reinterpret_cast<float4*>(Bs + kp * BS + c4 * 4) = b_reg[i];
+        }
+    };
+    prefetch_b(0);
+
+    // ---- halo, 16-byte loads: thread = (channel quad, pixel lane) ----
+    {
+        constexpr int U = 8, CQ = CIN / 4, PPL = 256 / CQ;
+        const int cq = t % CQ, pl = t / CQ;
+        if (pl < PPL) {
+            for (int i0 = pl; i0 < npix; i0 += PPL * U) {
+                float4 v[U], u2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * PPL;
+                    const int q = base + i;
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    u2[u] = v[u];
+                    if (i < npix && q >= 0 && q < a.M) {
+                        v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)q * CIN + 4 * cq);
+                        if (a.resample) {
+                            const int b = q / HW, rem = q - b * HW;
+                            const int y = rem / W, x = rem - y * W;
+                            size_t p2;
+                            if (a.resample == 1) p2 = ((size_t)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                            else                 p2 = ((size_t)b * (H << 1) + (y << 1)) * (W << 1) + (x << 1);
+                            u2[u] = *reinterpret_cast<const float4*>(a.in2 + p2 * CIN + 4 * cq);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * PPL;
+                    if (i < npix) {                          // pixel stride CS*4 bytes is only 8-byte aligned
+                        *reinterpret_cast<float2*>(halo + i * CS + 4 * cq) = make_float2(v[u].x + u2[u].x, v[u].y + u2[u].y);
+                        *reinterpret_cast<float2*>(halo + i * CS + 4 * cq + 2) = make_float2(v[u].z + u2[u].z, v[u].w + u2[u].w);
+                    }
+                }
+            }
+        }
+    }
+    stage_b();
+
+    const int r = wave * 32 + l31;
+    const int m = p0 + r;
+    unsigned tapmask = 0;
+    if (m < a.M) {
+        const int rem = m % HW;
+        const int y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) tapmask |= 1u << tap;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
+
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) prefetch_b(tap + 1);
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const bool ok = (tapmask >> tap) & 1u;
+        const float* Ab = halo + (W + 1 + r + dy * W + dx) * CS + 2 * h;
+        const float* Bb = Bs + l31 * 2 + h * BS;
+        float2 av = *reinterpret_cast<const float2*>(Ab);
+        float2 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
+#pragma unroll 8
+        for (int q = 0; q < NQ; ++q) {
+            float2 av_n = av, bv_n[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+            if (q + 1 < NQ) {
+                av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float ax = ok ? av.x : 0.0f, ay = ok ? av.y : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bv[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bv[nt].y, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            av = av_n;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+        }
+        if (tap + 1 < 9) {
+            __syncthreads();                                 // everyone is done with this tap's weights
+            stage_b();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: quad transpose -> 16-byte stores (out_ld = N-stride, multiples of 4 here)
+    const int j = lane & 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ncol = n0 + nt * 32 + l31;
+        const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
+        const int nq = n0 + nt * 32 + (l31 & ~3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
+            float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
+            {
+                const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            }
+            {
+                const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
+                const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+            }
+            const int mm = p0 + wave * 32 + 8 * g + 4 * h + j;
+            if (mm < a.M && nq < a.N)
+                *reinterpret_cast<float4*>(a.out + (size_t)mm * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
+        }
+    }
+}
+
+static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT)
+{
+    const int npix = 128 + 2 * W + 2;
+    return ((size_t)((npix * (Cin + 2) + 3) & ~3) + (size_t)(Cin / 2) * (32 * NT * 2)) * sizeof(float);
+}
+
 static size_t conv3x3_halo_lds(int W, int Cin, int NT)
 {
     const int npix = 128 + 2 * W + 2;
@@ -795,6 +969,26 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
     // LDS-resident halo kernel when the tile fits (always true for the 96-channel neck up to W ~ 150)
     const int nt32 = a.Npad / 32;
     const int NT = nt32 >= 3 && nt32 % 3 == 0 ? 3 : (nt32 % 2 == 0 ? 2 : 1);
+    // the network's 96->96 neck convs: per-tap weight chunks + 16-byte halo staging.  Small maps (few 128-pixel
+    // tiles) split N over three block columns instead: the kernel is then latency- not MFMA-bound.
+    if (a.K == 96 && NT == 3 && a.in_off == 0 && a.in_ld == 96 && (a.N & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_off & 3) == 0 &&
+        conv3x3_halo_tap_lds(a.W, 96, 3) <= 160 * 1024) {
+        static bool attr_t = false;
+        if (!attr_t) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<3, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_t = true;
+        }
+        const int tiles = (a.M + 127) / 128;
+        if (tiles * (a.Npad / 96) >= 256) {
+            g_last_kernel = "conv3x3_halo_tap_kernel<3,96>";
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<3, 96>), dim3(tiles, a.Npad / 96), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 3), s, a);
+        } else {
+            g_last_kernel = "conv3x3_halo_tap_kernel<1,96>";
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96>), dim3(tiles, a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1), s, a);
+        }
+        return;
+    }
     const size_t lds = (a.K % 32 == 0 && a.in_off == 0) ? conv3x3_halo_lds(a.W, a.K, NT) : (size_t)1 << 30;
     if (lds <= 160 * 1024 && a.K / 2 <= 256) {
         static bool attr = false;
