@@ -133,6 +133,12 @@ int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16
                    const float* target_dev, int B, float* losses_dev,
                    float* g_s8_dev, float* g_s16_dev, float* g_s32_dev);
 
+/* torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4).step() (train.py:167-171, 230) on ONE flat float32 bucket
+ * holding every parameter (1.27-1.33 M elements), fused with the 1/world_size averaging of the all-reduced
+ * gradient sum:  g = grads*grad_scale + wd*p ; buf = first_step ? g : momentum*buf + g ; p -= lr*buf. */
+int  yn_sgd_step(yn_handle* h, float* params_dev, const float* grads_dev, float* momentum_buf_dev, int64_t n,
+                 float lr, float momentum, float weight_decay, float grad_scale, int first_step);
+
 /* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
 /* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],
  * dense [Cout,Cin,3,3]; bias [Cout] or NULL. */

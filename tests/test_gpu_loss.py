@@ -99,3 +99,24 @@ def test_loss_heads_layout_equals_split_layout():
         assert torch.equal(g[:, :, A + A * C:].reshape(B, hw * A, 4), gt[:, sl])
         off += hw * A
     h.close()
+
+
+def test_sgd_step_matches_torch_optim():
+    """Fused SGD (train.py:167-171: lr, momentum 0.9, weight_decay 5e-4) on a flat bucket of the real parameter count,
+    with the 1/world gradient scaling folded in, against torch.optim.SGD on the CPU for three steps."""
+    from yolo_nano_amd import capi
+    n = arch.param_count("1.0x", 80)                      # 1,326,305 (odd: exercises the scalar tail)
+    rs = np.random.RandomState(0)
+    p0 = rs.standard_normal(n).astype(np.float32)
+    h = capi.Handle(64, 80, arch.MULTI_ANCHOR_SIZE_COCO)
+    p = dev(p0.copy()); buf = torch.zeros_like(p)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    world = 8
+    for step in range(3):
+        g = rs.standard_normal(n).astype(np.float32)
+        h.sgd_step(p, dev(g * world), buf, 1e-3, 0.9, 5e-4, grad_scale=1.0 / world, first_step=(step == 0))
+        ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    h.close()

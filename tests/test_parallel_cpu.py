@@ -57,3 +57,39 @@ def test_shard_properties():
             assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from yolo_nano_amd import parallel
+    parallel.init("gloo")
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+    bucket = parallel.FlatBucket(lin.named_parameters())
+    assert all(p.data_ptr() >= bucket.params.data_ptr() for p in lin.parameters())     # parameters live inside the bucket
+    for i in range(len(bucket.names)):
+        bucket.grad_view(i).fill_(float(rank + 1) * (i + 1))
+    scale = parallel_scale = bucket.allreduce_grads()
+    q.put((rank, scale, [float(bucket.grad_view(i).flatten()[0]) for i in range(len(bucket.names))], bucket.params.numel()))
+    parallel.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_two_ranks():
+    """SURVEY §8e training row: ONE flat-bucket all-reduce(sum) of the gradients, averaged by the returned scale."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, scale, firsts, n in res:
+        assert scale == 0.5
+        assert firsts == [3.0 * (i + 1) for i in range(len(firsts))]       # (1 + 2) * (i + 1): summed over both ranks
+        assert n == 3 * 4 * 9 + 4 + 4 + 4 + 4 * 2 + 2

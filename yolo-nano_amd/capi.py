@@ -54,6 +54,7 @@ SIGNATURES = {
     "yn_infer": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_loss_heads": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_conv3x3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -299,6 +300,12 @@ class Handle:
         self._ck(self.lib.yn_loss_heads(self.h, _ptr(heads[0]), _ptr(heads[1]), _ptr(heads[2]), target.data_ptr(), B, losses.data_ptr(),
                                         _ptr(g[0]), _ptr(g[1]), _ptr(g[2])), "yn_loss_heads")
         return losses, (g if grads else None)
+
+    def sgd_step(self, params, grads, momentum_buf, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, first_step=False):
+        """In-place SGD on flat float32 buffers (train.py:167-171); grad_scale = 1/world_size after a sum all-reduce."""
+        assert params.is_contiguous() and grads.is_contiguous() and momentum_buf.is_contiguous() and params.numel() == grads.numel() == momentum_buf.numel()
+        self._ck(self.lib.yn_sgd_step(self.h, params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), params.numel(),
+                                      float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step))), "yn_sgd_step")
 
     # ---- measurement
     def profile_enable(self, on=True):

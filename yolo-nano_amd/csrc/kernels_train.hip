@@ -171,4 +171,43 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nb, losses);
 }
 
+// -------------------------------------------------------------------------------------------------
+// torch.optim.SGD(momentum, weight_decay) step (train.py:167-171, 230) over one FLAT parameter bucket, fused with
+// the 1/world_size scaling of the all-reduced gradient sum (one flat bucket, one RCCL all-reduce per step):
+//     g = grad * grad_scale + wd * p ;  buf = first ? g : momentum * buf + g ;  p -= lr * buf
+// (dampening 0, nesterov off — the reference's settings).  16-byte accesses, grid-stride.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                   long n, float lr, float momentum, float wd, float grad_scale, int first)
+{
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
+        const float gx = gv.x * grad_scale + wd * pv.x, gy = gv.y * grad_scale + wd * pv.y;
+        const float gz = gv.z * grad_scale + wd * pv.z, gw = gv.w * grad_scale + wd * pv.w;
+        bv.x = first ? gx : momentum * bv.x + gx; bv.y = first ? gy : momentum * bv.y + gy;
+        bv.z = first ? gz : momentum * bv.z + gz; bv.w = first ? gw : momentum * bv.w + gw;
+        pv.x -= lr * bv.x; pv.y -= lr * bv.y; pv.z -= lr * bv.z; pv.w -= lr * bv.w;
+        reinterpret_cast<float4*>(buf)[i] = bv;
+        reinterpret_cast<float4*>(p)[i] = pv;
+    }
+    const long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x;        // tail (n % 4 elements)
+    if (i < n) {
+        const float gg = g[i] * grad_scale + wd * p[i];
+        const float b = first ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
+void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s)
+{
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, grad_scale, first);
+}
+
 }  // namespace ynk

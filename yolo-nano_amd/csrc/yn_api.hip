@@ -963,6 +963,17 @@ int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, con
     return 0;
 }
 
+int yn_sgd_step(yn_handle* h, float* params, const float* grads, float* momentum_buf, int64_t n,
+                float lr, float momentum, float weight_decay, float grad_scale, int first_step)
+{
+    if (!h) return 1;
+    if (n < 0 || !params || !grads || !momentum_buf) return fail(h, "yn_sgd_step: bad arguments");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) return fail(h, "yn_sgd_step: buffers must be 16-byte aligned");
+    launch_sgd(params, grads, momentum_buf, (long)n, lr, momentum, weight_decay, grad_scale, first_step, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // ---- single operators ----------------------------------------------------------------------------
 namespace {
 struct TmpLayer {

@@ -99,4 +99,6 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
                  const float* target, const GridInfo& g, int B, float* partial, float* losses,
                  float* g_conf, float* g_cls, float* g_t, hipStream_t s);
 
+void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s);
+
 }  // namespace ynk
