@@ -41,10 +41,15 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.001)
     ap.add_argument("--nms", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent inference streams per GPU (one handle + one HIP stream each); steps are dealt round-robin, "
+                         "so one stream's NMS overlaps the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer HIP-event timings (stderr)")
+    ap.add_argument("--latency", type=int, default=0, metavar="N",
+                    help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
 
 
@@ -95,28 +100,59 @@ def main():
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
     sd = weights.make_state_dict(args.backbone, args.classes)
     B, S = args.batch, args.size
-    stream = torch.cuda.Stream(device=dev)
+    ns = max(1, args.streams if args.latency == 0 else 1)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    handles, xs, outs, counts = [], [], [], []
+    for k, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            hk = capi.Handle(S, args.classes, anchors, args.backbone, args.conf, args.nms, max_batch=B, device=dev, stream=st)
+            hk.load_state_dict(sd)
+            hk.fold_bn()
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1234 + rank * 16 + k)
+            xs.append(torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32))   # synthetic, resident in HBM
+            outs.append(hk.alloc_outputs(B))
+            counts.append(torch.empty((B,), dtype=torch.int32).pin_memory())
+            hk.use_graph(not args.no_graph)
+            handles.append(hk)
+    stream, h, x, out, counts_host = streams[0], handles[0], xs[0], outs[0], counts[0]
+    step_no = [0]
     with torch.cuda.stream(stream):
-        h = capi.Handle(S, args.classes, anchors, args.backbone, args.conf, args.nms, max_batch=B, device=dev, stream=stream)
-        h.load_state_dict(sd)
-        h.fold_bn()
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
-        x = torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32)   # synthetic, resident in HBM
-        out = h.alloc_outputs(B)
-        counts_host = torch.empty((B,), dtype=torch.int32).pin_memory()
-        h.use_graph(not args.no_graph)
-
         def step():
-            h.infer(x, out)
-            counts_host.copy_(out[4], non_blocking=True)
+            k = step_no[0] % ns
+            step_no[0] += 1
+            with torch.cuda.stream(streams[k]):
+                handles[k].infer(xs[k], outs[k])
+                counts[k].copy_(outs[k][4], non_blocking=True)
 
         def sync_all():
-            stream.synchronize()
+            for st in streams:
+                st.synchronize()
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
+        if args.latency > 0:
+            # per-call latency: launch (graph replay), wait for the device, repeat — the protocol of benchmark.py:62-75
+            for _ in range(max(args.warmup, 50)):
+                step()
+            stream.synchronize()
+            lat = []
+            for _ in range(args.latency):
+                t1 = time.perf_counter()
+                step()
+                stream.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            lat.sort()
+            if rank == 0:
+                print(json.dumps({"metric": "p50 latency YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
+                                  "value": round(lat[len(lat) // 2], 4), "unit": "ms", "p99_ms": round(lat[int(len(lat) * 0.99)], 4),
+                                  "min_ms": round(lat[0], 4), "n_gpus": world, "steps": args.latency, "warmup": max(args.warmup, 50),
+                                  "higher_is_better": False, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                                  "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, hipGraph replay, conf %.3g nms %.2f"
+                                                         % (args.backbone, S, S, B, args.conf, args.nms), "hipgraph": not args.no_graph}}), flush=True)
+            h.close()
+            return
         for _ in range(args.warmup):
             step()
         sync_all()
@@ -133,10 +169,11 @@ def main():
         if rank == 0:
             hb = torch.empty((B, h.N, 4), dtype=torch.float32).pin_memory()
             n_pc = max(5, args.steps // 10)
-            stream.synchronize()
+            sync_all()
             t1 = time.perf_counter()
-            for _ in range(n_pc):
-                step()
+            for _ in range(n_pc):                      # single stream, every kept row copied to pinned host memory
+                h.infer(x, out)
+                counts_host.copy_(out[4], non_blocking=True)
                 stream.synchronize()
                 for b, k in enumerate(counts_host.tolist()):
                     hb[b, :k].copy_(out[0][b, :k], non_blocking=True)
@@ -195,7 +232,8 @@ def main():
             pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
                         "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
 
-        h.use_graph(False)
+        for hk in handles:
+            hk.use_graph(False)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         if rank == 0:
@@ -208,6 +246,7 @@ def main():
                                        % (args.backbone, S, S, B, args.classes),
                            "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
                            "parallelism": "image-sharded x%d, no collective" % world, "hipgraph": not args.no_graph,
+                           "streams_per_gpu": ns,
                            "detections_per_step_rank0": kept},
                 "roofline": roof,
                 "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
@@ -216,7 +255,8 @@ def main():
                 "kernels": kernels,
             }
             print(json.dumps(line), flush=True)
-        h.close()
+        for hk in handles:
+            hk.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
