@@ -417,8 +417,58 @@ def gen_05x():
          head1=t2n(outs[0]), head2=t2n(outs[1]), head3=t2n(outs[2]))
 
 
+def gen_train():
+    """One full training step of the reference (train.py:212-231): train-mode forward (BatchNorm batch statistics),
+    the four losses, total.backward(), SGD(momentum 0.9, wd 5e-4) — two consecutive steps so that the momentum
+    buffer is exercised.  Recorded: inputs, labels, losses, a checksum of every gradient + a few full gradients,
+    sampled parameters after each step and the BN running statistics."""
+    S, C, B = 128, 20, 2
+    anchors = arch.MULTI_ANCHOR_SIZE
+    m = ref_model(S, C, anchors)
+    m.trainable = True                      # SURVEY §8c recipe: construct with trainable=False, then flip (train.py:140-144)
+    m.init_bias()
+    m.train()
+    rs = np.random.RandomState(77)
+    labels = []
+    for b in range(B):
+        n = 4 + b
+        cxy = rs.uniform(0.25, 0.75, (n, 2)); wh = rs.uniform(0.08, 0.45, (n, 2))
+        box = np.clip(np.concatenate([cxy - wh / 2, cxy + wh / 2], 1), 0, 1)
+        labels.append(np.concatenate([box, rs.randint(0, C, (n, 1)).astype(np.float64)], 1).tolist())
+    tgt = ref_tools.multi_gt_creator(S, list(arch.STRIDES), labels, anchors)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    names = [n for n, _ in m.named_parameters()]
+    full = ["backbone.conv1.0.weight", "backbone.stage2.0.branch1.0.weight", "backbone.stage3.2.branch2.5.weight", "backbone.stage4.1.branch2.4.bias",
+            "conv1x1_1.convs.0.weight", "smooth_1.convs.0.weight", "smooth_2.convs.1.weight", "head_det_1.2.convs.0.weight", "head_det_2.4.weight", "head_det_3.4.bias"]
+    a = {"S": np.int64(S), "C": np.int64(C), "B": np.int64(B), "target": t2n(tgt), "lr": np.float64(1e-3),
+         "init_bias_value": np.float64(-np.log((1 - 0.01) / 0.01)), "param_names": np.array(names)}
+    rsi = np.random.RandomState(5)
+    for step in range(2):
+        x = torch.from_numpy(weights.make_input(B, S, seed=10 + step))
+        losses = m(x, target=tgt)
+        total = sum(losses)
+        opt.zero_grad()
+        total.backward()
+        a["losses_%d" % step] = np.array([float(l.detach()) for l in losses], dtype=np.float64)
+        gsum = []
+        for n, p in m.named_parameters():
+            g = t2n(p.grad).astype(np.float64)
+            gsum.append([np.abs(g).sum(), g.sum(), np.sqrt((g * g).sum())])
+            if n in full:
+                a["grad_%d:%s" % (step, n)] = t2n(p.grad)
+        a["grad_sums_%d" % step] = np.array(gsum)
+        opt.step()
+        sd = m.state_dict()
+        for n in full:
+            a["param_%d:%s" % (step, n)] = t2n(sd[n])
+        for k in ("backbone.conv1.1", "backbone.stage3.0.branch2.4", "smooth_0.convs.1", "head_det_3.1.convs.1"):
+            a["rm_%d:%s" % (step, k)] = t2n(sd[k + ".running_mean"])
+            a["rv_%d:%s" % (step, k)] = t2n(sd[k + ".running_var"])
+    save("train.npz", **a)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x"]
+    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x", "train"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

@@ -202,3 +202,32 @@ def test_loss_oracle_matches_reference_autograd(golden):
     np.testing.assert_allclose(gc, g["g_conf"][..., 0], atol=1e-6, rtol=1e-4)
     np.testing.assert_allclose(gcl, g["g_cls"], atol=1e-6, rtol=1e-4)
     np.testing.assert_allclose(gt, g["g_txtytwth"], atol=1e-6, rtol=1e-4)
+
+
+def test_train_oracle_matches_reference_two_steps(golden):
+    """two reference training steps (train-mode BN, losses, backward, SGD) vs oracle/torch_port.TrainNet."""
+    import torch
+    from oracle.torch_port import TrainNet
+    g = golden("train.npz")
+    S, C, B = int(g["S"]), int(g["C"]), int(g["B"])
+    sd = weights.make_state_dict("1.0x", C)
+    net = TrainNet(sd, "1.0x", C, anchors=arch.MULTI_ANCHOR_SIZE)
+    with torch.no_grad():                                   # YOLONano.init_bias (models/yolo_nano.py:77-83)
+        for h in (1, 2, 3):
+            net.p["head_det_%d.4.bias" % h][:3] = float(g["init_bias_value"])
+    names = [str(n) for n in g["param_names"]]
+    for step in range(2):
+        losses, grads = net.train_step(weights.make_input(B, S, seed=10 + step), g["target"], S, lr=float(g["lr"]))
+        np.testing.assert_allclose(losses, g["losses_%d" % step], rtol=2e-4)
+        sums = np.array([[grads[n].abs().double().sum().item(), grads[n].double().sum().item(), (grads[n].double() ** 2).sum().sqrt().item()] for n in names])
+        np.testing.assert_allclose(sums[:, 2], g["grad_sums_%d" % step][:, 2], rtol=5e-3, atol=1e-4)   # conv biases in front of a BN have a mathematically zero gradient: pure round-off
+        for k in g:
+            if k.startswith("grad_%d:" % step):
+                ref = g[k]
+                np.testing.assert_allclose(grads[k.split(":", 1)[1]].numpy(), ref, rtol=5e-3, atol=2e-4 * np.abs(ref).max())
+            if k.startswith("param_%d:" % step):
+                np.testing.assert_allclose(net.p[k.split(":", 1)[1]].detach().numpy(), g[k], rtol=1e-4, atol=1e-6)
+            if k.startswith("rm_%d:" % step):
+                np.testing.assert_allclose(net.p[k.split(":", 1)[1] + ".running_mean"].numpy(), g[k], rtol=1e-4, atol=1e-6)
+            if k.startswith("rv_%d:" % step):
+                np.testing.assert_allclose(net.p[k.split(":", 1)[1] + ".running_var"].numpy(), g[k], rtol=1e-4, atol=1e-6)
