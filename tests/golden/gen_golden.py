@@ -455,15 +455,15 @@ def gen_train():
             g = t2n(p.grad).astype(np.float64)
             gsum.append([np.abs(g).sum(), g.sum(), np.sqrt((g * g).sum())])
             if n in full:
-                a["grad_%d:%s" % (step, n)] = t2n(p.grad)
+                a["grad_%d:%s" % (step, n)] = t2n(p.grad).copy()
         a["grad_sums_%d" % step] = np.array(gsum)
         opt.step()
         sd = m.state_dict()
         for n in full:
-            a["param_%d:%s" % (step, n)] = t2n(sd[n])
+            a["param_%d:%s" % (step, n)] = t2n(sd[n]).copy()       # copy: the parameter is updated in place by the next step
         for k in ("backbone.conv1.1", "backbone.stage3.0.branch2.4", "smooth_0.convs.1", "head_det_3.1.convs.1"):
-            a["rm_%d:%s" % (step, k)] = t2n(sd[k + ".running_mean"])
-            a["rv_%d:%s" % (step, k)] = t2n(sd[k + ".running_var"])
+            a["rm_%d:%s" % (step, k)] = t2n(sd[k + ".running_mean"]).copy()
+            a["rv_%d:%s" % (step, k)] = t2n(sd[k + ".running_var"]).copy()
     save("train.npz", **a)
 
 
