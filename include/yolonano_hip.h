@@ -139,6 +139,23 @@ int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16
 int  yn_sgd_step(yn_handle* h, float* params_dev, const float* grads_dev, float* momentum_buf_dev, int64_t n,
                  float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 
+/* ---- training step (train.py:212-231) ---------------------------------------------------------------- */
+/* Parameters, gradients and SGD momentum live in three caller-owned FLAT float32 device buffers of
+ * yn_train_param_count() elements, in nn.Module.named_parameters() order of the reference model (per layer:
+ * conv.weight, [conv.bias], [bn.weight, bn.bias]); yn_train_param_offset maps a state-dict key to its slice.
+ * yn_train_bind copies the loaded state dict into `params`, zeroes `grads` / `momentum`.  BatchNorm running statistics
+ * stay inside the handle (updated in place, momentum 0.1; read back with yn_read_param). */
+int64_t yn_train_param_count(yn_handle* h);
+int  yn_train_param_offset(yn_handle* h, const char* state_dict_key, int64_t* offset, int64_t* numel);
+int  yn_train_bind(yn_handle* h, float* params_dev, float* grads_dev, float* momentum_dev, int64_t n);
+/* One step: train-mode forward (BatchNorm batch statistics) of x [B,3,S,S], the four losses of tools.loss against
+ * target [B,N,11] into losses_dev[4], backward into `grads` (overwritten).  do_update != 0 also applies
+ * SGD(lr, momentum, weight_decay) with grads*grad_scale; data-parallel callers pass do_update = 0, all-reduce `grads`
+ * (RCCL, one flat bucket) and then call yn_sgd_step(grad_scale = 1/world).  Call yn_fold_bn before the next inference. */
+int  yn_train_step(yn_handle* h, const float* x_dev, const float* target_dev, int B, float lr, float momentum,
+                   float weight_decay, float grad_scale, int do_update, float* losses_dev);
+int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_t numel);
+
 /* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
 /* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],
  * dense [Cout,Cin,3,3]; bias [Cout] or NULL. */

@@ -99,16 +99,19 @@ class TrainNet:
     running-stat update), the loss of tools.py:219-276 / models/yolo_nano.py:332-358, SGD(momentum, weight_decay) as
     train.py:167-171,222-231.  Pinned against tests/golden/train.npz (two reference training steps)."""
 
-    def __init__(self, state_dict, backbone="1.0x", num_classes=20, num_anchors=3, anchors=None):
-        self.C, self.A, self.backbone = num_classes, num_anchors, backbone
-        self.anchors = torch.tensor(anchors, dtype=torch.float32).view(3, num_anchors, 2)
+    def __init__(self, state_dict, backbone="1.0x", num_classes=20, num_anchors=3, anchors=None, dtype=torch.float32):
+        """dtype=torch.float64 gives the round-off-free gradient the fp32 paths (reference, this port, HIP) are judged against."""
+        self.C, self.A, self.backbone, self.dt = num_classes, num_anchors, backbone, dtype
+        self.anchors = torch.tensor(anchors, dtype=dtype).view(3, num_anchors, 2)
         self.specs = [s for s in arch.conv_specs(backbone, num_classes, num_anchors)]
         self.by = {s.name: s for s in self.specs}
         self.p = {}
         for k, v in state_dict.items():
             t = torch.as_tensor(np.asarray(v)).clone()
-            if t.dtype == torch.float32 and not k.endswith(("running_mean", "running_var")):
-                t.requires_grad_(True)
+            if t.dtype == torch.float32:
+                t = t.to(dtype)
+                if not k.endswith(("running_mean", "running_var")):
+                    t.requires_grad_(True)
             self.p[k] = t
         self.momentum_buf = {}
 
@@ -140,7 +143,7 @@ class TrainNet:
         return out.view(B, 2, C // 2, H, W).transpose(1, 2).contiguous().view(B, C, H, W)
 
     def forward_raw(self, x):
-        x = F.max_pool2d(self.conv("stem", torch.as_tensor(x).float()), 3, 2, 1)
+        x = F.max_pool2d(self.conv("stem", torch.as_tensor(x).to(self.dt)), 3, 2, 1)
         feats = []
         for si, rep in enumerate(arch.STAGE_REPEATS):
             for bi in range(rep):
@@ -170,25 +173,25 @@ class TrainNet:
             clss.append(p[:, :, A:A + A * C].reshape(B, -1, C))
             ts.append(p[:, :, A * (1 + C):].reshape(B, -1, 4))
             gy, gx = torch.meshgrid(torch.arange(Hs), torch.arange(Hs), indexing="ij")
-            g = torch.stack([gx, gy], -1).float().view(-1, 1, 2).repeat(1, A, 1).view(-1, 2)
-            grids.append(g); strides.append(torch.full((Hs * Hs * A, 1), float(st))); ancs.append(self.anchors[si].repeat(Hs * Hs, 1))
+            g = torch.stack([gx, gy], -1).to(self.dt).view(-1, 1, 2).repeat(1, A, 1).view(-1, 2)
+            grids.append(g); strides.append(torch.full((Hs * Hs * A, 1), float(st), dtype=self.dt)); ancs.append(self.anchors[si].repeat(Hs * Hs, 1))
         conf, cls, t = torch.cat(confs, 1), torch.cat(clss, 1), torch.cat(ts, 1)
         grid, stride, anc = torch.cat(grids, 0), torch.cat(strides, 0), torch.cat(ancs, 0)
         cxy = (torch.sigmoid(t[..., :2]) + grid) * stride
         wh = torch.exp(t[..., 2:]) * anc
         box = torch.cat([cxy - wh / 2, cxy + wh / 2], -1) / S
-        target = torch.as_tensor(target).float()
+        target = torch.as_tensor(target).to(self.dt)
         gt = target[..., 7:]
         tl, br = torch.max(box[..., :2], gt[..., :2]), torch.min(box[..., 2:], gt[..., 2:])
         area_a, area_b = torch.prod(box[..., 2:] - box[..., :2], -1), torch.prod(gt[..., 2:] - gt[..., :2], -1)
-        en = (tl < br).float().prod(-1)
+        en = (tl < br).to(self.dt).prod(-1)
         area_i = torch.prod(br - tl, -1) * en
         iou = area_i / (area_a + area_b - area_i)
         obj, gcls, gt_t, wgt = target[..., 0], target[..., 1].long(), target[..., 2:6], target[..., 6]
-        mask = (obj > 0).float()
+        mask = (obj > 0).to(self.dt)
         sg = torch.sigmoid(conf)
         gt_conf = iou.detach()
-        conf_loss = torch.sum(5.0 * (obj == 1).float() * (sg - gt_conf) ** 2 + (obj == 0).float() * sg ** 2) / B
+        conf_loss = torch.sum(5.0 * (obj == 1).to(self.dt) * (sg - gt_conf) ** 2 + (obj == 0).to(self.dt) * sg ** 2) / B
         cls_loss = torch.sum(F.cross_entropy(cls.permute(0, 2, 1), gcls, reduction="none") * mask) / B
         txty = torch.sum(torch.sum(F.binary_cross_entropy_with_logits(t[..., :2], gt_t[..., :2], reduction="none"), -1) * wgt * mask) / B
         twth = torch.sum(torch.sum(F.mse_loss(t[..., 2:], gt_t[..., 2:], reduction="none"), -1) * wgt * mask) / B

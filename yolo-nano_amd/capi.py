@@ -54,6 +54,11 @@ SIGNATURES = {
     "yn_infer": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_loss_heads": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yn_train_param_count": (ctypes.c_int64, [_vp]),
+    "yn_train_param_offset": (_i32, [_vp, ctypes.c_char_p, _i64p, _i64p]),
+    "yn_train_bind": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64]),
+    "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -306,6 +311,36 @@ class Handle:
         assert params.is_contiguous() and grads.is_contiguous() and momentum_buf.is_contiguous() and params.numel() == grads.numel() == momentum_buf.numel()
         self._ck(self.lib.yn_sgd_step(self.h, params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), params.numel(),
                                       float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step))), "yn_sgd_step")
+
+    # ---- training step
+    def train_bind(self):
+        """Allocate the flat parameter / gradient / momentum buffers and bind them (parameters = the loaded state dict)."""
+        n = int(self.lib.yn_train_param_count(self.h))
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.flat_momentum = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.yn_train_bind(self.h, self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.flat_momentum.data_ptr(), n), "yn_train_bind")
+        return n
+
+    def param_slice(self, key):
+        off, num = ctypes.c_int64(), ctypes.c_int64()
+        self._ck(self.lib.yn_train_param_offset(self.h, key.encode(), ctypes.byref(off), ctypes.byref(num)), "yn_train_param_offset")
+        return slice(off.value, off.value + num.value)
+
+    def train_step(self, x, target, lr=1e-3, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, update=True):
+        """-> losses [4] (conf, cls, bbox, iou) device tensor; gradients are left in self.flat_grads."""
+        B = x.shape[0]
+        x, target = x.contiguous().float(), target.contiguous().float()
+        losses = torch.empty((4,), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_train_step(self.h, x.data_ptr(), target.data_ptr(), B, float(lr), float(momentum), float(weight_decay),
+                                        float(grad_scale), int(bool(update)), losses.data_ptr()), "yn_train_step")
+        return losses
+
+    def read_param(self, key, shape):
+        import numpy as np
+        a = np.empty(shape, dtype=np.float32)
+        self._ck(self.lib.yn_read_param(self.h, key.encode(), a.ctypes.data, a.size), "yn_read_param(%s)" % key)
+        return a
 
     # ---- measurement
     def profile_enable(self, on=True):

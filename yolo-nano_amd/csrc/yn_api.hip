@@ -41,6 +41,8 @@ struct Layer {
     int Kp = 0, Npad = 0;
 };
 
+struct TrainPack { float* wp = nullptr; float* bias = nullptr; float* wp_bwd = nullptr; int Kb = 0, Npad_b = 0; };   // per-layer training weight packs
+
 struct ProfRec {
     std::string name, kernel;
     hipEvent_t e0, e1;
@@ -85,6 +87,15 @@ struct yn_handle {
     size_t heads_cap = 0;
     float* loss_partial = nullptr;
     size_t loss_partial_cap = 0;
+    // training (yn_train.inc): caller-owned flat buffers + per-layer packs + workspace
+    float *tP = nullptr, *tG = nullptr, *tM = nullptr;
+    int64_t tN = 0, tN_expected = 0;
+    long train_steps = 0;
+    std::map<std::string, size_t> toff;
+    std::vector<TrainPack> tpacks;
+    float* zeros = nullptr;
+    char* train_arena = nullptr;
+    size_t train_arena_bytes = 0;
     // graphs / profiling
     bool use_graph = false;
     bool autotune = true;
@@ -655,6 +666,9 @@ void yn_destroy(yn_handle* h)
     if (h->tune_e0) { (void)hipEventDestroy(h->tune_e0); (void)hipEventDestroy(h->tune_e1); }
     for (hipEvent_t e : h->fj_events) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
+    for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
+    if (h->zeros) (void)hipFree(h->zeros);
+    if (h->train_arena) (void)hipFree(h->train_arena);
     delete h;
 }
 
@@ -761,6 +775,11 @@ int yn_load_param_dev(yn_handle* h, const char* key, const void* dev_ptr, const 
 int yn_fold_bn(yn_handle* h)
 {
     if (!h) return 1;
+    if (h->tP)                                              // after training: the flat buffer holds the current parameters
+        for (const auto& kv : h->toff) {
+            const Param* p = find_param(h, kv.first);
+            if (p) HIPCHK(h, hipMemcpyAsync(p->dev, h->tP + kv.second, p->numel * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        }
     for (Layer& l : h->layers) {
         const Param* w = find_param(h, l.conv + ".weight");
         if (!w) return fail(h, "missing parameter '%s.weight'", l.conv.c_str());
@@ -1145,3 +1164,5 @@ int yn_profile_get(yn_handle* h, int i, char* name, int name_cap, char* kernel, 
 
 }  // extern "C"
 #pragma GCC visibility pop
+
+#include "yn_train.inc"

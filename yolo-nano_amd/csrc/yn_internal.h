@@ -99,6 +99,45 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
                  const float* target, const GridInfo& g, int B, float* partial, float* losses,
                  float* g_conf, float* g_cls, float* g_t, hipStream_t s);
 
+// ---- train-mode kernels (kernels_bwd.hip) --------------------------------------------------------------
+struct BnApplyArgs {
+    const float* y; const float* mean; const float* invstd; const float* var; const float* gamma; const float* beta;
+    float* out; int out_ld, out_off, out_cs;
+    const float* pass; int pass_ld, pass_off, pass_dst_off;
+    float* rmean; float* rvar; float momentum;
+    int M, C, act;
+};
+struct BnBwdArgs {
+    const float* dz; int dz_ld, dz_off, dz_cs;
+    const float* z; int z_ld, z_off, z_cs;
+    const float* y; const float* mean; const float* invstd; const float* gamma;
+    const float* m_dyh; const float* m_dyhx;
+    float* dy;
+    int M, C, act;
+};
+struct WgradArgs {
+    const float* dy; int dy_ld;
+    const float* x; int x_ld, x_off;
+    int H, W, Cin, dense;
+    float* dw;
+    int M, N, K;
+};
+int  col_partial_floats(int M, int C);
+void launch_col_stats(const float* y, int ld, int off, int M, int C, float eps, float* partial, float* mean, float* invstd, float* var, hipStream_t s);
+void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* partial, float* out, hipStream_t s);
+void launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
+void launch_bn_bwd(const BnBwdArgs& a, float* partial, float* dgamma, float* dbeta, float* scratch2C, hipStream_t s);
+void launch_wgrad(const WgradArgs& a, hipStream_t s);
+void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, hipStream_t s);
+void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
+void launch_stem_wgrad(const float* dy, const float* x, int B, int H, int W, int Cout, float* dw, hipStream_t s);
+void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, int32_t* idx, hipStream_t s);
+void launch_maxpool_bwd(const float* dy, const int32_t* idx, int B, int H, int W, int C, float* dx, hipStream_t s);
+void launch_resample(const float* a, const float* b, float* out, int B, int H, int W, int C, int mode, hipStream_t s);
+void launch_strided_copy(const float* src, int src_ld, int src_off, int src_cs, float* dst, int dst_ld, int dst_off, int dst_cs,
+                         long M, int n, int accumulate, hipStream_t s);
+void launch_pack_bwd(const float* w, int Cout, int Cin, int kind, int Npad, float* out, hipStream_t s);
+
 void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s);
 
 }  // namespace ynk
