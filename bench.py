@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer HIP-event timings (stderr)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the SGD training step instead (BASELINE configs[2] shape with --size 608): train-mode forward, "
+                         "loss, backward, flat-bucket gradient all-reduce over RCCL when N>1, fused SGD")
     ap.add_argument("--latency", type=int, default=0, metavar="N",
                     help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
@@ -86,6 +89,71 @@ def cpu_baseline(args, sd, anchors):
             "sample": "%d reps of a %d-image batch, %dx%d, torch-CPU network + C-oracle NMS, %.1f s" % (reps, n, args.size, args.size, dt)}
 
 
+def synthetic_targets(B, S, C, seed):
+    """[B, N, 11] training labels in tools.multi_gt_creator's layout (tools.py:150-215): 8 objects per image."""
+    import numpy as np
+    from yolo_nano_amd import arch
+    rs = np.random.RandomState(seed)
+    N = arch.num_predictions(S)
+    t = np.zeros((B, N, 11), np.float32)
+    for b in range(B):
+        idx = rs.choice(N, 8, replace=False)
+        t[b, idx, 0] = 1.0
+        t[b, idx, 1] = rs.randint(0, C, 8)
+        t[b, idx, 2:4] = rs.uniform(0, 1, (8, 2))
+        t[b, idx, 4:6] = rs.standard_normal((8, 2)) * 0.3
+        t[b, idx, 6] = rs.uniform(1.0, 2.0, 8)
+        c = rs.uniform(0.2, 0.8, (8, 2)); wh = rs.uniform(0.05, 0.4, (8, 2))
+        t[b, idx, 7:9], t[b, idx, 9:11] = c - wh / 2, c + wh / 2
+    return t
+
+
+def train_bench(args, rank, world, dev, dist):
+    """Secondary line (not BASELINE's headline metric): images/s of the full training step, data-parallel over ranks."""
+    from yolo_nano_amd import arch, capi, parallel, weights
+    B, S = args.batch, args.size
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
+    sd = weights.make_state_dict(args.backbone, args.classes)
+    h = capi.Handle(S, args.classes, anchors, args.backbone, max_batch=B, device=dev)
+    h.load_state_dict(sd)
+    n_param = h.train_bind()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    x = torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32)
+    target = torch.as_tensor(synthetic_targets(B, S, args.classes, 77 + rank)).to(dev)
+    lr = 1e-5                                                # small enough that random-init weights stay finite over the run
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    losses = None
+    for _ in range(args.warmup):
+        losses = parallel.dp_train_step(h, x, target, lr)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = parallel.dp_train_step(h, x, target, lr)
+    sync_all()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    lv = [float(v) for v in losses.tolist()]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d SGD training step" % (args.backbone, S, S, B),
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 training step: train-mode forward (BN batch statistics), "
+                                   "loss, backward, SGD(0.9, 5e-4); %d-class head (BASELINE configs[2] shape, fp32 not fp16)"
+                                   % (args.backbone, S, S, B, args.classes),
+                       "global_batch": world * B, "parameters": n_param,
+                       "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
+            "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}), flush=True)
+    h.close()
+
+
 def main():
     args = parse()
     from yolo_nano_amd import arch, capi, parallel, weights
@@ -96,6 +164,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     parallel.init("nccl", dev)                               # RCCL; used only for the barrier / max-over-ranks
     dist = torch.distributed if world > 1 else None
+    if args.train:
+        train_bench(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
     sd = weights.make_state_dict(args.backbone, args.classes)

@@ -168,3 +168,56 @@ def test_train_then_infer_uses_updated_parameters(golden):
     assert torch.isfinite(after).all()
     assert (after - before).abs().max().item() > 1e-3
     h.close()
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "fused"])
+def test_shim_runs_the_reference_training_loop(golden, optimizer):
+    """train.py:219-231 verbatim on the shim: model(images, target=targets) -> four losses -> total.backward() ->
+    optimizer.step() -> optimizer.zero_grad(); torch.optim.SGD and the fused yn_sgd_step optimiser give the reference's
+    recorded parameters; the BN statistics come back through state_dict()."""
+    import yolo_nano_amd
+    g = golden("train.npz")
+    S, C, B, lr = int(g["S"]), int(g["C"]), int(g["B"]), float(g["lr"])
+    model = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=True, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in weights.make_state_dict("1.0x", C).items()}, strict=False)
+    model.init_bias()
+    model = model.to("cuda").train()
+    if optimizer == "torch":
+        opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=5e-4)
+    else:
+        opt = yolo_nano_amd.SGD(model, lr=lr, momentum=0.9, weight_decay=5e-4)
+    images = torch.as_tensor(weights.make_input(B, S, seed=10)).cuda()
+    targets = torch.as_tensor(g["target"]).cuda()
+    conf_loss, cls_loss, bbox_loss, iou_loss = model(images, target=targets)
+    total_loss = conf_loss + cls_loss + bbox_loss + iou_loss
+    assert not torch.isnan(total_loss)
+    total_loss.backward()
+    np.testing.assert_allclose([conf_loss.item(), cls_loss.item(), bbox_loss.item(), iou_loss.item()], g["losses_0"], rtol=2e-4)
+    named = dict(model.named_parameters())
+    for k in g:
+        if k.startswith("grad_0:"):
+            ref = g[k]
+            got = named[k[7:]].grad.cpu().numpy()
+            assert np.linalg.norm((got - ref).ravel()) <= 5e-2 * np.linalg.norm(ref.ravel()) + 1e-3, k   # the reference's own fp32 error, see _oracle64
+    opt.step()
+    opt.zero_grad()
+    sd = model.state_dict()
+    for k in g:
+        name = k.split(":", 1)[-1]
+        if k.startswith("param_0:"):
+            ref_g = g[k.replace("param_0", "grad_0")]
+            bound = lr * 5e-2 * float(np.abs(ref_g).max()) + 1e-5
+            assert float(np.abs(sd[name].cpu().numpy() - g[k]).max()) <= bound, name
+        if k.startswith("rm_0:"):
+            np.testing.assert_allclose(sd[name + ".running_mean"].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)
+        if k.startswith("rv_0:"):
+            np.testing.assert_allclose(sd[name + ".running_var"].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)
+    # a second iteration on the updated parameters, then inference with the trained weights (eval.py path)
+    losses2 = model(images, target=targets)
+    sum(losses2).backward()
+    opt.step()
+    opt.zero_grad()
+    model.trainable = False
+    model.eval()
+    boxes, scores, cls = model(images)
+    assert boxes.shape[1] == 4 and len(scores) == len(cls) == len(boxes) and np.isfinite(boxes).all()

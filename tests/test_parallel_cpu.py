@@ -93,3 +93,71 @@ def test_flat_bucket_allreduce_two_ranks():
         assert scale == 0.5
         assert firsts == [3.0 * (i + 1) for i in range(len(firsts))]       # (1 + 2) * (i + 1): summed over both ranks
         assert n == 3 * 4 * 9 + 4 + 4 + 4 + 4 * 2 + 2
+
+
+class _StubHandle:
+    """Stands in for capi.Handle after train_bind() (no GPU here): same attributes / methods dp_train_step touches."""
+
+    def __init__(self, rank, n=1000):
+        import torch
+        self.rank = rank
+        self.flat_params = torch.linspace(-1, 1, n)
+        self.flat_grads = torch.zeros(n)
+        self.flat_momentum = torch.zeros(n)
+        self.calls = []
+
+    def train_step(self, x, target, lr, momentum, weight_decay, update=True):
+        import torch
+        self.calls.append(("train_step", update))
+        self.flat_grads.copy_(x.sum() * torch.arange(self.flat_grads.numel()).float())     # "gradient" of this rank's shard
+        if update:
+            self.sgd_step(self.flat_params, self.flat_grads, self.flat_momentum, lr, momentum, weight_decay)
+        return torch.tensor([float(self.rank)] * 4)
+
+    def sgd_step(self, p, g, m, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+        self.calls.append(("sgd_step", grad_scale))
+        d = g * grad_scale + weight_decay * p
+        m.mul_(momentum).add_(d)
+        p.sub_(lr * m)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from yolo_nano_amd import parallel
+    parallel.init("gloo")
+    global_batch = torch.arange(8.0).view(8, 1)
+    lo, hi = parallel.shard(8, rank, world)
+    h = _StubHandle(rank)
+    losses = parallel.dp_train_step(h, global_batch[lo:hi], None, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    q.put((rank, h.calls, h.flat_params.clone().numpy(), losses.tolist()))
+    parallel.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_dp_train_step_two_ranks_equals_single_process_on_the_mean_gradient():
+    """BASELINE config 3 / SURVEY §8e: per-rank step without update -> one all-reduce(sum) of the flat gradients ->
+    fused SGD with grad_scale = 1/world.  Both ranks must end with identical parameters, equal to one process applying
+    the mean of the per-shard gradients."""
+    import torch
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _StubHandle(0)
+    g0 = torch.arange(4.0).sum() * torch.arange(1000).float()
+    g1 = torch.arange(4.0, 8.0).sum() * torch.arange(1000).float()
+    single.flat_grads.copy_((g0 + g1) / 2)
+    single.sgd_step(single.flat_params, single.flat_grads, single.flat_momentum, 0.1, 0.9, 5e-4)
+    for rank, calls, params, losses in res:
+        assert calls == [("train_step", False), ("sgd_step", 0.5)]
+        np.testing.assert_allclose(params, single.flat_params.numpy(), rtol=1e-6, atol=1e-6)
+        assert losses == [float(rank)] * 4                     # losses stay local (the reference prints per-rank values)
+    np.testing.assert_array_equal(res[0][2], res[1][2])

@@ -173,19 +173,24 @@ class YOLONano(nn.Module):
         self._handle_keys = None
         self._sig = None
         self._graph = False
+        self._bound = None                   # the handle whose flat training buffers hold the parameters
+        self._stats_stale = False            # module BN buffers newer than the handle's
+        self._stats_dirty = False            # handle BN statistics newer than the module's
+        self.dp_average = True               # data-parallel: average gradients over ranks inside backward()
 
     def __deepcopy__(self, memo):
         """deepcopy (utils/misc.py:70 ModelEMA) must not clone the native handle; the copy builds its own."""
         import copy
-        saved = (self._handle, self._handle_keys, self._sig)
-        self._handle, self._handle_keys, self._sig = None, None, None
+        self.sync_running_stats()
+        saved = (self._handle, self._handle_keys, self._sig, self._bound)
+        self._handle, self._handle_keys, self._sig, self._bound = None, None, None, None
         try:
             new = self.__class__.__new__(self.__class__)
             memo[id(self)] = new
             for k, v in self.__dict__.items():
                 setattr(new, k, copy.deepcopy(v, memo))
         finally:
-            self._handle, self._handle_keys, self._sig = saved
+            self._handle, self._handle_keys, self._sig, self._bound = saved
         return new
 
     # ---- reference helpers ------------------------------------------------------------------------
@@ -312,10 +317,128 @@ class YOLONano(nn.Module):
         counts = out[4].cpu().tolist()
         return [self._to_host(out, b, counts[b]) for b in range(x.shape[0])]
 
+    # ---- training (models/yolo_nano.py:332-358, train.py:219-231) -----------------------------------------
+    def _train_handle(self, batch):
+        """The handle with this module's parameters living INSIDE its flat training buffers: every nn.Parameter becomes a
+        view of `flat_params` (named_parameters() order == the C ABI's flat order), so the HIP step, torch.optim.SGD,
+        `yolo_nano_amd.SGD`, load_state_dict and ModelEMA all see the same storage and nothing is copied per step."""
+        h = self._handle
+        if h is None or self._bound is not h:
+            h = self.handle(batch)                           # loads the current weights + BN statistics
+            n = h.train_bind()
+            off = 0
+            for name, p in self.named_parameters():
+                sl = h.param_slice(name)
+                if sl.start != off or sl.stop - sl.start != p.numel():
+                    raise YnError("parameter order mismatch at %s" % name)
+                off = sl.stop
+                p.data = h.flat_params[sl].view(p.shape)
+                p.grad = None
+            if off != n:
+                raise YnError("flat parameter buffer holds %d values, the module %d" % (n, off))
+            self._bound = h
+            self._stats_stale = False
+        if h.S != self.input_size:                           # multi-scale training: train.py:202-208
+            h.set_grid(self.input_size)
+        if self._stats_stale:                                # load_state_dict after binding: push the BN statistics down
+            for k, v in self.state_dict().items():
+                if k.endswith(("running_mean", "running_var")):
+                    h.load_param(k, v)
+            self._stats_stale = False
+        return h
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._sig = None
+        self._stats_stale = True
+        return out
+
+    def sync_running_stats(self):
+        """Bring the BatchNorm running statistics the HIP training step updates back into the module's buffers
+        (state_dict() / checkpoints / the eval-mode fold read them from there)."""
+        h = self._handle
+        if h is None or self._bound is not h or not self._stats_dirty:
+            return
+        for k, v in self.state_dict().items():
+            if k.endswith(("running_mean", "running_var")):
+                v.copy_(torch.as_tensor(h.read_param(k, tuple(v.shape))))
+        self._stats_dirty = False
+
+    def state_dict(self, *a, **kw):
+        if getattr(self, "_stats_dirty", False) and not getattr(self, "_in_sync", False):
+            self._in_sync = True
+            try:
+                self.sync_running_stats()
+            finally:
+                self._in_sync = False
+        return super().state_dict(*a, **kw)
+
     def forward(self, x, target=None):
         if self.trainable:
-            raise YnError("training step (models/yolo_nano.py:332-358) is not built yet in this round; "
-                          "set model.trainable = False for inference")
+            if target is None:
+                raise YnError("trainable forward needs target [B, N, 11] (tools.multi_gt_creator layout)")
+            return _TrainStep.apply(self, x, target, *list(self.parameters()))
         h = self.handle(x.shape[0])
         out = h.infer(x.float())
         return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
+
+
+class _TrainStep(torch.autograd.Function):
+    """`model(images, target=targets)` in train mode: yn_train_step(do_update=0) runs forward + loss + backward in one
+    call and leaves d(conf+cls+bbox+iou)/d(parameters) in the flat gradient buffer; autograd's backward() only hands
+    views of that buffer to the parameters (after the data-parallel all-reduce), so train.py:219-231 runs unchanged:
+        conf_loss, cls_loss, bbox_loss, iou_loss = model(images, target=targets)
+        (conf_loss + cls_loss + bbox_loss + iou_loss).backward(); optimizer.step(); optimizer.zero_grad()"""
+
+    @staticmethod
+    def forward(ctx, model, x, target, *params):
+        h = model._train_handle(x.shape[0])
+        losses = h.train_step(x, target, update=False)
+        model._stats_dirty = True
+        model._sig = None
+        ctx.model = model
+        return tuple(losses.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *g):
+        model = ctx.model
+        h = model._handle
+        gs = torch.stack([t if t is not None else torch.zeros_like(g[0]) for t in g]).tolist()
+        scale = float(gs[0])
+        if any(v != scale for v in gs):
+            raise YnError("the four losses must enter the total with equal weights (train.py:222): the HIP backward "
+                          "differentiates their sum")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(h.flat_grads, op=dist.ReduceOp.SUM)          # ONE flat bucket over RCCL / xGMI
+            if model.dp_average:
+                scale /= dist.get_world_size()
+        if scale != 1.0:
+            h.flat_grads.mul_(scale)
+        out = [None, None, None]
+        off = 0
+        for p in model.parameters():
+            out.append(h.flat_grads[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return tuple(out)
+
+
+class SGD:
+    """torch.optim.SGD(lr, momentum, weight_decay) as train.py:167-171 builds it, as ONE fused HIP kernel over the model's
+    flat parameter / gradient / momentum buffers (yn_sgd_step).  `param_groups[0]['lr']` is what train.py's set_lr writes."""
+
+    def __init__(self, model, lr=1e-3, momentum=0.9, weight_decay=5e-4):
+        self.model = model
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay, "params": list(model.parameters())}]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.param_groups[0]["params"]:
+            p.grad = None
+
+    def step(self):
+        m, g = self.model, self.param_groups[0]
+        h = m._handle
+        if h is None or m._bound is not h:
+            raise YnError("SGD.step() before the first training forward/backward")
+        h.sgd_step(h.flat_params, h.flat_grads, h.flat_momentum, g["lr"], g["momentum"], g["weight_decay"])
+        m._sig = None

@@ -94,3 +94,16 @@ class FlatBucket:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
+
+
+def dp_train_step(handle, x, target, lr, momentum=0.9, weight_decay=5e-4):
+    """One data-parallel training step on this rank's shard of the global batch (BASELINE config 3):
+    yn_train_step(do_update=0) -> ONE all-reduce(sum) of the flat gradient buffer -> yn_sgd_step(grad_scale=1/world).
+    `handle` is a capi.Handle after train_bind(); call on the stream the handle was created on.  -> losses [4] (local)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return handle.train_step(x, target, lr, momentum, weight_decay, update=True)
+    losses = handle.train_step(x, target, lr, momentum, weight_decay, update=False)
+    dist.all_reduce(handle.flat_grads, op=dist.ReduceOp.SUM)
+    handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0 / world)
+    return losses
