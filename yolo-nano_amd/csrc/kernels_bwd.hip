@@ -14,161 +14,242 @@ namespace ynk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // =================================================================================================
-// Column reductions over an [M, C] matrix (row stride ld, channel offset off), two-stage and deterministic:
-//   MODE 0: s0 = sum x                                  (BN mean, bias gradient)
-//   MODE 1: s0 = sum (x - mean)^2                       (BN variance, second pass)
-//   MODE 2: s0 = sum dyh, s1 = sum dyh * xhat           (BN backward; dyh = dz * act'(z), xhat = (y-mean)*invstd)
-// partial[g][2][C]; col_finalize turns them into what the consumer needs.
+// Column reductions over an [M, C] matrix and the BatchNorm kernels built on them.
+//
+// Thread layout of every kernel here: a lane owns a PAIR of adjacent channels (one float2 per row) and walks down the
+// rows, `lanesC` (a power of two >= C/2, at most 256) lanes side by side and 256/lanesC rows per block iteration, so a
+// wave reads whole consecutive NHWC rows.  Reductions accumulate in double, combine the row-lanes of a block through LDS
+// and add ONE double atomic per channel per block into a zeroed accumulator; the consumer kernels turn the sums into
+// mean / invstd / gradients themselves, so there is no finalize launch.
+//   stats   : acc[0][c] = sum y,   acc[1][c] = sum y*y                  (one pass; E[y^2]-E[y]^2 in double)
+//   bwd sums: acc[0][c] = sum dyh, acc[1][c] = sum dyh * xhat           (dyh = dz * act'(z), xhat = (y-mean)*invstd)
 // =================================================================================================
-struct ColArgs {
-    const float* x; int x_ld, x_off;            // MODE 0/1: the matrix; MODE 2: y (pre-BN conv output)
-    const float* dz; int dz_ld, dz_off, dz_cs;  // MODE 2: upstream gradient (may be a strided channel view)
-    const float* z; int z_ld, z_off, z_cs;      // MODE 2: BN+act output (for act')
+struct Lanes { int lanesC, rowsPer; };
+static Lanes lanes_for(int C)
+{
+    const int CP = (C + 1) / 2;
+    int l = 1;
+    while (l < CP && l < 256) l <<= 1;
+    return Lanes{l, 256 / l};
+}
+static int reduce_blocks(int M, int rowsPer)
+{
+    long b = ((long)M + (long)rowsPer * 8 - 1) / ((long)rowsPer * 8);      // >= 8 rows per row-lane
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct RedArgs {
+    const float* y; int y_ld, y_off;                  // stats / col-sum: the matrix; bwd sums: the pre-BN conv output (dense, ld = C)
+    const float* dz; int dz_ld, dz_off, dz_cs;        // bwd sums: upstream gradient (may be a strided channel view)
+    const float* z; int z_ld, z_off, z_cs;            // bwd sums: BN+act output (for act')
     const float* mean; const float* invstd;
-    float* partial; int M, C, act;
+    double* acc; float* facc;
+    int M, C, act, lanesC;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a)
+__device__ __forceinline__ float2 load2(const float* base, size_t row_off, int c0, int cs, bool vec, bool has1)
 {
-    const int G = gridDim.x;
-    const int rows = (a.M + G - 1) / G;
-    const int r0 = blockIdx.x * rows, r1 = min(a.M, r0 + rows);
-    for (int c = threadIdx.x; c < a.C; c += 256) {
-        float s0 = 0.0f, s1 = 0.0f;
-        float mu = 0.0f, is = 0.0f;
-        if (MODE >= 1) mu = a.mean[c];
-        if (MODE == 2) is = a.invstd[c];
-        for (int r = r0; r < r1; ++r) {
-            if (MODE == 0) s0 += a.x[(size_t)r * a.x_ld + a.x_off + c];
-            else if (MODE == 1) { const float d = a.x[(size_t)r * a.x_ld + a.x_off + c] - mu; s0 += d * d; }
-            else {
-                float g = a.dz[(size_t)r * a.dz_ld + a.dz_off + c * a.dz_cs];
-                if (a.act) {
-                    const float zz = a.z[(size_t)r * a.z_ld + a.z_off + c * a.z_cs];
-                    g = zz > 0.0f ? g : (a.act == 2 ? 0.1f * g : 0.0f);
+    if (vec) return *reinterpret_cast<const float2*>(base + row_off + c0);
+    float2 v;
+    v.x = base[row_off + (size_t)c0 * cs];
+    v.y = has1 ? base[row_off + (size_t)(c0 + 1) * cs] : 0.0f;
+    return v;
+}
+__device__ __forceinline__ float act_grad(float g, float zz, int act) { return zz > 0.0f ? g : (act == 2 ? 0.1f * g : 0.0f); }
+
+// MODE 0: stats (sum, sum of squares) -> double atomics ; MODE 2: BN backward sums -> double atomics ; MODE 3: plain column sum -> float atomics
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(RedArgs a)
+{
+    __shared__ double red[256][4];
+    const int lanesC = a.lanesC, rowsPer = 256 / lanesC;
+    const int cl = threadIdx.x & (lanesC - 1), rl = threadIdx.x / lanesC;
+    const int CP = (a.C + 1) >> 1;
+    const bool yvec = !(a.y_ld & 1) && !(a.y_off & 1);
+    const bool dvec = MODE == 2 && a.dz_cs == 1 && !(a.dz_ld & 1) && !(a.dz_off & 1);
+    const bool zvec = MODE == 2 && a.z_cs == 1 && !(a.z_ld & 1) && !(a.z_off & 1);
+    for (int cp = cl; cp < ((CP + lanesC - 1) / lanesC) * lanesC; cp += lanesC) {
+        const int c0 = cp * 2;
+        const bool live = cp < CP, has1 = c0 + 1 < a.C;
+        double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
+        if (live) {
+            float mu0 = 0.0f, mu1 = 0.0f, is0 = 0.0f, is1 = 0.0f;
+            if (MODE == 2) { mu0 = a.mean[c0]; is0 = a.invstd[c0]; if (has1) { mu1 = a.mean[c0 + 1]; is1 = a.invstd[c0 + 1]; } }
+            for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += (long)gridDim.x * rowsPer) {
+                const float2 v = load2(a.y, (size_t)r * a.y_ld + a.y_off, c0, 1, yvec && has1, has1);
+                if (MODE == 0) {
+                    s0a += (double)v.x; s0b += (double)v.y;
+                    s1a += (double)v.x * (double)v.x; s1b += (double)v.y * (double)v.y;
+                } else if (MODE == 3) {
+                    s0a += (double)v.x; s0b += (double)v.y;
+                } else {
+                    float2 g = load2(a.dz, (size_t)r * a.dz_ld + a.dz_off, c0, a.dz_cs, dvec && has1, has1);
+                    if (a.act) {
+                        const float2 zz = load2(a.z, (size_t)r * a.z_ld + a.z_off, c0, a.z_cs, zvec && has1, has1);
+                        g.x = act_grad(g.x, zz.x, a.act); g.y = act_grad(g.y, zz.y, a.act);
+                    }
+                    const float xh0 = (v.x - mu0) * is0, xh1 = (v.y - mu1) * is1;
+                    s0a += (double)g.x; s0b += (double)g.y;
+                    s1a += (double)g.x * (double)xh0; s1b += (double)g.y * (double)xh1;
                 }
-                const float xh = (a.x[(size_t)r * a.x_ld + a.x_off + c] - mu) * is;
-                s0 += g; s1 += g * xh;
             }
         }
-        a.partial[((size_t)blockIdx.x * 2 + 0) * a.C + c] = s0;
-        a.partial[((size_t)blockIdx.x * 2 + 1) * a.C + c] = s1;
+        __syncthreads();
+        red[threadIdx.x][0] = s0a; red[threadIdx.x][1] = s0b; red[threadIdx.x][2] = s1a; red[threadIdx.x][3] = s1b;
+        __syncthreads();
+        if (rl == 0 && live) {
+            for (int k = 1; k < rowsPer; ++k) {
+                const double* q = red[k * lanesC + cl];
+                s0a += q[0]; s0b += q[1]; s1a += q[2]; s1b += q[3];
+            }
+            if (MODE == 3) {
+                atomicAdd(a.facc + c0, (float)s0a);
+                if (has1) atomicAdd(a.facc + c0 + 1, (float)s0b);
+            } else {
+                atomicAdd(a.acc + c0, s0a); atomicAdd(a.acc + a.C + c0, s1a);
+                if (has1) { atomicAdd(a.acc + c0 + 1, s0b); atomicAdd(a.acc + a.C + c0 + 1, s1b); }
+            }
+        }
     }
 }
 
-// what: 0 -> out0 = s0 / M (mean) ; 1 -> out0 = 1/sqrt(s0/M + eps) (invstd), out1 = s0/M (biased var);
-//       2 -> out0 += s0 (dbeta), out1 += s1 (dgamma), and out2/out3 = s0/M, s1/M for the dx pass ; 3 -> out0 += s0 (bias grad)
-__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial, int G, int C, int M, float eps, int what,
-                                                            float* out0, float* out1, float* out2, float* out3)
+void launch_bn_stats(const float* y, int M, int C, double* acc, hipStream_t s)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int g = 0; g < G; ++g) { s0 += (double)partial[((size_t)g * 2 + 0) * C + c]; s1 += (double)partial[((size_t)g * 2 + 1) * C + c]; }
-    if (what == 0) out0[c] = (float)(s0 / M);
-    else if (what == 1) { const double var = s0 / M; out0[c] = (float)(1.0 / sqrt(var + (double)eps)); out1[c] = (float)var; }
-    else if (what == 2) { out0[c] += (float)s0; out1[c] += (float)s1; out2[c] = (float)(s0 / M); out3[c] = (float)(s1 / M); }
-    else out0[c] += (float)s0;
+    RedArgs a{};
+    const Lanes L = lanes_for(C);
+    a.y = y; a.y_ld = C; a.y_off = 0; a.acc = acc; a.M = M; a.C = C; a.lanesC = L.lanesC;
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(reduce_blocks(M, L.rowsPer)), dim3(256), 0, s, a);
 }
 
-static int col_groups(int M) { int g = (M + 255) / 256; if (g > 512) g = 512; if (g < 1) g = 1; return g; }
-
-int col_partial_floats(int M, int C) { return col_groups(M) * 2 * C; }
-
-void launch_col_stats(const float* y, int ld, int off, int M, int C, float eps, float* partial, float* mean, float* invstd, float* var, hipStream_t s)
+// out[c] += sum_m x[m*ld + off + c]   (float atomics; `out` is a zero-initialised gradient slice)
+void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* out, hipStream_t s)
 {
-    ColArgs a{};
-    a.x = y; a.x_ld = ld; a.x_off = off; a.partial = partial; a.M = M; a.C = C; a.mean = mean;
-    const int G = col_groups(M);
-    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(G), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, G, C, M, eps, 0, mean, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(G), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, G, C, M, eps, 1, invstd, var, (float*)nullptr, (float*)nullptr);
+    RedArgs a{};
+    const Lanes L = lanes_for(C);
+    a.y = x; a.y_ld = ld; a.y_off = off; a.facc = out; a.M = M; a.C = C; a.lanesC = L.lanesC;
+    hipLaunchKernelGGL(col_reduce_kernel<3>, dim3(reduce_blocks(M, L.rowsPer)), dim3(256), 0, s, a);
 }
 
-void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* partial, float* out, hipStream_t s)
-{
-    ColArgs a{};
-    a.x = x; a.x_ld = ld; a.x_off = off; a.partial = partial; a.M = M; a.C = C;
-    const int G = col_groups(M);
-    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(G), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, G, C, M, 0.0f, 3, out, (float*)nullptr, (float*)nullptr, (float*)nullptr);
-}
-
-// ---- BatchNorm forward apply: z = act((y - mean) * invstd * gamma + beta); optional channel-interleaved output
-//      (out[m][off + c*cs]) and pass-through copy (out[m][pass_dst_off + c*cs] = pass[m][pass_off + c]) = concat+shuffle;
-//      also the running-statistics update (momentum 0.1, unbiased variance) by block 0.
-
+// ---- BatchNorm forward apply: z = act((y - mean) * invstd * gamma + beta) with mean / invstd derived from the stats
+//      accumulator; optional channel-interleaved output (out[m][off + c*cs]) and pass-through copy
+//      (out[m][pass_dst_off + c*cs] = pass[m][pass_off + c]) = concat + channel shuffle.  Block 0 also saves mean / invstd
+//      for the backward pass and updates the running statistics (momentum 0.1, unbiased variance).
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a)
 {
-    const long total = (long)a.M * a.C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % a.C);
-        const long m = i / a.C;
-        float v = (a.y[i] - a.mean[c]) * a.invstd[c] * a.gamma[c] + a.beta[c];
-        if (a.act == 1) v = v > 0.0f ? v : 0.0f;
-        else if (a.act == 2) v = v > 0.0f ? v : 0.1f * v;
-        a.out[(size_t)m * a.out_ld + a.out_off + c * a.out_cs] = v;
-        if (a.pass) a.out[(size_t)m * a.out_ld + a.pass_dst_off + c * a.out_cs] = a.pass[(size_t)m * a.pass_ld + a.pass_off + c];
-    }
-    if (blockIdx.x == 0 && a.rmean) {
-        for (int c = threadIdx.x; c < a.C; c += 256) {
-            const float unbiased = a.M > 1 ? a.var[c] * ((float)a.M / (float)(a.M - 1)) : a.var[c];
-            a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * a.mean[c];
-            a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+    const int lanesC = a.lanesC, rowsPer = 256 / lanesC;
+    const int cl = threadIdx.x & (lanesC - 1), rl = threadIdx.x / lanesC;
+    const int CP = (a.C + 1) >> 1;
+    const double invM = 1.0 / (double)a.M;
+    const bool ovec = a.out_cs == 1 && !(a.out_ld & 1) && !(a.out_off & 1);
+    const bool shuf = a.pass && a.out_cs == 2 && a.out_off == 1 && a.pass_dst_off == 0 && !(a.out_ld & 3) && !(a.pass_ld & 1) && !(a.pass_off & 1);
+    for (int cp = cl; cp < CP; cp += lanesC) {
+        const int c0 = cp * 2;
+        const bool has1 = c0 + 1 < a.C;
+        float mu[2], is[2], ga[2], be[2];
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + j < a.C ? c0 + j : c0;
+            const double m = a.acc[c] * invM;
+            double var = a.acc[a.C + c] * invM - m * m;
+            if (var < 0.0) var = 0.0;
+            mu[j] = (float)m; is[j] = (float)(1.0 / sqrt(var + (double)a.eps)); ga[j] = a.gamma[c]; be[j] = a.beta[c];
+            if (blockIdx.x == 0 && rl == 0 && (j == 0 || has1)) {
+                a.mean[c] = mu[j]; a.invstd[c] = is[j];
+                if (a.rmean) {
+                    const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
+                    a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu[j];
+                    a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+                }
+            }
+        }
+        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += (long)gridDim.x * rowsPer) {
+            float2 v = load2(a.y, (size_t)r * a.C, c0, 1, has1, has1);
+            v.x = (v.x - mu[0]) * is[0] * ga[0] + be[0];
+            v.y = (v.y - mu[1]) * is[1] * ga[1] + be[1];
+            if (a.act == 1) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; }
+            else if (a.act == 2) { v.x = v.x > 0.0f ? v.x : 0.1f * v.x; v.y = v.y > 0.0f ? v.y : 0.1f * v.y; }
+            float* o = a.out + (size_t)r * a.out_ld;
+            if (shuf && has1) {
+                const float2 p = *reinterpret_cast<const float2*>(a.pass + (size_t)r * a.pass_ld + a.pass_off + c0);
+                *reinterpret_cast<float4*>(o + 2 * c0) = make_float4(p.x, v.x, p.y, v.y);
+            } else {
+                if (ovec && has1) *reinterpret_cast<float2*>(o + a.out_off + c0) = v;
+                else { o[a.out_off + (size_t)c0 * a.out_cs] = v.x; if (has1) o[a.out_off + (size_t)(c0 + 1) * a.out_cs] = v.y; }
+                if (a.pass) {
+                    const float* p = a.pass + (size_t)r * a.pass_ld + a.pass_off;
+                    o[a.pass_dst_off + (size_t)c0 * a.out_cs] = p[c0];
+                    if (has1) o[a.pass_dst_off + (size_t)(c0 + 1) * a.out_cs] = p[c0 + 1];
+                }
+            }
         }
     }
 }
 
-void launch_bn_apply(const BnApplyArgs& a, hipStream_t s)
+static int stream_blocks(int M, int rowsPer)
 {
-    long blocks = ((long)a.M * a.C + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    long b = ((long)M + (long)rowsPer * 4 - 1) / ((long)rowsPer * 4);
+    if (b > 256 * 8) b = 256 * 8;
+    if (b < 1) b = 1;
+    return (int)b;
 }
 
-// ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)),  dyh = dz * act'(z).
-//      With gamma == nullptr it is the plain activation backward (layers without BN).
+void launch_bn_apply(const BnApplyArgs& a0, hipStream_t s)
+{
+    BnApplyArgs a = a0;
+    const Lanes L = lanes_for(a.C);
+    a.lanesC = L.lanesC;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(a.M, L.rowsPer)), dim3(256), 0, s, a);
+}
 
+// ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)),  dyh = dz * act'(z);
+//      block 0 writes dbeta = sum dyh and dgamma = sum dyh * xhat.
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a)
 {
-    const long total = (long)a.M * a.C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % a.C);
-        const long m = i / a.C;
-        float g = a.dz[(size_t)m * a.dz_ld + a.dz_off + c * a.dz_cs];
-        if (a.act) {
-            const float zz = a.z[(size_t)m * a.z_ld + a.z_off + c * a.z_cs];
-            g = zz > 0.0f ? g : (a.act == 2 ? 0.1f * g : 0.0f);
+    const int lanesC = a.lanesC, rowsPer = 256 / lanesC;
+    const int cl = threadIdx.x & (lanesC - 1), rl = threadIdx.x / lanesC;
+    const int CP = (a.C + 1) >> 1;
+    const double invM = 1.0 / (double)a.M;
+    const bool dvec = a.dz_cs == 1 && !(a.dz_ld & 1) && !(a.dz_off & 1);
+    const bool zvec = a.z_cs == 1 && !(a.z_ld & 1) && !(a.z_off & 1);
+    for (int cp = cl; cp < CP; cp += lanesC) {
+        const int c0 = cp * 2;
+        const bool has1 = c0 + 1 < a.C;
+        float mu[2], is[2], k[2], m0[2], m1[2];
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + j < a.C ? c0 + j : c0;
+            mu[j] = a.mean[c]; is[j] = a.invstd[c]; k[j] = a.gamma[c] * is[j];
+            m0[j] = (float)(a.acc[c] * invM); m1[j] = (float)(a.acc[a.C + c] * invM);
+            if (blockIdx.x == 0 && rl == 0 && (j == 0 || has1)) { a.dbeta[c] = (float)a.acc[c]; a.dgamma[c] = (float)a.acc[a.C + c]; }
         }
-        if (a.gamma) {
-            const float xh = (a.y[i] - a.mean[c]) * a.invstd[c];
-            g = a.gamma[c] * a.invstd[c] * (g - a.m_dyh[c] - xh * a.m_dyhx[c]);
+        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += (long)gridDim.x * rowsPer) {
+            float2 g = load2(a.dz, (size_t)r * a.dz_ld + a.dz_off, c0, a.dz_cs, dvec && has1, has1);
+            if (a.act) {
+                const float2 zz = load2(a.z, (size_t)r * a.z_ld + a.z_off, c0, a.z_cs, zvec && has1, has1);
+                g.x = act_grad(g.x, zz.x, a.act); g.y = act_grad(g.y, zz.y, a.act);
+            }
+            const float2 v = load2(a.y, (size_t)r * a.C, c0, 1, has1, has1);
+            const float xh0 = (v.x - mu[0]) * is[0], xh1 = (v.y - mu[1]) * is[1];
+            g.x = k[0] * (g.x - m0[0] - xh0 * m1[0]);
+            g.y = k[1] * (g.y - m0[1] - xh1 * m1[1]);
+            float* o = a.dy + (size_t)r * a.C + c0;
+            if (has1) *reinterpret_cast<float2*>(o) = g; else o[0] = g.x;
         }
-        a.dy[i] = g;
     }
 }
 
-void launch_bn_bwd(const BnBwdArgs& a, float* partial, float* dgamma, float* dbeta, float* scratch2C, hipStream_t s)
+void launch_bn_bwd(const BnBwdArgs& a0, hipStream_t s)
 {
-    BnBwdArgs b = a;
-    if (a.gamma) {
-        ColArgs c{};
-        c.x = a.y; c.x_ld = a.C; c.x_off = 0;
-        c.dz = a.dz; c.dz_ld = a.dz_ld; c.dz_off = a.dz_off; c.dz_cs = a.dz_cs;
-        c.z = a.z; c.z_ld = a.z_ld; c.z_off = a.z_off; c.z_cs = a.z_cs;
-        c.mean = a.mean; c.invstd = a.invstd; c.partial = partial; c.M = a.M; c.C = a.C; c.act = a.act;
-        const int G = col_groups(a.M);
-        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(G), dim3(256), 0, s, c);
-        hipLaunchKernelGGL(col_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, partial, G, a.C, a.M, 0.0f, 2, dbeta, dgamma, scratch2C, scratch2C + a.C);
-        b.m_dyh = scratch2C; b.m_dyhx = scratch2C + a.C;
-    }
-    long blocks = ((long)a.M * a.C + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
+    BnBwdArgs a = a0;
+    const Lanes L = lanes_for(a.C);
+    a.lanesC = L.lanesC;
+    RedArgs c{};
+    c.y = a.y; c.y_ld = a.C; c.y_off = 0;
+    c.dz = a.dz; c.dz_ld = a.dz_ld; c.dz_off = a.dz_off; c.dz_cs = a.dz_cs;
+    c.z = a.z; c.z_ld = a.z_ld; c.z_off = a.z_off; c.z_cs = a.z_cs;
+    c.mean = a.mean; c.invstd = a.invstd; c.acc = a.acc; c.M = a.M; c.C = a.C; c.act = a.act; c.lanesC = L.lanesC;
+    hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(reduce_blocks(a.M, L.rowsPer)), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(stream_blocks(a.M, L.rowsPer)), dim3(256), 0, s, a);
 }
 
 // =================================================================================================
@@ -250,46 +331,67 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s)
 }
 
 // ---- depthwise 3x3 weight gradient: dW[c][tap] += sum_p dY[p][c] * X[p*stride + tap - 1][c]  (torch layout [C][1][3][3])
+//      Same lane layout as the column reductions: a lane owns two channels (float2 loads), row-lanes walk the output
+//      pixels; 18 float accumulators per lane, LDS combine over the row-lanes, one float atomic per (c, tap) per block.
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_ld, int x_off,
-                                                        int B, int H, int W, int C, int stride, float* __restrict__ dw)
+                                                        int B, int H, int W, int C, int stride, float* __restrict__ dw, int lanesC)
 {
+    __shared__ float red[256][19];
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long Mo = (long)B * Ho * Wo;
-    const long rows = (Mo + gridDim.x - 1) / gridDim.x;
-    const long p0 = (long)blockIdx.x * rows, p1 = min(Mo, p0 + rows);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc[9];
+    const int rowsPer = 256 / lanesC;
+    const int cl = threadIdx.x & (lanesC - 1), rl = threadIdx.x / lanesC;
+    const int CP = (C + 1) >> 1;
+    const bool xvec = !(x_ld & 1) && !(x_off & 1), dvec = !(C & 1);
+    for (int cp = cl; cp < ((CP + lanesC - 1) / lanesC) * lanesC; cp += lanesC) {
+        const int c0 = cp * 2;
+        const bool live = cp < CP, has1 = c0 + 1 < C;
+        float acc[18];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
-        for (long p = p0; p < p1; ++p) {
-            const int ox = (int)(p % Wo);
-            const long q = p / Wo;
-            const int oy = (int)(q % Ho), b = (int)(q / Ho);
-            const float g = dy[(size_t)p * C + c];
+        for (int k = 0; k < 18; ++k) acc[k] = 0.0f;
+        if (live) {
+            for (long p = (long)blockIdx.x * rowsPer + rl; p < Mo; p += (long)gridDim.x * rowsPer) {
+                const int ox = (int)(p % Wo);
+                const long q = p / Wo;
+                const int oy = (int)(q % Ho), b = (int)(q / Ho);
+                const float2 g = load2(dy, (size_t)p * C, c0, 1, dvec && has1, has1);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy * stride - 1 + ky;
-                if (iy < 0 || iy >= H) continue;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = oy * stride - 1 + ky;
+                    if (iy < 0 || iy >= H) continue;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * stride - 1 + kx;
-                    if (ix < 0 || ix >= W) continue;
-                    acc[ky * 3 + kx] += g * x[((size_t)(b * H + iy) * W + ix) * x_ld + x_off + c];
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = ox * stride - 1 + kx;
+                        if (ix < 0 || ix >= W) continue;
+                        const float2 v = load2(x, ((size_t)(b * H + iy) * W + ix) * x_ld + x_off, c0, 1, xvec && has1, has1);
+                        acc[(ky * 3 + kx) * 2 + 0] += g.x * v.x;
+                        acc[(ky * 3 + kx) * 2 + 1] += g.y * v.y;
+                    }
                 }
             }
         }
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(dw + (size_t)c * 9 + k, acc[k]);
+        for (int k = 0; k < 18; ++k) red[threadIdx.x][k] = acc[k];
+        __syncthreads();
+        if (rl == 0 && live) {
+            for (int j = 1; j < rowsPer; ++j)
+#pragma unroll
+                for (int k = 0; k < 18; ++k) acc[k] += red[j * lanesC + cl][k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                atomicAdd(dw + (size_t)c0 * 9 + k, acc[2 * k]);
+                if (has1) atomicAdd(dw + (size_t)(c0 + 1) * 9 + k, acc[2 * k + 1]);
+            }
+        }
     }
 }
 
 void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, hipStream_t s)
 {
     const long Mo = (long)B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
-    int G = (int)((Mo + 127) / 128);
-    if (G > 1024) G = 1024;
-    if (G < 1) G = 1;
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(G), dim3(256), 0, s, dy, x, x_ld, x_off, B, H, W, C, stride, dw);
+    const Lanes L = lanes_for(C);
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(reduce_blocks((int)Mo, L.rowsPer)), dim3(256), 0, s, dy, x, x_ld, x_off, B, H, W, C, stride, dw, L.lanesC);
 }
 
 // ---- depthwise 3x3 stride-2 input gradient: dX[iy][ix][c] = sum_{ky,kx} dY[(iy+1-ky)/2][(ix+1-kx)/2][c] * w[ky][kx][c]
@@ -334,35 +436,60 @@ void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, in
 }
 
 // ---- stem weight gradient: dW[co][ci][ky][kx] += sum_p dY[p][co] * x_nchw[b][ci][2oy-1+ky][2ox-1+kx]
+//      As a GEMM: dW^T[r = ci*9+ky*3+kx (27 -> 32)][co (24 -> 32)] = Xpatch^T[32 x M] * dY[M x 32], one 32x32 f32 MFMA tile per
+//      wave fed straight from global memory (lane l supplies patch element r = l%32 and dY column co = l%32 of output pixel
+//      2*step + l/32).  A wave owns whole output rows; the four waves of a block are combined through LDS before the
+//      float atomics into dW.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int H, int W, int Cout,
                                                           float* __restrict__ dw)
 {
+    __shared__ float red[3][64][17];
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long Mo = (long)B * Ho * Wo;
-    const long rows = (Mo + gridDim.x - 1) / gridDim.x;
-    const long p0 = (long)blockIdx.x * rows, p1 = min(Mo, p0 + rows);
-    const int nout = Cout * 27;
-    for (int o = threadIdx.x; o < nout; o += 256) {
-        const int co = o / 27, r = o - co * 27;
-        const int ci = r / 9, ky = (r % 9) / 3, kx = r % 3;
-        float acc = 0.0f;
-        for (long p = p0; p < p1; ++p) {
-            const int ox = (int)(p % Wo);
-            const long q = p / Wo;
-            const int oy = (int)(q % Ho), b = (int)(q / Ho);
-            const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-            acc += dy[(size_t)p * Cout + co] * x[(((size_t)b * 3 + ci) * H + iy) * W + ix];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int r = l31, ci = r / 9, ky = (r % 9) / 3, kx = r % 3;
+    const bool rlive = r < 27, clive = l31 < Cout;
+    const int nrows = B * Ho;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int row = blockIdx.x * 4 + wave; row < nrows; row += gridDim.x * 4) {
+        const int b = row / Ho, oy = row - b * Ho;
+        const int iy = 2 * oy - 1 + ky;
+        const bool yok = rlive && iy >= 0 && iy < H;
+        const float* xrow = x + (((size_t)b * 3 + (rlive ? ci : 0)) * H + (yok ? iy : 0)) * W + (kx - 1);
+        const float* drow = dy + (size_t)row * Wo * Cout + l31;
+#pragma unroll 4
+        for (int ox0 = 0; ox0 < Wo; ox0 += 2) {
+            const int ox = ox0 + hh;
+            const int ix = 2 * ox + kx - 1;
+            float av = 0.0f, bv = 0.0f;
+            if (yok && ox < Wo && ix >= 0 && ix < W) av = xrow[2 * ox];
+            if (clive && ox < Wo) bv = drow[(size_t)ox * Cout];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
-        atomicAdd(dw + o, acc);
+    }
+    // acc[i]: row (patch element) = (i&3) + 8*(i>>2) + 4*hh, column (co) = l31
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave - 1][lane][i] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = acc[i] + red[0][lane][i] + red[1][lane][i] + red[2][lane][i];
+            const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (rr < 27 && clive) atomicAdd(dw + (size_t)l31 * 27 + rr, v);
+        }
     }
 }
 
 void launch_stem_wgrad(const float* dy, const float* x, int B, int H, int W, int Cout, float* dw, hipStream_t s)
 {
-    const long Mo = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
-    int G = (int)((Mo + 255) / 256);
-    if (G > 2048) G = 2048;
+    const int nrows = B * ((H - 1) / 2 + 1);
+    int G = (nrows + 3) / 4;
+    if (G > 512) G = 512;
+    if (G < 1) G = 1;
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(G), dim3(256), 0, s, dy, x, B, H, W, Cout, dw);
 }
 

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
         l_conf = (5.0f * pos * (sg - iou) * (sg - iou) + neg * sg * sg) * invB;
         if (qconf) qconf[0] = (5.0f * pos * 2.0f * (sg - iou) + neg * 2.0f * sg) * sg * (1.0f - sg) * invB;
         // class cross-entropy * mask
-        if (mask > 0.0f || qcls) {
+        // candidates that are not positives contribute nothing to the class term: their (pre-zeroed, see the callers)
+        // gradient slots are left untouched, so only the handful of positives walk the class vector
+        if (mask > 0.0f) {
             float mx = -INFINITY;
             for (int c = 0; c < g.C; ++c) mx = fmaxf(mx, pcls[c]);
             float sum = 0.0f;

@@ -962,6 +962,7 @@ int yn_loss(yn_handle* h, const float* conf, const float* cls, const float* txty
     if ((g_conf != nullptr) != (g_cls != nullptr) || (g_conf != nullptr) != (g_txtytwth != nullptr))
         return fail(h, "yn_loss: pass all three gradient buffers or none");
     if (ensure_loss(h, B)) return 1;
+    if (g_cls) HIPCHK(h, hipMemsetAsync(g_cls, 0, (size_t)B * h->grid.N * h->grid.C * sizeof(float), h->stream));   // the kernel only writes the positives' class gradients
     launch_loss(conf, cls, txtytwth, nullptr, nullptr, target, h->grid, B, h->loss_partial, losses, g_conf, g_cls, g_txtytwth, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -977,6 +978,8 @@ int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, con
     if (ensure_loss(h, B)) return 1;
     const float* const head[3] = {head_s8, head_s16, head_s32};
     float* const ghead[3] = {g_s8, g_s16, g_s32};
+    if (g_s8)                                                   // the kernel only writes the positives' class gradients
+        for (int k = 0; k < 3; ++k) HIPCHK(h, hipMemsetAsync(ghead[k], 0, (size_t)B * h->grid.hw[k] * h->grid.head_ld * sizeof(float), h->stream));
     launch_loss(nullptr, nullptr, nullptr, head, ghead, target, h->grid, B, h->loss_partial, losses, nullptr, nullptr, nullptr, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;

@@ -101,19 +101,22 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
 
 // ---- train-mode kernels (kernels_bwd.hip) --------------------------------------------------------------
 struct BnApplyArgs {
-    const float* y; const float* mean; const float* invstd; const float* var; const float* gamma; const float* beta;
+    const float* y; const double* acc; float eps;           // acc[2][C]: sum y, sum y*y (launch_bn_stats)
+    float* mean; float* invstd;                              // saved for the backward pass
+    const float* gamma; const float* beta;
     float* out; int out_ld, out_off, out_cs;
     const float* pass; int pass_ld, pass_off, pass_dst_off;
     float* rmean; float* rvar; float momentum;
-    int M, C, act;
+    int M, C, act, lanesC;
 };
 struct BnBwdArgs {
     const float* dz; int dz_ld, dz_off, dz_cs;
     const float* z; int z_ld, z_off, z_cs;
     const float* y; const float* mean; const float* invstd; const float* gamma;
-    const float* m_dyh; const float* m_dyhx;
+    double* acc;                                             // acc[2][C], zeroed: sum dyh, sum dyh*xhat
+    float* dgamma; float* dbeta;
     float* dy;
-    int M, C, act;
+    int M, C, act, lanesC;
 };
 struct WgradArgs {
     const float* dy; int dy_ld;
@@ -122,11 +125,10 @@ struct WgradArgs {
     float* dw;
     int M, N, K;
 };
-int  col_partial_floats(int M, int C);
-void launch_col_stats(const float* y, int ld, int off, int M, int C, float eps, float* partial, float* mean, float* invstd, float* var, hipStream_t s);
-void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* partial, float* out, hipStream_t s);
+void launch_bn_stats(const float* y, int M, int C, double* acc, hipStream_t s);
+void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* out, hipStream_t s);
 void launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
-void launch_bn_bwd(const BnBwdArgs& a, float* partial, float* dgamma, float* dbeta, float* scratch2C, hipStream_t s);
+void launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
 void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, hipStream_t s);
 void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
