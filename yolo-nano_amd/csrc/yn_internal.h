@@ -100,8 +100,13 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
                  float* g_conf, float* g_cls, float* g_t, hipStream_t s);
 
 // ---- train-mode kernels (kernels_bwd.hip) --------------------------------------------------------------
+// Same-address atomics serialise (~50 ns each on this part), so every atomically-accumulated result has several copies
+// ("slots", chosen by block index) that the consumer sums: BatchNorm sums ACC_SLOTS x [2][C] doubles, weight gradients
+// GRAD_SLOTS copies of the flat gradient buffer combined once per step by launch_grad_combine.
+constexpr int ACC_SLOTS = 8;
+constexpr int GRAD_SLOTS = 8;
 struct BnApplyArgs {
-    const float* y; const double* acc; float eps;           // acc[2][C]: sum y, sum y*y (launch_bn_stats)
+    const float* y; const double* acc; float eps;           // acc[ACC_SLOTS][2][C]: sum y, sum y*y (launch_bn_stats)
     float* mean; float* invstd;                              // saved for the backward pass
     const float* gamma; const float* beta;
     float* out; int out_ld, out_off, out_cs;
@@ -111,9 +116,8 @@ struct BnApplyArgs {
 };
 struct BnBwdArgs {
     const float* dz; int dz_ld, dz_off, dz_cs;
-    const float* z; int z_ld, z_off, z_cs;
-    const float* y; const float* mean; const float* invstd; const float* gamma;
-    double* acc;                                             // acc[2][C], zeroed: sum dyh, sum dyh*xhat
+    const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta;
+    double* acc;                                             // acc[ACC_SLOTS][2][C], zeroed: sum dyh, sum dyh*xhat
     float* dgamma; float* dbeta;
     float* dy;
     int M, C, act, lanesC;
@@ -122,17 +126,19 @@ struct WgradArgs {
     const float* dy; int dy_ld;
     const float* x; int x_ld, x_off;
     int H, W, Cin, dense;
-    float* dw;
+    float* dw;                                               // the gradient itself (written, not accumulated)
+    float* partial; size_t partial_cap;                      // scratch for the per-slice copies of dW (floats)
     int M, N, K;
 };
 void launch_bn_stats(const float* y, int M, int C, double* acc, hipStream_t s);
-void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* out, hipStream_t s);
+void launch_col_sum_accumulate(const float* x, int ld, int off, int M, int C, float* out, size_t slot_stride, hipStream_t s);
+void launch_grad_combine(float* g, const float* slots, long n, size_t stride, hipStream_t s);
 void launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 void launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, hipStream_t s);
+void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, size_t slot_stride, hipStream_t s);
 void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
-void launch_stem_wgrad(const float* dy, const float* x, int B, int H, int W, int Cout, float* dw, hipStream_t s);
+void launch_stem_wgrad(const float* dy, const float* x, int B, int H, int W, int Cout, float* dw, float* partial, size_t partial_cap, hipStream_t s);
 void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, int32_t* idx, hipStream_t s);
 void launch_maxpool_bwd(const float* dy, const int32_t* idx, int B, int H, int W, int C, float* dx, hipStream_t s);
 void launch_resample(const float* a, const float* b, float* out, int B, int H, int W, int C, int mode, hipStream_t s);
