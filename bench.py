@@ -89,23 +89,16 @@ def cpu_baseline(args, sd, anchors):
             "sample": "%d reps of a %d-image batch, %dx%d, torch-CPU network + C-oracle NMS, %.1f s" % (reps, n, args.size, args.size, dt)}
 
 
-def synthetic_targets(B, S, C, seed):
-    """[B, N, 11] training labels in tools.multi_gt_creator's layout (tools.py:150-215): 8 objects per image."""
+def synthetic_labels(B, C, seed):
+    """8 random boxes per image, w,h ~ U(0.05, 0.5), uniform classes: lists of [xmin, ymin, xmax, ymax, cls]."""
     import numpy as np
-    from yolo_nano_amd import arch
     rs = np.random.RandomState(seed)
-    N = arch.num_predictions(S)
-    t = np.zeros((B, N, 11), np.float32)
-    for b in range(B):
-        idx = rs.choice(N, 8, replace=False)
-        t[b, idx, 0] = 1.0
-        t[b, idx, 1] = rs.randint(0, C, 8)
-        t[b, idx, 2:4] = rs.uniform(0, 1, (8, 2))
-        t[b, idx, 4:6] = rs.standard_normal((8, 2)) * 0.3
-        t[b, idx, 6] = rs.uniform(1.0, 2.0, 8)
-        c = rs.uniform(0.2, 0.8, (8, 2)); wh = rs.uniform(0.05, 0.4, (8, 2))
-        t[b, idx, 7:9], t[b, idx, 9:11] = c - wh / 2, c + wh / 2
-    return t
+    out = []
+    for _ in range(B):
+        c = rs.uniform(0.25, 0.75, (8, 2)); wh = rs.uniform(0.05, 0.5, (8, 2))
+        box = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32).astype(np.float64)
+        out.append(np.concatenate([box, rs.randint(0, C, (8, 1)).astype(np.float64)], 1).tolist())
+    return out
 
 
 def train_bench(args, rank, world, dev, dist):
@@ -120,8 +113,15 @@ def train_bench(args, rank, world, dev, dist):
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     x = torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32)
-    target = torch.as_tensor(synthetic_targets(B, S, args.classes, 77 + rank)).to(dev)
+    labels = synthetic_labels(B, args.classes, 77 + rank)
+    target = torch.empty((B, h.N, 11), dtype=torch.float32, device=dev)
     lr = 1e-5                                                # small enough that random-init weights stay finite over the run
+
+    def step():
+        # the body of train.py:210-231: label assignment (tools.multi_gt_creator -> yn_make_targets, labels cross PCIe),
+        # forward + loss + backward, gradient all-reduce, SGD
+        h.make_targets(labels, anchors, out=target)
+        return parallel.dp_train_step(h, x, target, lr)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -131,14 +131,28 @@ def train_bench(args, rank, world, dev, dist):
 
     losses = None
     for _ in range(args.warmup):
-        losses = parallel.dp_train_step(h, x, target, lr)
+        losses = step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = parallel.dp_train_step(h, x, target, lr)
+        losses = step()
     sync_all()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     lv = [float(v) for v in losses.tolist()]
+    assign = None
+    if rank == 0:                                            # the label assigner alone, and the CPU restatement of the reference beside it
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            h.make_targets(labels, anchors, out=target)
+        torch.cuda.synchronize(dev)
+        gpu_ms = (time.perf_counter() - t1) / 20 * 1e3
+        from oracle import targets as otg
+        t1 = time.perf_counter()
+        ref = otg.multi_gt_creator(S, [8, 16, 32], labels, anchors)
+        cpu_ms = (time.perf_counter() - t1) * 1e3
+        assign = {"gpu_ms_incl_h2d": round(gpu_ms, 4), "cpu_oracle_ms": round(cpu_ms, 2), "cores": 1,
+                  "objects": sum(len(l) for l in labels), "matches_oracle": bool(torch.equal(target.cpu(), torch.from_numpy(ref)))}
     if rank == 0:
         print(json.dumps({
             "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d SGD training step" % (args.backbone, S, S, B),
@@ -146,10 +160,11 @@ def train_bench(args, rank, world, dev, dist):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 training step: train-mode forward (BN batch statistics), "
-                                   "loss, backward, SGD(0.9, 5e-4); %d-class head (BASELINE configs[2] shape, fp32 not fp16)"
+                                   "loss, backward, SGD(0.9, 5e-4), label assignment on the device; %d-class head (BASELINE configs[2] shape, fp32 not fp16)"
                                    % (args.backbone, S, S, B, args.classes),
                        "global_batch": world * B, "parameters": n_param,
                        "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
+            "label_assigner": assign,
             "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}), flush=True)
     h.close()
 

@@ -139,6 +139,14 @@ int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16
 int  yn_sgd_step(yn_handle* h, float* params_dev, const float* grads_dev, float* momentum_buf_dev, int64_t n,
                  float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 
+/* ---- training labels: tools.multi_gt_creator (tools.py:97-216, call site train.py:212) --------------------------------
+ * labels_dev float64 [total][5] = xmin, ymin, xmax, ymax (fractions of the image), class — the objects of image b are rows
+ * offsets_dev[b] .. offsets_dev[b+1]-1 IN LIST ORDER (a later object overwrites the slot of an earlier one, as in the
+ * reference).  anchors_host: the 9 [w,h] pairs in input pixels as float64 (the reference's Python floats; the float32
+ * copy inside the handle would move IoU ties).  target_dev float32 [B][N][11] = obj, cls, tx, ty, tw, th, weight,
+ * xmin, ymin, xmax, ymax is fully overwritten.  N and the grid come from the handle's current input size. */
+int  yn_make_targets(yn_handle* h, const double* labels_dev, const int32_t* offsets_dev, int B, const double* anchors_host, float* target_dev);
+
 /* ---- training step (train.py:212-231) ---------------------------------------------------------------- */
 /* Parameters, gradients and SGD momentum live in three caller-owned FLAT float32 device buffers of
  * yn_train_param_count() elements, in nn.Module.named_parameters() order of the reference model (per layer:

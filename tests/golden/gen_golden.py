@@ -467,8 +467,48 @@ def gen_train():
     save("train.npz", **a)
 
 
+def gen_targets():
+    """tools.multi_gt_creator (tools.py:97-216) on label lists that exercise every branch: plain positives, several
+    anchors above the ignore threshold (ignore writes), two objects in one cell/anchor slot (last writer wins, an ignore
+    write on top of a positive and the other way round), sub-pixel 'dirty' boxes, image-border boxes, an empty image."""
+    rs = np.random.RandomState(77)
+    out = {}
+    cases = []
+    for ci, (S, C, B, anchors, nobj) in enumerate([(320, 20, 3, arch.MULTI_ANCHOR_SIZE, 12), (416, 80, 4, arch.MULTI_ANCHOR_SIZE_COCO, 25),
+                                                    (608, 80, 2, arch.MULTI_ANCHOR_SIZE_COCO, 40), (128, 20, 2, arch.MULTI_ANCHOR_SIZE, 6)]):
+        labels = []
+        for b in range(B):
+            n = nobj + b
+            cxy = rs.uniform(0.05, 0.95, (n, 2))
+            wh = np.exp(rs.uniform(np.log(0.01), np.log(0.9), (n, 2)))         # log-uniform sizes: every anchor gets used
+            box = np.clip(np.concatenate([cxy - wh / 2, cxy + wh / 2], 1), 0, 1)
+            box = box.astype(np.float32).astype(np.float64)                       # labels are float32 tensors .tolist()-ed (train.py:210)
+            cls = rs.randint(0, C, (n, 1)).astype(np.float64)
+            ls = np.concatenate([box, cls], 1).tolist()
+            # anchor-shaped boxes (IoU 1 with one anchor, > 0.5 with neighbours) stacked on ONE centre: overwrite order matters
+            for k in (0, 4, 8, 3):
+                aw, ah = anchors[k]
+                c = 0.37 + 0.1 * b
+                ls.append([max(c - aw / S / 2, 0.0), max(c - ah / S / 2, 0.0), min(c + aw / S / 2, 1.0), min(c + ah / S / 2, 1.0), float(k % C)])
+            ls.append([0.5, 0.5, 0.5 + 0.9 / S, 0.9, 3.0])                        # dirty: w < 1 px
+            ls.append([0.0, 0.0, 0.2, 0.3, 1.0])                                  # touches the image corner
+            ls.append([0.7, 0.6, 1.0, 1.0, 2.0])                                  # touches the far corner
+            labels.append(ls)
+        if ci == 1:
+            labels[2] = []                                                        # an image without objects
+        tgt = ref_tools.multi_gt_creator(S, list(arch.STRIDES), labels, [list(a) for a in anchors])
+        flat = np.array([[b] + l for b, ls in enumerate(labels) for l in ls], dtype=np.float64).reshape(-1, 6)
+        out["case%d_meta" % ci] = np.array([S, C, B, 0 if anchors is arch.MULTI_ANCHOR_SIZE else 1], dtype=np.int64)
+        out["case%d_labels" % ci] = flat
+        out["case%d_target" % ci] = t2n(tgt)
+        nz = np.count_nonzero(t2n(tgt)[..., 0])
+        cases.append((S, B, flat.shape[0], nz, int((t2n(tgt)[..., 0] < 0).sum())))
+    print("targets cases (S, B, labels, nonzero obj, ignored):", cases)
+    save("targets.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x", "train"]
+    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x", "train", "targets"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

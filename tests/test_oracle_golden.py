@@ -233,3 +233,20 @@ def test_train_oracle_matches_reference_two_steps(golden):
                 np.testing.assert_allclose(net.p[k.split(":", 1)[1] + ".running_mean"].numpy(), g[k], rtol=1e-4, atol=1e-6)
             if k.startswith("rv_%d:" % step):
                 np.testing.assert_allclose(net.p[k.split(":", 1)[1] + ".running_var"].numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def test_label_assigner_oracle_matches_reference(golden):
+    """tools.multi_gt_creator (tools.py:97-216) — the numpy restatement reproduces the reference's
+    targets EXACTLY (float64 arithmetic, float32 cast) on every branch: positives, ignore writes, slot overwrites,
+    dirty boxes, border boxes, an empty image."""
+    from oracle import targets as otg
+    g = golden("targets.npz")
+    for ci in range(4):
+        S, C, B, coco = (int(v) for v in g["case%d_meta" % ci])
+        anchors = arch.MULTI_ANCHOR_SIZE_COCO if coco else arch.MULTI_ANCHOR_SIZE
+        labels = otg.labels_from_flat(g["case%d_labels" % ci], B)
+        got = otg.multi_gt_creator(S, list(arch.STRIDES), labels, anchors)
+        ref = g["case%d_target" % ci]
+        assert got.shape == ref.shape == (B, arch.num_predictions(S), 11)
+        np.testing.assert_array_equal(got, ref)
+        assert (ref[..., 0] < 0).any() and (ref[..., 0] > 0).any()      # the fixture does exercise the ignore branch

@@ -59,6 +59,7 @@ SIGNATURES = {
     "yn_train_bind": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64]),
     "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
+    "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -311,6 +312,28 @@ class Handle:
         assert params.is_contiguous() and grads.is_contiguous() and momentum_buf.is_contiguous() and params.numel() == grads.numel() == momentum_buf.numel()
         self._ck(self.lib.yn_sgd_step(self.h, params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), params.numel(),
                                       float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step))), "yn_sgd_step")
+
+    # ---- training labels
+    def make_targets(self, label_lists, anchor_size, out=None):
+        """tools.multi_gt_creator (tools.py:97-216): list (per image) of [xmin, ymin, xmax, ymax, class] rows ->
+        float32 device tensor [B, N, 11].  The (tiny) label table crosses PCIe once; the assignment runs on the GPU."""
+        import numpy as np
+        B = len(label_lists)
+        counts = [len(l) for l in label_lists]
+        flat = np.zeros((max(sum(counts), 1), 5), dtype=np.float64)
+        if sum(counts):
+            flat[:sum(counts)] = np.array([row for l in label_lists for row in l], dtype=np.float64).reshape(-1, 5)
+        offs = np.zeros(B + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(counts)
+        anchors = np.ascontiguousarray(np.array(anchor_size, dtype=np.float64).reshape(-1))
+        if anchors.size != 6 * self.A:
+            raise YnError("anchor_size must hold %d [w,h] pairs" % (3 * self.A))
+        d_flat = torch.from_numpy(flat).to(self.device, non_blocking=True)
+        d_offs = torch.from_numpy(offs).to(self.device, non_blocking=True)
+        if out is None:
+            out = torch.empty((B, self.N, 11), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.yn_make_targets(self.h, d_flat.data_ptr(), d_offs.data_ptr(), B, anchors.ctypes.data, out.data_ptr()), "yn_make_targets")
+        return out
 
     # ---- training step
     def train_bind(self):

@@ -174,6 +174,84 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
 }
 
 // -------------------------------------------------------------------------------------------------
+// Training label assigner: tools.multi_gt_creator (tools.py:97-216) with compute_iou (tools.py:36-76).
+// The reference walks the objects of an image IN LIST ORDER and later objects overwrite the (cell, anchor) slot of
+// earlier ones (an 'ignore' write only touches obj and weight), so one thread owns one image and keeps that order;
+// float64 arithmetic like numpy, float32 at the store.  `target` must be zero-filled by the caller.
+// -------------------------------------------------------------------------------------------------
+struct TargetArgs {
+    const double* labels;          // [total][5] xmin, ymin, xmax, ymax, class
+    const int32_t* offsets;        // [B+1]
+    float* target;                 // [B][N][11]
+    double anchors[18];
+    int B, S, A, N;
+    int w[3], off[3];
+};
+
+__global__ void targets_kernel(TargetArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const double w = (double)a.S, h = (double)a.S;
+    const int na = 3 * a.A;
+    float* out = a.target + (size_t)b * a.N * 11;
+    for (int li = a.offsets[b]; li < a.offsets[b + 1]; ++li) {
+        const double* lab = a.labels + (size_t)li * 5;
+        const double xmin = lab[0], ymin = lab[1], xmax = lab[2], ymax = lab[3];
+        const int cls = (int)lab[4];
+        const double c_x = (xmax + xmin) / 2 * w, c_y = (ymax + ymin) / 2 * h;
+        const double box_w = (xmax - xmin) * w, box_h = (ymax - ymin) * h;
+        if (box_w < 1. || box_h < 1.) continue;                                   // tools.py:122-124
+        double iou[9];
+        int best = 0;
+        bool any_above = false;
+        for (int i = 0; i < na; ++i) {
+            const double aw = a.anchors[2 * i], ah = a.anchors[2 * i + 1];
+            const double ax1 = 0.0 - aw / 2, ay1 = 0.0 - ah / 2, ax2 = 0.0 + aw / 2, ay2 = 0.0 + ah / 2;
+            const double gx1 = 0.0 - box_w / 2, gy1 = 0.0 - box_h / 2, gx2 = 0.0 + box_w / 2, gy2 = 0.0 + box_h / 2;
+            const double i_w = fmin(gx2, ax2) - fmax(gx1, ax1);
+            const double i_h = fmin(gy2, ay2) - fmax(gy1, ay1);
+            const double s_i = i_h * i_w;
+            const double u = box_w * box_h + aw * ah - s_i + 1e-20;
+            iou[i] = s_i / u;
+            if (iou[i] > iou[best]) best = i;                                       // np.argmax: first maximum
+            any_above |= iou[i] > 0.5;
+        }
+        for (int index = 0; index < na; ++index) {
+            const bool is_best = index == best;
+            if (any_above ? !(iou[index] > 0.5) : !is_best) continue;
+            const int si = index / a.A, ab = index - si * a.A;
+            const double s = (double)(8 << si);
+            const double c_x_s = c_x / s, c_y_s = c_y / s;
+            const int gx = (int)c_x_s, gy = (int)c_y_s;
+            if (gx < 0 || gy < 0 || gx >= a.w[si] || gy >= a.w[si]) continue;     // positives: tools.py:157; ignore writes would raise in numpy
+            float* t = out + ((size_t)a.off[si] + ((size_t)gy * a.w[si] + gx) * a.A + ab) * 11;
+            if (is_best) {
+                const double pw = a.anchors[2 * index], ph = a.anchors[2 * index + 1];
+                t[0] = 1.0f;
+                t[1] = (float)cls;
+                t[2] = (float)(c_x_s - gx); t[3] = (float)(c_y_s - gy);
+                t[4] = (float)log(box_w / pw); t[5] = (float)log(box_h / ph);
+                t[6] = (float)(2.0 - (box_w / w) * (box_h / h));
+                t[7] = (float)xmin; t[8] = (float)ymin; t[9] = (float)xmax; t[10] = (float)ymax;
+            } else {
+                t[0] = -1.0f;                                                       // tools.py:206-207
+                t[6] = -1.0f;
+            }
+        }
+    }
+}
+
+void launch_make_targets(const double* labels, const int32_t* offsets, int B, const double* anchors18, const GridInfo& g, float* target, hipStream_t s)
+{
+    TargetArgs a{};
+    a.labels = labels; a.offsets = offsets; a.target = target; a.B = B; a.S = g.S; a.A = g.A; a.N = g.N;
+    for (int i = 0; i < 18; ++i) a.anchors[i] = i < 6 * g.A ? anchors18[i] : 0.0;
+    for (int k = 0; k < 3; ++k) { a.w[k] = g.w[k]; a.off[k] = g.off[k]; }
+    hipLaunchKernelGGL(targets_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
+}
+
+// -------------------------------------------------------------------------------------------------
 // torch.optim.SGD(momentum, weight_decay) step (train.py:167-171, 230) over one FLAT parameter bucket, fused with
 // the 1/world_size scaling of the all-reduced gradient sum (one flat bucket, one RCCL all-reduce per step):
 //     g = grad * grad_scale + wd * p ;  buf = first ? g : momentum * buf + g ;  p -= lr * buf

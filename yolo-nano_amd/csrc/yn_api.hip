@@ -985,6 +985,17 @@ int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, con
     return 0;
 }
 
+int yn_make_targets(yn_handle* h, const double* labels_dev, const int32_t* offsets_dev, int B, const double* anchors_host, float* target_dev)
+{
+    if (!h) return 1;
+    if (B <= 0 || !offsets_dev || !target_dev || !anchors_host) return fail(h, "yn_make_targets: bad arguments");
+    if (h->grid.A != 3) return fail(h, "yn_make_targets: the label assigner is defined for 3 anchors per scale (got %d)", h->grid.A);
+    HIPCHK(h, hipMemsetAsync(target_dev, 0, (size_t)B * h->grid.N * 11 * sizeof(float), h->stream));
+    launch_make_targets(labels_dev, offsets_dev, B, anchors_host, h->grid, target_dev, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int yn_sgd_step(yn_handle* h, float* params, const float* grads, float* momentum_buf, int64_t n,
                 float lr, float momentum, float weight_decay, float grad_scale, int first_step)
 {

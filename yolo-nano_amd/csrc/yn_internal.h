@@ -99,6 +99,8 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
                  const float* target, const GridInfo& g, int B, float* partial, float* losses,
                  float* g_conf, float* g_cls, float* g_t, hipStream_t s);
 
+void launch_make_targets(const double* labels, const int32_t* offsets, int B, const double* anchors18, const GridInfo& g, float* target, hipStream_t s);
+
 // ---- train-mode kernels (kernels_bwd.hip) --------------------------------------------------------------
 // Same-address atomics serialise (~50 ns each on this part), so every atomically-accumulated result has several copies
 // ("slots", chosen by block index) that the consumer sums: BatchNorm sums ACC_SLOTS x [2][C] doubles, weight gradients

@@ -347,6 +347,13 @@ class YOLONano(nn.Module):
             self._stats_stale = False
         return h
 
+    def make_targets(self, label_lists):
+        """tools.multi_gt_creator for this model's input size / anchors, on the model's device -> [B, N, 11] CUDA tensor."""
+        h = self._handle if self._handle is not None else self.handle(len(label_lists))
+        if h.S != self.input_size:
+            h.set_grid(self.input_size)
+        return h.make_targets(label_lists, self.anchor_list)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._sig = None
@@ -381,6 +388,24 @@ class YOLONano(nn.Module):
         h = self.handle(x.shape[0])
         out = h.infer(x.float())
         return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
+
+
+_target_handles = {}
+
+
+def multi_gt_creator(input_size, strides, label_lists, anchor_size, device=None):
+    """tools.multi_gt_creator (tools.py:97-216) with the reference's signature, computed on the GPU (yn_make_targets):
+    -> float32 CUDA tensor [B, N, 11] (the reference returns a CPU tensor that train.py:216 moves to the device)."""
+    if list(strides) != [8, 16, 32]:
+        raise YnError("strides must be [8, 16, 32] (models/yolo_nano.py:23), got %r" % (strides,))
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (int(input_size), str(dev))
+    h = _target_handles.get(key)
+    if h is None:
+        if len(_target_handles) >= 16:                       # multi-scale training cycles through 10 sizes (train.py:202-208)
+            _target_handles.pop(next(iter(_target_handles))).close()
+        h = _target_handles[key] = Handle(int(input_size), 1, [list(a) for a in anchor_size], "1.0x", max_batch=1, device=dev)
+    return h.make_targets(label_lists, anchor_size)
 
 
 class _TrainStep(torch.autograd.Function):
