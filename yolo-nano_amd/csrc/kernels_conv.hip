@@ -1020,37 +1020,69 @@ __device__ __forceinline__ void vfma(float4& acc, const float4 v, const float4 w
 __device__ __forceinline__ float2 vact(float2 v, int act) { return make_float2(apply_act(v.x, act), apply_act(v.y, act)); }
 __device__ __forceinline__ float4 vact(float4 v, int act) { return make_float4(apply_act(v.x, act), apply_act(v.y, act), apply_act(v.z, act), apply_act(v.w, act)); }
 
-// VEC channels per thread: 4 (16-byte accesses) whenever C, the row strides and the channel offsets allow it
-template <int STRIDE, int VEC>
+// Depthwise 3x3, one thread = VEC channels x a RUN of R horizontally adjacent output pixels.  The whole input window
+// of the run (3 rows x (R+2) or (2R+1) columns) is fetched with unconditional loads at clamped addresses before any of
+// it is used — with `if (inside) load` the compiler emits one branch + one vmcnt(0) wait per tap and the kernel sits at
+// a third of the HBM rate — and out-of-image taps are zeroed with an opaque bit mask (a select would be sunk back into
+// a branch).  VEC = 4 (16-byte accesses) whenever C, the row strides and the channel offsets allow it, else 2.
+__device__ __forceinline__ unsigned opaque_mask(bool ok)
+{
+    unsigned mk = ok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(mk));
+    return mk;
+}
+__device__ __forceinline__ float2 vmask(float2 v, unsigned mk)
+{
+    return make_float2(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk));
+}
+__device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
+{
+    return make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
+                       __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+}
+
+template <int STRIDE, int VEC, int R>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
 {
     typedef typename VecT<VEC>::type vec;
+    constexpr int NCOL = STRIDE == 1 ? R + 2 : 2 * R + 1;
     const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
-    const int cv_n = a.C / VEC;
-    const long total = (long)a.B * Ho * Wo * cv_n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cv = (int)(i % cv_n);
-        const long p = i / cv_n;
-        const int ox = (int)(p % Wo);
-        const long q = p / Wo;
-        const int oy = (int)(q % Ho);
-        const int b = (int)(q / Ho);
-        const int c = cv * VEC;
-        vec acc = *reinterpret_cast<const vec*>(a.bias + c);
+    const int cv_n = a.C / VEC, segs = (Wo + R - 1) / R;
+    const int total = a.B * Ho * segs * cv_n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cv = i % cv_n;
+    int q = i / cv_n;
+    const int seg = q % segs; q /= segs;
+    const int oy = q % Ho, b = q / Ho;
+    const int c = cv * VEC, ox0 = seg * R;
+    vec col[3][NCOL];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * STRIDE - 1 + ky;
-            if (iy < 0 || iy >= a.H) continue;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * STRIDE - 1 + ky;
+        const bool yok = iy >= 0 && iy < a.H;
+        const float* row = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * a.in_ld + a.in_off + c;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * STRIDE - 1 + kx;
-                if (ix < 0 || ix >= a.W) continue;
-                const vec v = *reinterpret_cast<const vec*>(a.in + ((size_t)(b * a.H + iy) * a.W + ix) * a.in_ld + a.in_off + c);
-                const vec w = *reinterpret_cast<const vec*>(a.w + (ky * 3 + kx) * a.C + c);
-                vfma(acc, v, w);
-            }
+        for (int j = 0; j < NCOL; ++j) {
+            const int ix = ox0 * STRIDE - 1 + j;
+            const unsigned mk = opaque_mask(yok && ix >= 0 && ix < a.W);
+            col[ky][j] = vmask(*reinterpret_cast<const vec*>(row + (size_t)(ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix)) * a.in_ld), mk);
         }
-        *reinterpret_cast<vec*>(a.out + (size_t)p * a.out_ld + a.out_off + c) = vact(acc, a.act);
+    }
+    vec w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const vec*>(a.w + k * a.C + c);
+    const vec bias = *reinterpret_cast<const vec*>(a.bias + c);
+    float* orow = a.out + ((size_t)(b * Ho + oy) * Wo) * a.out_ld + a.out_off + c;
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        if (ox0 + o >= Wo) break;
+        vec acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) vfma(acc, col[ky][o * STRIDE + kx], w[ky * 3 + kx]);
+        *reinterpret_cast<vec*>(orow + (size_t)(ox0 + o) * a.out_ld) = vact(acc, a.act);
     }
 }
 
@@ -1058,18 +1090,18 @@ void launch_dw(const DwArgs& a, hipStream_t s)
 {
     const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
     const bool v4 = (a.C % 4 == 0) && (a.in_ld % 4 == 0) && (a.in_off % 4 == 0) && (a.out_ld % 4 == 0) && (a.out_off % 4 == 0);
-    const long total = (long)a.B * Ho * Wo * (a.C / (v4 ? 4 : 2));
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (blocks < 1) blocks = 1;
-    const dim3 g((unsigned)blocks), blk(256);
+    // run length: 4 outputs per thread (8 for the 2-channel variant at stride 1) unless that leaves too few threads to fill the chip
+    auto blocks_for = [&](int vec, int r) { return ((long)a.B * Ho * ((Wo + r - 1) / r) * (a.C / vec) + 255) / 256; };
+#define YN_DW(ST, V, R) { g_last_kernel = "dwconv3x3_kernel<" #ST "," #V "," #R ">"; \
+        hipLaunchKernelGGL((dwconv3x3_kernel<ST, V, R>), dim3((unsigned)blocks_for(V, R)), dim3(256), 0, s, a); return; }
     if (a.stride == 1) {
-        if (v4) { g_last_kernel = "dwconv3x3_kernel<1,4>"; hipLaunchKernelGGL((dwconv3x3_kernel<1, 4>), g, blk, 0, s, a); }
-        else    { g_last_kernel = "dwconv3x3_kernel<1,2>"; hipLaunchKernelGGL((dwconv3x3_kernel<1, 2>), g, blk, 0, s, a); }
+        if (v4) { if (blocks_for(4, 4) >= 1024) YN_DW(1, 4, 4) else YN_DW(1, 4, 2) }
+        else    { if (blocks_for(2, 8) >= 1024) YN_DW(1, 2, 8) else YN_DW(1, 2, 4) }
     } else {
-        if (v4) { g_last_kernel = "dwconv3x3_kernel<2,4>"; hipLaunchKernelGGL((dwconv3x3_kernel<2, 4>), g, blk, 0, s, a); }
-        else    { g_last_kernel = "dwconv3x3_kernel<2,2>"; hipLaunchKernelGGL((dwconv3x3_kernel<2, 2>), g, blk, 0, s, a); }
+        if (v4) { if (blocks_for(4, 4) >= 1024) YN_DW(2, 4, 4) else YN_DW(2, 4, 2) }
+        else    { if (blocks_for(2, 4) >= 1024) YN_DW(2, 2, 4) else YN_DW(2, 2, 2) }
     }
+#undef YN_DW
 }
 
 // -------------------------------------------------------------------------------------------------
