@@ -27,6 +27,26 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
+// Loads whose result is only sometimes wanted are issued UNCONDITIONALLY at a clamped (always legal) address and the
+// unwanted values are zeroed with a bit mask the optimiser cannot see through.  `if (ok) v = load` — and `ok ? load : 0`,
+// and `load & mask` with a visible mask — all compile to a branch around the load followed by s_waitcnt vmcnt(0), i.e.
+// one full memory latency per load instead of one per batch of loads.
+__device__ __forceinline__ unsigned opaque_mask(bool ok)
+{
+    unsigned mk = ok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(mk));
+    return mk;
+}
+__device__ __forceinline__ float2 vmask(float2 v, unsigned mk)
+{
+    return make_float2(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk));
+}
+__device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
+{
+    return make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
+                       __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+}
+
 // -------------------------------------------------------------------------------------------------
 // GEMM convolution.  Block = 4 waves laid out WM x WN; each wave owns a 32 x (32*NT) output tile and
 // keeps it in NT 32x32 f32 MFMA accumulators.  K is consumed in chunks of 2*KP through NBUF LDS buffers:
@@ -96,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 #pragma unroll
             for (int i = 0; i < A_PER / 2; ++i) {
                 const int m = m0 + t / (KP / 2) + (512 / KP) * i;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (kv && m < a.M) v = *reinterpret_cast<const float4*>(a.in + (size_t)m * a.in_ld + a.in_off + k);
+                const bool ok = kv && m < a.M;
+                const float4 v = vmask(*reinterpret_cast<const float4*>(a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0)), opaque_mask(ok));
                 a_reg[2 * i] = make_float2(v.x, v.y);
                 a_reg[2 * i + 1] = make_float2(v.z, v.w);
             }
@@ -106,9 +126,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
             const bool kv = k < a.K;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                float2 v = make_float2(0.0f, 0.0f);
-                if (kv && a_m[i] >= 0) v = *reinterpret_cast<const float2*>(a.in + (size_t)a_m[i] * a.in_ld + a.in_off + k);
-                a_reg[i] = v;
+                const bool ok = kv && a_m[i] >= 0;
+                a_reg[i] = vmask(*reinterpret_cast<const float2*>(a.in + (size_t)(a_m[i] >= 0 ? a_m[i] : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0)), opaque_mask(ok));
             }
         } else {
             const int kk = k0 + 2 * a_kp;                   // global k = tap*Cin + ci
@@ -117,21 +136,21 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
-                float2 v = make_float2(0.0f, 0.0f);
-                if (a_m[i] >= 0 && tap < 9) {
-                    const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
-                    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                        const int src = a_m[i] + dy * a.W + dx;
-                        v = *reinterpret_cast<const float2*>(a.in + (size_t)src * a.in_ld + a.in_off + ci);
-                        if (a.resample) {
-                            const int b = a_m[i] / (a.H * a.W);
-                            size_t p2;
-                            if (a.resample == 1) p2 = ((size_t)b * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1);
-                            else                 p2 = ((size_t)b * (a.H << 1) + (y << 1)) * (a.W << 1) + (x << 1);
-                            const float2 u = *reinterpret_cast<const float2*>(a.in2 + p2 * a.K + ci);
-                            v.x += u.x; v.y += u.y;
-                        }
-                    }
+                const int mc = a_m[i] >= 0 ? a_m[i] : 0;
+                const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+                const bool ok = a_m[i] >= 0 && tap < 9 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                const unsigned mk = opaque_mask(ok);
+                const int src = ok ? mc + dy * a.W + dx : mc;          // clamped to the centre pixel when the tap is outside
+                const int cic = tap < 9 ? ci : 0;
+                float2 v = vmask(*reinterpret_cast<const float2*>(a.in + (size_t)src * a.in_ld + a.in_off + cic), mk);
+                if (a.resample) {
+                    const int yc = ok ? y : 0, xc = ok ? x : 0;
+                    const int b = mc / (a.H * a.W);
+                    size_t p2;
+                    if (a.resample == 1) p2 = ((size_t)b * (a.H >> 1) + (yc >> 1)) * (a.W >> 1) + (xc >> 1);
+                    else                 p2 = ((size_t)b * (a.H << 1) + (yc << 1)) * (a.W << 1) + (xc << 1);
+                    const float2 u = vmask(*reinterpret_cast<const float2*>(a.in2 + p2 * a.K + cic), mk);
+                    v.x += u.x; v.y += u.y;
                 }
                 a_reg[i] = v;
             }
@@ -142,9 +161,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
             const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
             const int kpg = (k0 >> 1) + kp;
             const int n = n0 + c4 * 2;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kpg < kp_total && n < a.Npad) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + n) * 2);
-            b_reg[i] = v;
+            const bool ok = kpg < kp_total && n < a.Npad;
+            b_reg[i] = vmask(*reinterpret_cast<const float4*>(a.Wp + ((size_t)(ok ? kpg : 0) * a.Npad + (ok ? n : 0)) * 2), opaque_mask(ok));
         }
     };
     auto stage = [&](int buf) {
@@ -1025,22 +1043,6 @@ __device__ __forceinline__ float4 vact(float4 v, int act) { return make_float4(a
 // it is used — with `if (inside) load` the compiler emits one branch + one vmcnt(0) wait per tap and the kernel sits at
 // a third of the HBM rate — and out-of-image taps are zeroed with an opaque bit mask (a select would be sunk back into
 // a branch).  VEC = 4 (16-byte accesses) whenever C, the row strides and the channel offsets allow it, else 2.
-__device__ __forceinline__ unsigned opaque_mask(bool ok)
-{
-    unsigned mk = ok ? 0xffffffffu : 0u;
-    asm volatile("" : "+v"(mk));
-    return mk;
-}
-__device__ __forceinline__ float2 vmask(float2 v, unsigned mk)
-{
-    return make_float2(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk));
-}
-__device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
-{
-    return make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
-                       __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
-}
-
 template <int STRIDE, int VEC, int R>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
 {
