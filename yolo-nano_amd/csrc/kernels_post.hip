@@ -448,32 +448,42 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
     if (jr < n) {
         const float4 bx = sb[jr];
         const float ar = (bx.z - bx.x) * (bx.w - bx.y);
-        const bool fast_ok = !DIOU && thresh >= 1e-9f && plain_box(bx) && ar > 1e-10f;
-        const f32x2 ilo = {bx.x, bx.y}, ihi = {bx.z, bx.w};
         const int t0 = (ri == ci) ? lane + 1 : 0;
         const int t1 = min(64, n - ci * 64);
         u64 valid = (t1 == 64 ? ~0ull : ((1ull << t1) - 1ull));
         valid &= (t0 >= 64) ? 0ull : ~((1ull << t0) - 1ull);
-        // phase 1, branch-free: which columns are geometrically disjoint from this row's box
-        unsigned dlo = 0, dhi = 0;
-#ifdef YN_EXP_NOFILTER
-        dlo = dhi = 0xffffffffu;
-#else
+        u64 slow = valid;
+        if (!DIOU) {
+            // Dense, branch-free pass over the chunk's columns (uniform loop, broadcast LDS reads, 8 columns per step, only the
+            // t1 live columns): the reference's own arithmetic up to inter and union, then the division-free decision of
+            // suppressed() — inter vs thresh*union with a 1e-5 guard band.  Pairs inside the band (or with union <= 0 / NaN)
+            // are the only ones left for the exact path below.
+            const f32x2 ilo = {bx.x, bx.y}, ihi = {bx.z, bx.w};
+            const f32x2 tiny = {1e-28f, 1e-28f};
+            u64 sure = 0, unsure = 0;
+            for (int t8 = 0; t8 < t1; t8 += 8) {
+                unsigned s8 = 0, u8 = 0;
 #pragma unroll
-        for (int t = 0; t < 64; ++t) {
-            const float4 bt = cbox[t];
-            const f32x2 jlo = {bt.x, bt.y}, jhi = {bt.z, bt.w};
-            const f32x2 d = __builtin_elementwise_min(ihi, jhi) - __builtin_elementwise_max(ilo, jlo);
-            const unsigned bit = fminf(d.x, d.y) <= 0.0f ? (1u << (t & 31)) : 0u;
-            if (t < 32) dlo |= bit; else dhi |= bit;
+                for (int u = 0; u < 8; ++u) {
+                    const float4 bt = cbox[t8 + u];
+                    const f32x2 jlo = {bt.x, bt.y}, jhi = {bt.z, bt.w};
+                    const f32x2 d = __builtin_elementwise_min(ihi, jhi) - __builtin_elementwise_max(ilo, jlo);
+                    const f32x2 wh = __builtin_elementwise_max(tiny, d);
+                    const float inter = wh.x * wh.y;
+                    const float un = (ar + carea[t8 + u]) - inter;
+                    const float pth = thresh * un;
+                    const bool dec = un > 0.0f && pth > 1e-30f;
+                    const bool st = dec && inter > pth * 1.00001f;
+                    const bool sf = dec && inter < pth * 0.99999f;
+                    s8 |= st ? (1u << u) : 0u;
+                    u8 |= (st || sf) ? 0u : (1u << u);
+                }
+                sure |= (u64)s8 << t8;
+                unsure |= (u64)u8 << t8;
+            }
+            mask = sure & valid;
+            slow = unsure & valid;
         }
-#endif
-        const u64 disjoint = ((u64)dhi << 32) | dlo;
-        // phase 2, exact arithmetic only for the pairs the filter cannot decide (overlapping or non-plain boxes)
-        u64 slow = fast_ok ? (valid & ~(disjoint & col_plain)) : valid;
-#ifdef YN_EXP_NOSLOW
-        mask = slow; slow = 0;
-#endif
         while (slow) {
             const int t = __ffsll((long long)slow) - 1;
             slow &= slow - 1;
