@@ -14,6 +14,7 @@
 
 #include "../../include/yolonano_hip.h"
 #include "yn_internal.h"
+#include <stdlib.h>
 
 using namespace ynk;
 
@@ -87,6 +88,7 @@ struct yn_handle {
     size_t heads_cap = 0;
     float* loss_partial = nullptr;
     size_t loss_partial_cap = 0;
+    bool fuse_unit = false;              // stride-1 ShuffleV2 units as one kernel (kernels_unit.hip): parity-tested, measured slower — YN_FUSE_UNIT=1 enables
     // training (yn_train.inc): caller-owned flat buffers + per-layer packs + workspace
     float *tP = nullptr, *tG = nullptr, *tM = nullptr;
     int64_t tN = 0, tN_expected = 0;
@@ -407,6 +409,29 @@ void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
 
 // depthwise 3x3 (stride 1) + the pointwise conv that consumes it, fused (launch_dwpw); falls back to the two
 // separate kernels through `tmp` when the shape does not fit the fused kernel's LDS budget
+// stride-1 ShuffleV2 unit (backbone/shufflenetv2.py:70-72): x [B,H,W,C] -> out [B,H,W,C]; one fused kernel when the shape
+// fits (kernels_unit.hip), else pointwise -> depthwise -> pointwise with the concat+shuffle epilogue (t1, t2 scratch)
+void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
+              float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off);
+void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, int W, float* out, float* t1, float* t2)
+{
+    const Layer& pw1 = L(h, P + ".b2.pw1");
+    const Layer& dw = L(h, P + ".b2.dw");
+    const Layer& pw2 = L(h, P + ".b2.pw2");
+    const int bf = pw1.cout, C = 2 * bf;
+    const long M = (long)B * H * W;
+    if (h->fuse_unit && pw1.cin == bf && pw1.act == YN_ACT_RELU && pw2.act == YN_ACT_RELU && dw.stride == 1 && dw.act != YN_ACT_LEAKY) {
+        UnitArgs a{};
+        a.x = x; a.out = out; a.Wp1 = pw1.w_packed; a.b1 = pw1.b_packed; a.wdw = dw.w_packed; a.bdw = dw.b_packed;
+        a.Wp2 = pw2.w_packed; a.b2 = pw2.b_packed; a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw1.Npad; a.dw_act = dw.act;
+        Bracket br(h, P + ".unit", 2.0 * M * bf * (2.0 * bf + 9.0), 4.0 * (M * 4.0 * bf + 2.0 * bf * bf + 10.0 * bf));
+        if (launch_shuffle_unit(a, h->cur)) return;
+        br.cancel();
+    }
+    run_pw(h, pw1, x, C, bf, M, t1, bf, 0, nullptr, 0, 0);
+    run_dwpw(h, dw, pw2, t1, bf, 0, B, H, W, t2, out, C, 0, x, C, 0);
+}
+
 void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
               float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
 {
@@ -527,8 +552,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             snprintf(nm, sizeof nm, "backbone.stage%d.%d", si + 2, bi);
             const std::string P = nm;
             // stride-1 block: backbone/shufflenetv2.py:70-72 — x1 = ch [0,bf) passes through, x2 = ch [bf,C)
-            run_pw(h, L(h, P + ".b2.pw1"), o_cur, C, bf, Mo, t1, bf, 0, nullptr, 0, 0);
-            run_dwpw(h, L(h, P + ".b2.dw"), L(h, P + ".b2.pw2"), t1, bf, 0, B, Ho, Ho, t2, o_nxt, C, 0, o_cur, C, 0);
+            run_unit(h, P, o_cur, B, Ho, Ho, o_nxt, t1, t2);
             float* tmp = o_cur; o_cur = o_nxt; o_nxt = tmp;
         }
         cfeat[si] = o_cur;
@@ -641,6 +665,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
+    if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
     *out = h;
@@ -1120,8 +1145,7 @@ int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, 
         run_dw(h, L(h, P + ".b2.dw"), t1, bf, 0, B, H, W, t2, bf, 0);
         run_pw(h, L(h, P + ".b2.pw2"), t2, bf, 0, Mo, y, C, 0, tb1, bf, 0);
     } else {
-        run_pw(h, pw1, x, C, bf, Mi, t1, bf, 0, nullptr, 0, 0);
-        run_dwpw(h, L(h, P + ".b2.dw"), L(h, P + ".b2.pw2"), t1, bf, 0, B, H, W, t2, y, C, 0, x, C, 0);
+        run_unit(h, P, x, B, H, W, y, t1, t2);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -28,6 +28,17 @@ struct DwArgs {
     int B, H, W, C, stride, act;                // H,W = input extent
 };
 
+// one stride-1 ShuffleV2 unit in a single kernel (kernels_unit.hip)
+struct UnitArgs {
+    const float* x; float* out;                 // [B,H,W,2*bf] NHWC; x1 = channels [0,bf), x2 = [bf,2bf)
+    const float* Wp1; const float* b1;          // pw1: packed [bf/2][Npad][2], bias [Npad] (BN folded, ReLU)
+    const float* wdw; const float* bdw;         // depthwise: [9][bf], [bf]
+    const float* Wp2; const float* b2;          // pw2
+    int B, H, W, bf, Npad, dw_act;
+    int CS, TH, TW, tilesY, tilesX;             // filled by the launcher
+};
+bool launch_shuffle_unit(const UnitArgs& a, hipStream_t s);
+
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
 void set_last_kernel_name(const char* n);
 int  pw_config_count();
