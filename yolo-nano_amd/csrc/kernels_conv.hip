@@ -47,6 +47,71 @@ __device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
                        __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
 }
 
+// ---- GEMM epilogue shared by the tiled and the persistent kernel: bias + activation (+ concat/shuffle interleave with
+//      the pass-through half).  mbase / nbase = first row / column of this wave's 32 x (32*NT) accumulator block.
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane)
+{
+    const int l31 = lane & 31, h = lane >> 5;
+    if (vecO) {
+        // 16-byte stores: an accumulator quad (regs 4g..4g+3 = 4 consecutive rows, lanes 4q'..4q'+3 = 4 consecutive
+        // columns) is transposed inside its 4 lanes with two xor-shuffles, so lane j ends up with row j x 4 columns.
+        const int j = lane & 3;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ncol = nbase + nt * 32 + l31;            // this lane's column before the transpose
+            const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
+            const int nq = nbase + nt * 32 + (l31 & ~3);       // first column of the quad
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
+                float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
+                {   // 2x2 blocks
+                    const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
+                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+                }
+                {   // 4x4
+                    const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
+                    const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                    if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+                }
+                const int m = mbase + 8 * g + 4 * h + j;
+                if (m < a.M && nq < a.N) {
+                    if (a.pass) {
+                        const float4 p = *reinterpret_cast<const float4*>(a.pass + (size_t)m * a.pass_ld + a.pass_off + nq);
+                        float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
+                        *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
+                        *reinterpret_cast<float4*>(o + 4) = make_float4(p.z, v2, p.w, v3);
+                    } else {
+                        *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nbase + nt * 32 + l31;
+        if (n >= a.N) continue;
+        const float bias = a.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = mbase + row;
+            if (m >= a.M) continue;
+            const float v = apply_act(acc[nt][r] + bias, a.act);
+            if (a.pass) {
+                const float p = a.pass[(size_t)m * a.pass_ld + a.pass_off + n];
+                *reinterpret_cast<float2*>(a.out + (size_t)m * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
+            } else {
+                a.out[(size_t)m * a.out_ld + a.out_off + n] = v;
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // GEMM convolution.  Block = 4 waves laid out WM x WN; each wave owns a 32 x (32*NT) output tile and
 // keeps it in NT 32x32 f32 MFMA accumulators.  K is consumed in chunks of 2*KP through NBUF LDS buffers:
@@ -240,64 +305,164 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
         }
     }
 
-    // ---- epilogue: bias + activation (+ concat/shuffle interleave with the pass-through half) ----
-    if (vecO) {
-        // 16-byte stores: an accumulator quad (regs 4g..4g+3 = 4 consecutive rows, lanes 4q'..4q'+3 = 4 consecutive
-        // columns) is transposed inside its 4 lanes with two xor-shuffles, so lane j ends up with row j x 4 columns.
-        const int j = lane & 3;
+    gemm_epilogue<NT>(a, acc, m0 + wm * 32, n0 + wn * NT * 32, vecO, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Persistent pointwise GEMM for thin K (K <= 128).  The tiled kernel above re-stages the K x BN weight slice for
+// every 32..128-row tile and runs "load -> barrier -> MFMA -> store" once per block, so a launch of a few hundred
+// blocks is mostly latency.  Here the weight slice of the block column is staged into LDS ONCE and a block walks
+// 64-row M tiles (tile = blockIdx.x + i*gridDim.x): the next tile's A rows are requested from global memory before the
+// MFMAs of the current tile are issued and written to the other A buffer after its epilogue, so the loads, MFMAs and
+// stores of consecutive tiles overlap inside a block.  Same fragment layout and k order as gemm_conv_kernel => results
+// are bit-identical to every tiled configuration.  Block = 4 waves as 2 (M) x 2 (N), 32 x (32*NTW) per wave.
+// -------------------------------------------------------------------------------------------------
+template <int NTW>
+__global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs a)
+{
+    constexpr int BM = 64, BN = 64 * NTW, AS = BM * 2 + 2, BS = BN * 2, A_MAX = 8;
+    extern __shared__ __attribute__((aligned(16))) float ps_smem[];
+    const int nq = (a.K + 3) >> 2, kpn = 2 * nq, kp_total = (a.K + 1) >> 1;
+    float* Bs = ps_smem;                                     // [kpn][BS]
+    float* As = Bs + (size_t)kpn * BS;                       // [2][kpn][AS]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n0 = blockIdx.y * BN;
+    const int ntiles = (a.M + BM - 1) / BM;
+    const bool vecA = ((a.K | a.in_ld | a.in_off) & 3) == 0;
+    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
+    const int kqn = vecA ? (a.K >> 2) : (a.K >> 1);          // 16- or 8-byte groups per row
+    const int agroups = BM * kqn;
+
+    float4 a_reg[A_MAX];
+    auto prefetch_a = [&](int tile) {
+        const int m0 = tile * BM;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int ncol = n0 + (wn * NT + nt) * 32 + l31;            // this lane's column before the transpose
-            const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
-            const int nq = n0 + (wn * NT + nt) * 32 + (l31 & ~3);       // first column of the quad
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
-                float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
-                {   // 2x2 blocks
-                    const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
-                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
-                    if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
-                }
-                {   // 4x4
-                    const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
-                    const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
-                    if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
-                }
-                const int m = m0 + wm * 32 + 8 * g + 4 * h + j;
-                if (m < a.M && nq < a.N) {
-                    if (a.pass) {
-                        const float4 p = *reinterpret_cast<const float4*>(a.pass + (size_t)m * a.pass_ld + a.pass_off + nq);
-                        float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
-                        *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
-                        *reinterpret_cast<float4*>(o + 4) = make_float4(p.z, v2, p.w, v3);
-                    } else {
-                        *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
-                    }
-                }
-            }
+        for (int i = 0; i < A_MAX; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / kqn, kq = idx - row * kqn;
+            const int m = m0 + row;
+            const bool ok = idx < agroups && m < a.M;
+            const unsigned mk = opaque_mask(ok);
+            const float* src = a.in + (size_t)(ok ? m : m0) * a.in_ld + a.in_off + (ok ? kq : 0) * (vecA ? 4 : 2);
+            if (vecA) a_reg[i] = vmask(*reinterpret_cast<const float4*>(src), mk);
+            else { const float2 v = vmask(*reinterpret_cast<const float2*>(src), mk); a_reg[i] = make_float4(v.x, v.y, 0.0f, 0.0f); }
         }
-        return;
-    }
+    };
+    auto stage_a = [&](int buf) {
+        float* Ab = As + (size_t)buf * kpn * AS;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias = a.bias[n];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + wm * 32 + row;
-            if (m >= a.M) continue;
-            const float v = apply_act(acc[nt][r] + bias, a.act);
-            if (a.pass) {
-                const float p = a.pass[(size_t)m * a.pass_ld + a.pass_off + n];
-                *reinterpret_cast<float2*>(a.out + (size_t)m * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
+        for (int i = 0; i < A_MAX; ++i) {
+            const int idx = t + 256 * i;
+            if (idx >= agroups) continue;
+            const int row = idx / kqn, kq = idx - row * kqn;
+            if (vecA) {
+                *reinterpret_cast<float2*>(Ab + (2 * kq) * AS + row * 2) = make_float2(a_reg[i].x, a_reg[i].y);
+                *reinterpret_cast<float2*>(Ab + (2 * kq + 1) * AS + row * 2) = make_float2(a_reg[i].z, a_reg[i].w);
             } else {
-                a.out[(size_t)m * a.out_ld + a.out_off + n] = v;
+                *reinterpret_cast<float2*>(Ab + kq * AS + row * 2) = make_float2(a_reg[i].x, a_reg[i].y);
             }
         }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch_a(tile);
+    // weights of this block column, once; k-pair rows past K are zero
+    for (int i0 = t; i0 < kpn * (BN / 2); i0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + 256 * u;
+            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
+            const int n = n0 + c4 * 2;
+            const bool ok = idx < kpn * (BN / 2) && kp < kp_total && n < a.Npad;
+            v[u] = vmask(*reinterpret_cast<const float4*>(a.Wp + ((size_t)(ok ? kp : 0) * a.Npad + (ok ? n : 0)) * 2), opaque_mask(ok));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + 256 * u;
+            if (idx < kpn * (BN / 2)) *reinterpret_cast<float4*>(Bs + (size_t)(idx / (BN / 2)) * BS + (idx % (BN / 2)) * 4) = v[u];
+        }
     }
+    // zero the k-pair rows of both A buffers that no tile ever writes (K % 4 == 2)
+    for (int i = t; i < 2 * (kpn - kp_total) * AS; i += 256) {
+        const int buf = i / ((kpn - kp_total) * AS), r = i - buf * (kpn - kp_total) * AS;
+        As[(size_t)buf * kpn * AS + (size_t)kp_total * AS + r] = 0.0f;
+    }
+    if (tile < ntiles) stage_a(0);
+    __syncthreads();
+
+    for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) prefetch_a(next);                 // in flight during this tile's MFMAs and stores
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        const float* Ab = As + (size_t)buf * kpn * AS + (wm * 32 + l31) * 2 + h * AS;
+        const float* Bb = Bs + (wn * NTW * 32 + l31) * 2 + h * BS;
+        float2 av = *reinterpret_cast<const float2*>(Ab);
+        float2 bv[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
+        for (int q = 0; q < nq; ++q) {
+            const int qn = q + 1 < nq ? q + 1 : q;           // fragments of step q+1 are read before the MFMAs of step q
+            const float2 av_n = *reinterpret_cast<const float2*>(Ab + 2 * qn * AS);
+            float2 bv_n[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * qn * BS + nt * 64);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            av = av_n;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bv[nt] = bv_n[nt];
+        }
+        gemm_epilogue<NTW>(a, acc, tile * BM + wm * 32, n0 + wn * NTW * 32, vecO, lane);
+        if (next < ntiles) stage_a(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+static size_t gemm_persist_lds(int K, int NTW)
+{
+    const int kpn = 2 * ((K + 3) >> 2);
+    return ((size_t)kpn * (64 * NTW * 2) + 2 * (size_t)kpn * (64 * 2 + 2)) * sizeof(float);
+}
+
+// false when the shape is not covered (K > 128, odd K, or unaligned thin rows wider than 64)
+static bool launch_pw_persist(const GemmArgs& a, int NTW, hipStream_t s)
+{
+    const bool vecA = ((a.K | a.in_ld | a.in_off) & 3) == 0;
+    if ((a.K & 1) || a.K > 128 || (!vecA && a.K > 64) || a.K < 2) return false;
+    const size_t lds = gemm_persist_lds(a.K, NTW);
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int BN = 64 * NTW;
+    const int gy = (a.Npad + BN - 1) / BN;
+    const int ntiles = (a.M + 63) / 64;
+    int bpc = (int)((160 * 1024) / lds);                     // blocks that fit a CU
+    if (bpc > 4) bpc = 4;
+    if (bpc < 1) bpc = 1;
+    int gx = (256 * bpc) / gy;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    g_last_kernel = NTW == 1 ? "gemm_persist_kernel<1>" : "gemm_persist_kernel<2>";
+    if (NTW == 1) hipLaunchKernelGGL(gemm_persist_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(gemm_persist_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a);
+    return true;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -910,7 +1075,8 @@ static const char* const g_pw_names[] = {
 };
 constexpr int N_PW_CFGS = (int)(sizeof(g_pw_cfgs) / sizeof(g_pw_cfgs[0]));
 
-int pw_config_count() { return N_PW_CFGS; }
+// tile configurations of gemm_conv_kernel, then the two persistent variants (gemm_persist_kernel<1>, <2>)
+int pw_config_count() { return N_PW_CFGS + 2; }
 
 static int find_pw_cfg(int wm, int wn, int nt, int kp, int nb)
 {
@@ -955,6 +1121,7 @@ static int choose_pw_cfg(int M, int K, int Npad)
 void launch_pw(const GemmArgs& a, hipStream_t s)
 {
     int idx = a.cfg;
+    if (idx >= N_PW_CFGS && idx < N_PW_CFGS + 2 && launch_pw_persist(a, idx - N_PW_CFGS + 1, s)) return;
     if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
     const TileCfg& c = g_pw_cfgs[idx];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;

@@ -353,6 +353,8 @@ const Layer& L(yn_handle* h, const std::string& name) { return h->layers[h->by_n
 // handle's stream (all configurations are bit-identical, so this only affects speed).  Never runs during capture.
 int tune_pw(yn_handle* h, GemmArgs a)
 {
+    static const int forced = getenv("YN_PW_FORCE_CFG") ? atoi(getenv("YN_PW_FORCE_CFG")) : -1;     // debugging / A-B runs
+    if (forced >= 0) return forced;
     const std::vector<int> key = {a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
     auto it = h->pw_tuned.find(key);
     if (it != h->pw_tuned.end()) return it->second;
