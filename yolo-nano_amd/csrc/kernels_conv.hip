@@ -1365,7 +1365,10 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
 {
     constexpr int PR = 8, PC = 7, CR = 2 * PR + 1, CC = 2 * PC + 1;     // pooled tile, conv tile
     __shared__ __attribute__((aligned(16))) float ws[28 * COUT];
-    __shared__ __attribute__((aligned(16))) float ct[CR * CC * COUT];
+    // one LDS region, two lives: first every thread's private 27 input values (stride 27: conflict-free), then — after a
+    // barrier — the conv tile the pooling reads
+    constexpr int CT = CR * CC * COUT > 256 * 27 ? CR * CC * COUT : 256 * 27;
+    __shared__ __attribute__((aligned(16))) float ct[CT];
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
     for (int i = threadIdx.x; i < COUT; i += 256) ws[27 * COUT + i] = bias[i];
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;               // conv output extent
@@ -1373,44 +1376,60 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     const int tiles_x = (Wp + PC - 1) / PC, tiles_y = (Hp + PR - 1) / PR;
     const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
     const int py0 = (tile / tiles_x) * PR, px0 = (tile % tiles_x) * PC;
-    __syncthreads();
     const int t = threadIdx.x;
-    if (t < CR * CC) {
-        const int r = t / CC, c = t - r * CC;
-        const int cy = 2 * py0 - 1 + r, cx = 2 * px0 - 1 + c;           // conv pixel of this thread
-        float acc[COUT];
-        if (cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
+    const int r = t / CC, c = t - r * CC;
+    const int cy = 2 * py0 - 1 + r, cx = 2 * px0 - 1 + c;               // conv pixel of this thread
+    const bool live = t < CR * CC && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+    {
+        // all 27 input values of the thread's conv pixel in ONE batch of unconditional (clamped, masked) loads
+        float in[27];
+        const int cyc = live ? cy : 0, cxc = live ? cx : 0;
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = ws[27 * COUT + co];
+        for (int q = 0; q < 9; ++q) {
+            const int ci = q / 3, ky = q - ci * 3;
+            const float* xp = x + ((size_t)b * 3 + ci) * H * W;
+            const int iy = cyc * 2 - 1 + ky;
+            const bool rowok = live && iy >= 0 && iy < H;
+            const float* xr = xp + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ix = cxc * 2 - 1 + k;
+                const unsigned mk = opaque_mask(rowok && ix >= 0 && ix < W);
+                in[q * 3 + k] = __uint_as_float(__float_as_uint(xr[ix < 0 ? 0 : (ix >= W ? W - 1 : ix)]) & mk);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 27; ++i) ct[t * 27 + i] = in[i];
+    }
+    __syncthreads();                                          // ws complete (the private input slots need no barrier)
+    float acc[COUT];
+    if (live) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = ws[27 * COUT + co];
 #pragma unroll 1
-            for (int q = 0; q < 9; ++q) {
-                const int ci = q / 3, ky = q - ci * 3;
-                const float* xp = x + ((size_t)b * 3 + ci) * H * W;
-                const int iy = cy * 2 - 1 + ky;
-                const bool rowok = iy >= 0 && iy < H;
-                float in[3];
+        for (int q = 0; q < 9; ++q) {
+            float in[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int ix = cx * 2 - 1 + k;
-                    in[k] = (rowok && ix >= 0 && ix < W) ? xp[(size_t)iy * W + ix] : 0.0f;
-                }
+            for (int k = 0; k < 3; ++k) in[k] = ct[t * 27 + q * 3 + k];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4* wr = reinterpret_cast<const float4*>(ws + (q * 3 + kx) * COUT);
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4* wr = reinterpret_cast<const float4*>(ws + (q * 3 + kx) * COUT);
 #pragma unroll
-                    for (int c4 = 0; c4 < COUT / 4; ++c4) {
-                        const float4 wv = wr[c4];
-                        acc[c4 * 4 + 0] += in[kx] * wv.x; acc[c4 * 4 + 1] += in[kx] * wv.y;
-                        acc[c4 * 4 + 2] += in[kx] * wv.z; acc[c4 * 4 + 3] += in[kx] * wv.w;
-                    }
+                for (int c4 = 0; c4 < COUT / 4; ++c4) {
+                    const float4 wv = wr[c4];
+                    acc[c4 * 4 + 0] += in[kx] * wv.x; acc[c4 * 4 + 1] += in[kx] * wv.y;
+                    acc[c4 * 4 + 2] += in[kx] * wv.z; acc[c4 * 4 + 3] += in[kx] * wv.w;
                 }
             }
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = apply_act(acc[co], act);
-        } else {
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = -INFINITY;          // max-pool padding
         }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = apply_act(acc[co], act);
+    } else {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = -INFINITY;              // max-pool padding
+    }
+    __syncthreads();                                          // every thread is done with its input slot
+    if (t < CR * CC) {
 #pragma unroll
         for (int co = 0; co < COUT; co += 4)
             *reinterpret_cast<float4*>(ct + t * COUT + co) = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
