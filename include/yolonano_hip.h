@@ -103,6 +103,12 @@ int  yn_create_grid(yn_handle* h, int input_size, float* grid_host, float* strid
 int  yn_nms(yn_handle* h, const float* dets_dev, const float* scores_dev, int n, float nms_thresh,
             int diou, int32_t* keep_dev, int32_t* count_dev);
 
+/* Per-class NMS over an arbitrary detection list — the merge step of TestTimeAugmentation (utils/misc.py:132-146, nms of
+ * utils/misc.py:8-37 = the arithmetic of YOLONano.nms): boxes [n,4], scores [n], cls [n] (0 <= cls < num_classes) ->
+ * kept detections in ascending input order, count[0] = K.  Output buffers have capacity n. */
+int  yn_nms_merge(yn_handle* h, const float* boxes_dev, const float* scores_dev, const int32_t* cls_dev, int n, int num_classes,
+                  float nms_thresh, int diou, float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count_dev);
+
 /* YOLONano.postprocess :245-279, batched: all_local [B,N,4], all_conf [B,N,C] ->
  * per image b: count[b] = K_b and, in ascending candidate order, out_boxes[b,0:K_b,4],
  * out_scores[b,0:K_b], out_cls[b,0:K_b], out_index[b,0:K_b] (candidate index; may be NULL).
@@ -138,6 +144,11 @@ int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16
  * gradient sum:  g = grads*grad_scale + wd*p ; buf = first_step ? g : momentum*buf + g ; p -= lr*buf. */
 int  yn_sgd_step(yn_handle* h, float* params_dev, const float* grads_dev, float* momentum_buf_dev, int64_t n,
                  float lr, float momentum, float weight_decay, float grad_scale, int first_step);
+
+/* ---- ModelEMA.update (utils/misc.py:76-86): ema[i] = ema[i] * d + (1 - d) * model[i] over one float32 tensor (or one flat
+ * buffer), d = decay * (1 - exp(-updates / 2000)) computed by the caller in double like the reference; the kernel keeps
+ * torch's rounding sequence, so the result is bit-identical to the reference's in-place update. */
+int  yn_ema_update(yn_handle* h, float* ema_dev, const float* model_dev, int64_t n, double decay);
 
 /* ---- training labels: tools.multi_gt_creator (tools.py:97-216, call site train.py:212) --------------------------------
  * labels_dev float64 [total][5] = xmin, ymin, xmax, ymax (fractions of the image), class — the objects of image b are rows

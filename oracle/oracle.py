@@ -272,3 +272,24 @@ def infer(net, x, S, anchors, conf_thresh=0.001, nms_thresh=0.5, image=0):
     heads = net.forward_raw(x)
     bbox, cls = score_decode([h[image] for h in heads], S, net.C, anchors, net.A)
     return postprocess(bbox, cls, conf_thresh, nms_thresh)
+
+
+def tta_merge(per_forward, num_classes, nms_thresh=0.4):
+    """utils/misc.py:112-148: per_forward = [(boxes, scores, labels), ...] in the reference's call order (scale 0, scale 0
+    flipped, scale 1, ...); odd entries are mirrored back (:126), everything is concatenated and every class goes through
+    nms (utils/misc.py:8-37 — the arithmetic of YOLONano.nms).  -> kept (boxes, scores, labels) in concatenation order."""
+    bb, sc, lb = [], [], []
+    for i, (b, s, l) in enumerate(per_forward):
+        b = np.array(b, dtype=np.float32, copy=True)
+        if i & 1:
+            b[:, 0::2] = 1.0 - b[:, 2::-2]
+        bb.append(b); sc.append(np.asarray(s, dtype=np.float32)); lb.append(np.asarray(l, dtype=np.int64))
+    bb, sc, lb = np.concatenate(bb), np.concatenate(sc), np.concatenate(lb)
+    keep = np.zeros(len(bb), dtype=np.int64)
+    for c in range(num_classes):
+        inds = np.where(lb == c)[0]
+        if len(inds) == 0:
+            continue
+        keep[inds[nms(bb[inds], sc[inds], nms_thresh)]] = 1
+    k = np.where(keep > 0)[0]
+    return bb[k], sc[k], lb[k], k

@@ -73,3 +73,10 @@ def labels_from_flat(flat, B):
     for row in np.asarray(flat, dtype=np.float64).reshape(-1, 6):
         out[int(row[0])].append([float(v) for v in row[1:]])
     return out
+
+
+def ema_update(ema, model, updates, decay=0.9999):
+    """utils/misc.py:76-86 on one array, float32 arithmetic with torch's rounding sequence: v*d, (1-d)*m, sum."""
+    d = decay * (1 - math.exp(-updates / 2000.))
+    df, omd = np.float32(d), np.float32(1.0 - d)
+    return (ema.astype(np.float32) * df + omd * model.astype(np.float32)).astype(np.float32)

@@ -507,8 +507,57 @@ def gen_targets():
     save("targets.npz", **out)
 
 
+def gen_tta():
+    """utils/misc.TestTimeAugmentation on the reference model (1.0x, VOC head, 3 scales x flip): the per-forward detections
+    it concatenates and the merged result."""
+    S, C = 160, 20
+    m = ref_model(S, C, arch.MULTI_ANCHOR_SIZE, conf=0.05, nms=0.5).eval()
+    x = torch.from_numpy(weights.make_input(1, S, seed=4))
+    per = []
+    orig_forward = m.forward
+
+    def rec(xx, target=None):
+        out = orig_forward(xx)
+        per.append(out)
+        return out
+    m.forward = rec
+    tta = ref_misc.TestTimeAugmentation(num_classes=C, nms_thresh=0.4, scale_range=[128, 192, 32])
+    with torch.no_grad():
+        bb, sc, lb = tta(x, m)
+    out = {"S": np.int64(S), "C": np.int64(C), "n_forwards": np.int64(len(per)), "boxes": bb, "scores": sc, "labels": lb.astype(np.int64)}
+    for i, (b_, s_, l_) in enumerate(per):
+        out["f%d_boxes" % i], out["f%d_scores" % i], out["f%d_labels" % i] = b_, s_, l_.astype(np.int64)
+    print("tta forwards:", [len(p[0]) for p in per], "merged:", len(bb))
+    save("tta.npz", **out)
+
+
+def gen_ema():
+    """utils/misc.ModelEMA on a small module: three updates with fresh model weights each time -> the EMA state."""
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    ema = ref_misc.ModelEMA(m, decay=0.9999, updates=0)
+    out = {"init:" + k: t2n(v).copy() for k, v in m.state_dict().items()}
+    rs = np.random.RandomState(8)
+    for step in range(3):
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v.copy_(torch.from_numpy(rs.standard_normal(tuple(v.shape)).astype(np.float32)))
+                    out["model%d:%s" % (step, k)] = t2n(v).copy()
+        ema.update(m)
+    for k, v in ema.ema.state_dict().items():
+        out["ema:" + k] = t2n(v).copy()
+    out["updates"] = np.int64(ema.updates)
+    # a later update count: the decay ramps up
+    ema.updates = 5000
+    ema.update(m)
+    for k, v in ema.ema.state_dict().items():
+        out["ema_late:" + k] = t2n(v).copy()
+    save("ema.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x", "train", "targets"]
+    which = sys.argv[1:] or ["keys", "ops", "blocks", "backbone", "fold", "net", "grid_decode", "nms", "loss", "05x", "train", "targets", "ema", "tta"]
     for w in which:
         print("==", w)
         globals()["gen_" + w]()

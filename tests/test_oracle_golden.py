@@ -250,3 +250,29 @@ def test_label_assigner_oracle_matches_reference(golden):
         assert got.shape == ref.shape == (B, arch.num_predictions(S), 11)
         np.testing.assert_array_equal(got, ref)
         assert (ref[..., 0] < 0).any() and (ref[..., 0] > 0).any()      # the fixture does exercise the ignore branch
+
+
+def test_ema_oracle_matches_reference(golden):
+    """utils/misc.ModelEMA.update — the numpy restatement is bit-exact on the reference's recorded run."""
+    from oracle import targets as otg
+    g = golden("ema.npz")
+    keys = [k[5:] for k in g if k.startswith("init:")]
+    for k in keys:
+        if not np.issubdtype(g["init:" + k].dtype, np.floating):
+            continue
+        v = g["init:" + k]
+        for step in range(3):
+            v = otg.ema_update(v, g["model%d:%s" % (step, k)], step + 1)
+        np.testing.assert_array_equal(v, g["ema:" + k])
+        np.testing.assert_array_equal(otg.ema_update(v, g["model2:" + k], 5001), g["ema_late:" + k])
+
+
+def test_tta_merge_oracle_matches_reference(golden):
+    """utils/misc.TestTimeAugmentation — flip-back, concatenation and per-class NMS of the reference's
+    own six forwards reproduce its merged detections exactly."""
+    g = golden("tta.npz")
+    per = [(g["f%d_boxes" % i], g["f%d_scores" % i], g["f%d_labels" % i]) for i in range(int(g["n_forwards"]))]
+    bb, sc, lb, _ = orc.tta_merge(per, int(g["C"]), 0.4)
+    np.testing.assert_array_equal(bb, g["boxes"])
+    np.testing.assert_array_equal(sc, g["scores"])
+    np.testing.assert_array_equal(lb, g["labels"])

@@ -60,6 +60,8 @@ SIGNATURES = {
     "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "yn_nms_merge": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_ema_update": (_i32, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -312,6 +314,25 @@ class Handle:
         assert params.is_contiguous() and grads.is_contiguous() and momentum_buf.is_contiguous() and params.numel() == grads.numel() == momentum_buf.numel()
         self._ck(self.lib.yn_sgd_step(self.h, params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), params.numel(),
                                       float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step))), "yn_sgd_step")
+
+    def nms_merge(self, boxes, scores, cls, num_classes, nms_thresh, diou=False):
+        """Per-class NMS over a detection list (TTA merge, utils/misc.py:132-146) -> (boxes [K,4], scores [K], cls [K], index [K])."""
+        n = int(boxes.shape[0])
+        boxes = boxes.contiguous().float(); scores = scores.contiguous().float(); cls = cls.contiguous().to(torch.int32)
+        ob = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)
+        osc = torch.empty((max(n, 1),), dtype=torch.float32, device=self.device)
+        oc = torch.empty((max(n, 1),), dtype=torch.int32, device=self.device)
+        oi = torch.empty((max(n, 1),), dtype=torch.int32, device=self.device)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._ck(self.lib.yn_nms_merge(self.h, boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), n, int(num_classes), float(nms_thresh),
+                                       int(bool(diou)), ob.data_ptr(), osc.data_ptr(), oc.data_ptr(), oi.data_ptr(), cnt.data_ptr()), "yn_nms_merge")
+        k = int(cnt.item())
+        return ob[:k], osc[:k], oc[:k], oi[:k]
+
+    def ema_update(self, ema, model, decay):
+        """ema = ema * d + (1 - d) * model, in place (utils/misc.py:83-86); float32 tensors of equal size on this device."""
+        assert ema.is_contiguous() and model.is_contiguous() and ema.numel() == model.numel() and ema.dtype == model.dtype == torch.float32
+        self._ck(self.lib.yn_ema_update(self.h, ema.data_ptr(), model.data_ptr(), ema.numel(), float(decay)), "yn_ema_update")
 
     # ---- training labels
     def make_targets(self, label_lists, anchor_size, out=None):

@@ -282,6 +282,22 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// ModelEMA.update (utils/misc.py:76-86): v = v * d + (1 - d) * m, with torch's rounding sequence (three separately rounded
+// float32 operations, d and 1-d rounded to float32 first) so that the result is bit-identical to the reference's.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ v, const float* __restrict__ m, long n, float d, float omd)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        v[i] = __fadd_rn(__fmul_rn(v[i], d), __fmul_rn(omd, m[i]));
+}
+
+void launch_ema(float* v, const float* m, long n, float d, float omd, hipStream_t s)
+{
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, s, v, m, n, d, omd);
+}
+
 void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s)
 {
     long blocks = ((n >> 2) + 255) / 256;

@@ -939,6 +939,18 @@ int yn_postprocess(yn_handle* h, const float* all_local, const float* all_conf, 
     return 0;
 }
 
+int yn_nms_merge(yn_handle* h, const float* boxes, const float* scores, const int32_t* cls, int n, int num_classes, float nms_thresh, int diou,
+                 float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count)
+{
+    if (!h) return 1;
+    if (n < 0 || num_classes <= 0 || !count) return fail(h, "yn_nms_merge: bad arguments");
+    if (n == 0) { HIPCHK(h, hipMemsetAsync(count, 0, sizeof(int32_t), h->stream)); return 0; }
+    if (ensure_post(h, 1, n, num_classes)) return 1;
+    launch_nms_pipeline(boxes, scores, cls, 1, n, num_classes, nms_thresh, diou, h->nms, out_boxes, out_scores, out_cls, out_index, count, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* out_scores, int32_t* out_cls,
              int32_t* out_index, int32_t* count)
 {
@@ -1019,6 +1031,16 @@ int yn_make_targets(yn_handle* h, const double* labels_dev, const int32_t* offse
     if (h->grid.A != 3) return fail(h, "yn_make_targets: the label assigner is defined for 3 anchors per scale (got %d)", h->grid.A);
     HIPCHK(h, hipMemsetAsync(target_dev, 0, (size_t)B * h->grid.N * 11 * sizeof(float), h->stream));
     launch_make_targets(labels_dev, offsets_dev, B, anchors_host, h->grid, target_dev, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_ema_update(yn_handle* h, float* ema_dev, const float* model_dev, int64_t n, double decay)
+{
+    if (!h) return 1;
+    if (n < 0 || (n > 0 && (!ema_dev || !model_dev))) return fail(h, "yn_ema_update: bad arguments");
+    if (n == 0) return 0;
+    launch_ema(ema_dev, model_dev, (long)n, (float)decay, (float)(1.0 - decay), h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

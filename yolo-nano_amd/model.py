@@ -390,6 +390,110 @@ class YOLONano(nn.Module):
         return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
 
 
+class ModelEMA(object):
+    """utils/misc.py:67-86 with the same constructor / attributes (`ema`, `updates`, `decay`) and `update(model)`; the
+    in-place lerp of every floating-point state-dict entry runs as yn_ema_update — ONE launch over the flat parameter
+    buffer when model and EMA copy are both bound to their training buffers, one launch per tensor otherwise."""
+
+    def __init__(self, model, decay=0.9999, updates=0):
+        import copy
+        import math
+        m = model.module if hasattr(model, "module") else model
+        self.ema = copy.deepcopy(m).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000.))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        # deepcopy gives every parameter its own storage: move the copy's parameters into one flat buffer (named_parameters
+        # order, the layout of the model's training buffers) so that update() is a single launch
+        ps = list(self.ema.parameters())
+        if ps and all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+            flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p in ps:
+                flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+
+    @staticmethod
+    def _flat_of(module):
+        """The single contiguous buffer all parameters are views of (after YOLONano._train_handle / deepcopy of it), else None."""
+        ps = list(module.parameters())
+        if not ps or any(not p.is_cuda for p in ps):
+            return None
+        st = ps[0].data.untyped_storage()
+        off = ps[0].data.storage_offset()
+        base = off
+        for p in ps:
+            if p.data.untyped_storage().data_ptr() != st.data_ptr() or p.data.storage_offset() != off or not p.data.is_contiguous():
+                return None
+            off += p.numel()
+        return torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(st, base, (off - base,))
+
+    def update(self, model):
+        m = model.module if hasattr(model, "module") else model
+        with torch.no_grad():
+            self.updates += 1
+            d = self.decay(self.updates)
+            h = m.handle() if getattr(m, "_handle", None) is None else m._handle
+            msd, esd = m.state_dict(), self.ema.state_dict()
+            fm, fe = self._flat_of(m), self._flat_of(self.ema)
+            done = set()
+            if fm is not None and fe is not None and fm.numel() == fe.numel():
+                h.ema_update(fe, fm, d)
+                done = {k for k, _ in m.named_parameters()}
+            for k, v in esd.items():
+                if k in done or not v.dtype.is_floating_point:
+                    continue
+                src = msd[k].detach()
+                if v.is_contiguous() and src.is_contiguous() and v.dtype == torch.float32 and v.is_cuda:
+                    h.ema_update(v, src, d)
+                else:
+                    v *= d
+                    v += (1. - d) * src
+            self.ema._sig = None                               # the EMA copy's folded weights are stale now
+
+
+class TestTimeAugmentation(object):
+    """utils/misc.py:90-148: multi-scale (scale_range) x horizontal flip forwards of image 0, merged by per-class NMS.
+    Same constructor and call signature; the forwards run through the model's handle, the merge through yn_nms_merge."""
+    __test__ = False                                           # not a pytest class
+
+    def __init__(self, num_classes=80, nms_thresh=0.4, scale_range=[320, 640, 32]):
+        self.num_classes = num_classes
+        self.nms_thresh = nms_thresh
+        self.scales = np.arange(scale_range[0], scale_range[1] + 1, scale_range[2])
+
+    def __call__(self, x, model):
+        bboxes_list, scores_list, labels_list = [], [], []
+        size0 = model.input_size
+        for s in self.scales:
+            s = int(s)
+            if x.size(-1) == s and x.size(-2) == s:
+                x_scale = x
+            else:
+                x_scale = torch.nn.functional.interpolate(input=x, size=(s, s), mode='bilinear', align_corners=False)
+            model.set_grid(s)
+            bboxes, scores, labels = model(x_scale)
+            bboxes_list.append(bboxes); scores_list.append(scores); labels_list.append(labels)
+            bboxes, scores, labels = model(torch.flip(x_scale, [-1]))
+            bboxes = bboxes.copy()
+            bboxes[:, 0::2] = 1.0 - bboxes[:, 2::-2]           # utils/misc.py:126
+            bboxes_list.append(bboxes); scores_list.append(scores); labels_list.append(labels)
+        if size0 is not None:
+            model.set_grid(size0)
+        bboxes = np.concatenate(bboxes_list)
+        scores = np.concatenate(scores_list)
+        labels = np.concatenate(labels_list)
+        if len(bboxes) == 0:
+            return bboxes, scores, labels
+        h = model.handle()
+        dev = h.device
+        ob, osc, oc, _ = h.nms_merge(torch.as_tensor(bboxes).to(dev), torch.as_tensor(scores).to(dev),
+                                     torch.as_tensor(labels.astype(np.int32)).to(dev), self.num_classes, self.nms_thresh)
+        return ob.cpu().numpy().copy(), osc.cpu().numpy().copy(), oc.cpu().numpy().astype(np.int64)
+
+
 _target_handles = {}
 
 
