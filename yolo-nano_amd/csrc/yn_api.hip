@@ -96,6 +96,7 @@ struct yn_handle {
     std::map<std::string, size_t> toff;
     std::vector<TrainPack> tpacks;
     float* zeros = nullptr;
+    std::vector<hipEvent_t> train_events;
     char* train_arena = nullptr;
     size_t train_arena_bytes = 0;
     // graphs / profiling
@@ -695,6 +696,7 @@ void yn_destroy(yn_handle* h)
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->zeros) (void)hipFree(h->zeros);
+    for (hipEvent_t e : h->train_events) (void)hipEventDestroy(e);
     if (h->train_arena) (void)hipFree(h->train_arena);
     delete h;
 }
