@@ -629,43 +629,52 @@ void launch_grad_combine(float* g, const float* slots, long n, size_t stride, hi
 
 // ---- depthwise 3x3 stride-2 input gradient: dX[iy][ix][c] = sum_{ky,kx} dY[(iy+1-ky)/2][(ix+1-kx)/2][c] * w[ky][kx][c]
 //      over the taps for which the division is exact and the output pixel exists.  w packed [9][C].  accumulate: dX += .
+//      Along each axis an input coordinate i is touched by output o0 = (i+1)>>1 through tap k0 = i+1-2*o0 (0 or 1) and, when
+//      k0 == 0, also by o0-1 through tap 2: at most 2 x 2 contributions, fetched with unconditional clamped loads.
+//      thread = (input pixel, channel pair).
 __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, int B, int H, int W, int C,
                                                            float* __restrict__ dx, int dx_ld, int dx_off, int accumulate)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * H * W * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const long p = i / C;
-        const int ix = (int)(p % W);
-        const long q = p / W;
-        const int iy = (int)(q % H), b = (int)(q / H);
-        float acc = 0.0f;
+    const int cpn = C >> 1;
+    const int total = B * H * W * cpn;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cp = i % cpn;
+    int p = i / cpn;
+    const int ix = p % W; int q = p / W;
+    const int iy = q % H, b = q / H;
+    const int c = cp * 2;
+    int oy[2], ky[2], ox[2], kx[2];
+    bool vy[2], vx[2];
+    oy[0] = (iy + 1) >> 1; ky[0] = iy + 1 - 2 * oy[0]; vy[0] = oy[0] < Ho;
+    oy[1] = oy[0] - 1;     ky[1] = 2;                  vy[1] = ky[0] == 0 && oy[1] >= 0;
+    ox[0] = (ix + 1) >> 1; kx[0] = ix + 1 - 2 * ox[0]; vx[0] = ox[0] < Wo;
+    ox[1] = ox[0] - 1;     kx[1] = 2;                  vx[1] = kx[0] == 0 && ox[1] >= 0;
+    float2 g[4], wv[4];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ty = iy + 1 - ky;
-            if (ty < 0 || (ty & 1)) continue;
-            const int oy = ty >> 1;
-            if (oy >= Ho) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tx = ix + 1 - kx;
-                if (tx < 0 || (tx & 1)) continue;
-                const int ox = tx >> 1;
-                if (ox >= Wo) continue;
-                acc += dy[((size_t)(b * Ho + oy) * Wo + ox) * C + c] * w[(ky * 3 + kx) * C + c];
-            }
-        }
-        float* d = dx + (size_t)p * dx_ld + dx_off + c;
-        *d = accumulate ? *d + acc : acc;
+    for (int u = 0; u < 4; ++u) {
+        const int a = u >> 1, e = u & 1;
+        const bool ok = vy[a] && vx[e];
+        const int oyc = vy[a] ? oy[a] : 0, oxc = vx[e] ? ox[e] : 0;
+        const float2 v = *reinterpret_cast<const float2*>(dy + ((size_t)(b * Ho + oyc) * Wo + oxc) * C + c);
+        unsigned mk = ok ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(mk));
+        g[u] = make_float2(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk));
+        wv[u] = *reinterpret_cast<const float2*>(w + (ky[a] * 3 + kx[e]) * C + c);
     }
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += g[u].x * wv[u].x; acc.y += g[u].y * wv[u].y; }
+    float2* d = reinterpret_cast<float2*>(dx + (size_t)p * dx_ld + dx_off + c);
+    if (accumulate) { const float2 o = *d; acc.x += o.x; acc.y += o.y; }
+    *d = acc;
 }
 
 void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s)
 {
-    long blocks = ((long)B * H * W * C + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(dw_dgrad_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, w, B, H, W, C, dx, dx_ld, dx_off, accumulate);
+    const long total = (long)B * H * W * (C >> 1);
+    hipLaunchKernelGGL(dw_dgrad_s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, w, B, H, W, C, dx, dx_ld, dx_off, accumulate);
 }
 
 // ---- stem weight gradient: dW[co][ci][ky][kx] += sum_p dY[p][co] * x_nchw[b][ci][2oy-1+ky][2ox-1+kx]
@@ -768,16 +777,40 @@ __global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restric
     }
 }
 
+// gather form (no atomics, no pre-zeroed output): an input pixel lies in at most 2 x 2 pooling windows — the same index algebra
+// as dw_dgrad_s2 — and receives the gradient of every window whose recorded arg-max is this pixel.  thread = (pixel, channel pair)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, int B, int H, int W, int C, float* __restrict__ dx)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * Ho * Wo * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const long p = i / C;
-        const int b = (int)(p / ((long)Ho * Wo));
-        atomicAdd(dx + ((size_t)b * H * W + idx[i]) * C + c, dy[i]);
+    const int cpn = C >> 1;
+    const int total = B * H * W * cpn;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cp = i % cpn;
+    int p = i / cpn;
+    const int ix = p % W; int q = p / W;
+    const int iy = q % H, b = q / H;
+    const int c = cp * 2, me = iy * W + ix;
+    int oy[2], ox[2];
+    bool vy[2], vx[2];
+    oy[0] = (iy + 1) >> 1; vy[0] = oy[0] < Ho; oy[1] = oy[0] - 1; vy[1] = (iy & 1) && oy[1] >= 0;
+    ox[0] = (ix + 1) >> 1; vx[0] = ox[0] < Wo; ox[1] = ox[0] - 1; vx[1] = (ix & 1) && ox[1] >= 0;
+    float2 g[4]; int2 id[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int a = u >> 1, e = u & 1;
+        const size_t o = ((size_t)(b * Ho + (vy[a] ? oy[a] : 0)) * Wo + (vx[e] ? ox[e] : 0)) * C + c;
+        g[u] = *reinterpret_cast<const float2*>(dy + o);
+        id[u] = *reinterpret_cast<const int2*>(idx + o);
     }
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = vy[u >> 1] && vx[u & 1];
+        acc.x += (ok && id[u].x == me) ? g[u].x : 0.0f;
+        acc.y += (ok && id[u].y == me) ? g[u].y : 0.0f;
+    }
+    *reinterpret_cast<float2*>(dx + (size_t)p * C + c) = acc;
 }
 
 void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, int32_t* idx, hipStream_t s)
@@ -789,8 +822,7 @@ void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, in
 
 void launch_maxpool_bwd(const float* dy, const int32_t* idx, int B, int H, int W, int C, float* dx, hipStream_t s)
 {
-    long blocks = ((long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    long blocks = ((long)B * H * W * (C >> 1) + 255) / 256;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, idx, B, H, W, C, dx);
 }
 
