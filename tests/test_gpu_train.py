@@ -222,3 +222,22 @@ def test_shim_runs_the_reference_training_loop(golden, optimizer):
     model.eval()
     boxes, scores, cls = model(images)
     assert boxes.shape[1] == 4 and len(scores) == len(cls) == len(boxes) and np.isfinite(boxes).all()
+
+
+def test_no_gradient_buffer_is_read_before_it_is_written(golden, monkeypatch):
+    """The step never memsets the activation gradients: every buffer is fully written by its first producer.  With the
+    whole gradient region NaN-filled first (YN_TRAIN_POISON), losses, gradients and the update must come out unchanged."""
+    g = golden("train.npz")
+    S, C, B = int(g["S"]), int(g["C"]), int(g["B"])
+    x = torch.as_tensor(weights.make_input(B, S, seed=10)).cuda()
+    t = torch.as_tensor(g["target"]).cuda()
+    h, _ = _handle(S, C, B, float(g["init_bias_value"]))
+    l0 = h.train_step(x, t, update=False).clone()
+    g0 = h.flat_grads.clone()
+    monkeypatch.setenv("YN_TRAIN_POISON", "1")
+    l1 = h.train_step(x, t, update=False)
+    assert torch.isfinite(h.flat_grads).all()
+    np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-6)
+    err = (h.flat_grads - g0).abs().max().item()
+    assert err <= 1e-3 * g0.abs().max().item()              # atomics / slice order only
+    h.close()
