@@ -102,24 +102,32 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
                                                       float* __restrict__ all_class)
 {
     const int j = threadIdx.x & 15;
-    const long total = (long)B * g.N;
+    const int total = B * g.N;
     const int HC = g.head_ld;
-    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; i < total; i += ((long)gridDim.x * 256) >> 4) {
-        const int b = (int)(i / g.N), n = (int)(i - (long)b * g.N);
+    for (int i = (int)(((long)blockIdx.x * 256 + threadIdx.x) >> 4); i < total; i += (int)(((long)gridDim.x * 256) >> 4)) {
+        const int b = i / g.N, n = i - b * g.N;
         int s, cell, a;
         cand_location(g, n, s, cell, a);                                  // candidate order of models/yolo_nano.py:308-330
         const float* head = s == 0 ? h0 : (s == 1 ? h1 : h2);
         const float* row = head + ((size_t)b * g.hw[s] + cell) * HC;
-        const float obj = sigmoid_f(row[a]);
         const float* cl = row + g.A + a * g.C;
+        // every load of the candidate is issued before any is used: objectness, this lane's class slice (clamped index,
+        // -inf through an opaque mask for the slots past C) and one of the four box values (gathered by lane 0 below)
+        const float obj_raw = row[a];
+        const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
         float v[KMAX];
-        float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int c = j + 16 * k;
-            v[k] = c < g.C ? cl[c] : -INFINITY;
-            mx = fmaxf(mx, v[k]);
+            unsigned mk = c < g.C ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(mk));
+            const unsigned bits = __float_as_uint(cl[c < g.C ? c : g.C - 1]);
+            v[k] = __uint_as_float((bits & mk) | (0xff800000u & ~mk));       // -inf
         }
+        const float obj = sigmoid_f(obj_raw);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, v[k]);
         mx = group16_max(mx);
         float sum = 0.0f;
 #pragma unroll
@@ -141,9 +149,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
             }
         }
         if (!FULL) best = group16_max_u64(best);
+        float t4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t4[k] = __shfl(tbox, (threadIdx.x & 48) + k);      // lanes 0..3 of this 16-lane group
         if (j == 0) {
             float box[4];
-            decode_one(g, s, cell, a, row + g.A * (1 + g.C) + a * 4, (float)g.S, box, true);
+            decode_one(g, s, cell, a, t4, (float)g.S, box, true);
             *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
             if (!FULL) {
                 const unsigned ub = (unsigned)(best >> 32);
