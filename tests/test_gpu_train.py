@@ -108,7 +108,7 @@ def _targets(S, C, B, seed=5):
     return target
 
 
-@pytest.mark.parametrize("backbone,S,C,B", [("1.0x", 128, 20, 2), ("0.5x", 96, 80, 3), ("1.0x", 160, 80, 4)])
+@pytest.mark.parametrize("backbone,S,C,B", [("1.0x", 128, 20, 2), ("0.5x", 96, 80, 3), ("1.0x", 160, 80, 4), ("1.0x", 224, 20, 1)])
 def test_train_step_every_gradient_vs_oracle(golden, backbone, S, C, B):
     """Every parameter gradient, the SGD update and the BN running statistics against the oracle step.
     The exact gradient is the fp64 oracle's; the fp32 oracle run of the same step measures how much fp32 round-off the
