@@ -44,7 +44,7 @@ def parse():
                     help="replay the step as a captured hipGraph instead of launching eagerly (measured 2-3 %% slower on this stack: "
                          "17.15 k vs 17.5 k images/s; the launch thread keeps up with ~75 kernels per 1.8 ms step)")
     ap.add_argument("--no-graph", action="store_true", help="(default now) launch kernels eagerly")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent inference streams per GPU (one handle + one HIP stream each); steps are dealt round-robin, "
                          "so one stream's NMS overlaps the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -723,14 +723,17 @@ static void set_sort_attr()
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
                          float nms_thresh, int diou, const NmsWork& wk,
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
-                         hipStream_t s)
+                         hipStream_t s, const NmsHook* hook)
 {
     set_sort_attr();
     const int large_cap = wk.large_cap;
+    auto mark = [&](const char* k) { if (hook && hook->fn) hook->fn(hook->ctx, k); };
+    mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
                        wk.large_list, large_cap, YN_SORT_SMALL);
     float4* sbox = reinterpret_cast<float4*>(wk.sbox);
     u64* M = reinterpret_cast<u64*>(wk.matrix);
+    mark("sort_kernel");
     hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                        N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0);
     if (N > YN_SORT_SMALL)                                  // only the (few) listed large segments get a 128 KB-LDS workgroup
@@ -742,9 +745,12 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
     if (G < 32) G = 32;
     if (G > 2048) G = 2048;
+    mark(diou ? "matrix_kernel<true>" : "matrix_kernel<false>");
     if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
     else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
+    mark("resolve_kernel");
     hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
+    mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
 

@@ -973,10 +973,17 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
             launch_decode_cand(ch, g, B, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->stream);
         }
         {
-            set_last_kernel_name("bucket_kernel+nms_kernel+compact_kernel");
-            Bracket br(h, "nms", 0.0, 4.0 * B * 12.0 * g.N);
+            // one profiling bracket per NMS kernel (the hook closes the previous one); bytes: candidate arrays read / written once
+            struct Ctx { yn_handle* h; Bracket* cur; double bytes; } ctx{h, nullptr, 4.0 * B * 12.0 * g.N / 5.0};
+            NmsHook hook{[](void* c, const char* k) {
+                Ctx* x = (Ctx*)c;
+                delete x->cur;
+                set_last_kernel_name(k);
+                x->cur = new Bracket(x->h, std::string("nms.") + k, 0.0, x->bytes);
+            }, &ctx};
             launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, g.N, g.C, h->cfg.nms_thresh, h->cfg.diou_nms, h->nms,
-                                out_boxes, out_scores, out_cls, out_index, count, h->stream);
+                                out_boxes, out_scores, out_cls, out_index, count, h->stream, h->profiling ? &hook : nullptr);
+            delete ctx.cur;
         }
         HIPCHK(h, hipGetLastError());
         return 0;

@@ -97,10 +97,12 @@ struct NmsWork {                                // per-handle scratch, sized for
     int      large_cap;
 };
 size_t nms_matrix_words_per_image(int N, int C);
+// optional per-kernel hook of launch_nms_pipeline: called with the kernel's name right before each launch (profiling brackets)
+struct NmsHook { void (*fn)(void* ctx, const char* kernel); void* ctx; };
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
                          float nms_thresh, int diou, const NmsWork& wk,
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
-                         hipStream_t s);
+                         hipStream_t s, const NmsHook* hook = nullptr);
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
                        int32_t* ids_scratch, float* sbox_scratch, void* matrix_scratch, int32_t* keep, int32_t* count, hipStream_t s);
 
