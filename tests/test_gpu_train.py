@@ -241,3 +241,39 @@ def test_no_gradient_buffer_is_read_before_it_is_written(golden, monkeypatch):
     err = (h.flat_grads - g0).abs().max().item()
     assert err <= 1e-3 * g0.abs().max().item()              # atomics / slice order only
     h.close()
+
+
+def test_full_size_directional_derivative():
+    """BASELINE configs[2] shape (1.0x, 608x608, bs=32, COCO head) through a size-independent property: moving the
+    parameters by -eps * g must lower the summed loss by eps * |g|^2 to first order (the whole backward pass checked against
+    the forward pass at full size, no oracle involved)."""
+    from yolo_nano_amd import capi
+    S, C, B = 608, 80, 32
+    sd = weights.make_state_dict("1.0x", C)
+    h = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", max_batch=B)
+    h.load_state_dict(sd)
+    h.train_bind()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x = torch.randn((B, 3, S, S), generator=gen, device="cuda")
+    rs = np.random.RandomState(3)
+    labels = []
+    for _ in range(B):
+        c = rs.uniform(0.25, 0.75, (8, 2)); wh = rs.uniform(0.05, 0.5, (8, 2))
+        box = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32).astype(np.float64)
+        labels.append(np.concatenate([box, rs.randint(0, C, (8, 1)).astype(np.float64)], 1).tolist())
+    t = h.make_targets(labels, arch.MULTI_ANCHOR_SIZE_COCO)
+    l0 = float(h.train_step(x, t, update=False).double().sum())
+    g = h.flat_grads.clone()
+    assert torch.isfinite(g).all()
+    g2 = float((g.double() ** 2).sum())
+    p0 = h.flat_params.clone()
+    ratios = []
+    for frac in (0.01, 0.02):                                   # target loss decrease, as a fraction of the loss
+        eps = frac * l0 / g2
+        h.flat_params.copy_(p0 - eps * g)
+        l1 = float(h.train_step(x, t, update=False).double().sum())
+        ratios.append((l0 - l1) / (eps * g2))
+    h.flat_params.copy_(p0)
+    assert all(0.8 < r < 1.1 for r in ratios), (l0, g2, ratios)     # second-order terms pull the ratio slightly below 1
+    assert abs(ratios[0] - 1.0) <= abs(ratios[1] - 1.0) + 0.05       # and it tends to 1 as the step shrinks
+    h.close()
