@@ -62,6 +62,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
             const int ncol = nbase + nt * 32 + l31;            // this lane's column before the transpose
             const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
             const int nq = nbase + nt * 32 + (l31 & ~3);       // first column of the quad
+            // the pass-through half of the four row groups: requested together, before the transposes (issued one by one
+            // inside the `if (m < M)` below, each load is followed by a full wait)
+            float4 pv[4];
+            if (a.pass) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = mbase + 8 * g + 4 * h + j;
+                    const bool ok = m < a.M && nq < a.N;
+                    pv[g] = *reinterpret_cast<const float4*>(a.pass + (size_t)(ok ? m : 0) * a.pass_ld + a.pass_off + (ok ? nq : 0));
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
@@ -79,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
                 const int m = mbase + 8 * g + 4 * h + j;
                 if (m < a.M && nq < a.N) {
                     if (a.pass) {
-                        const float4 p = *reinterpret_cast<const float4*>(a.pass + (size_t)m * a.pass_ld + a.pass_off + nq);
+                        const float4 p = pv[g];
                         float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
                         *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
                         *reinterpret_cast<float4*>(o + 4) = make_float4(p.z, v2, p.w, v3);
