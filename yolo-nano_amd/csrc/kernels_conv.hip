@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 
     float2 a_reg[A_PER];
     float4 b_reg[B_PER];
-    static_assert(A_PER % 2 == 0, "vec4 A path needs an even number of k-pairs per thread");
-    // 16-byte global accesses whenever the layer's channel counts / offsets are multiples of 4 floats (wave-uniform)
-    const bool vecA = (MODE == 0) && ((a.K | a.in_ld | a.in_off) & 3) == 0;
+    // 16-byte global accesses whenever the layer's channel counts / offsets are multiples of 4 floats (wave-uniform) and the
+    // thread owns an even number of k-pairs
+    const bool vecA = (MODE == 0) && (A_PER % 2 == 0) && ((a.K | a.in_ld | a.in_off) & 3) == 0;
     const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
 
     auto prefetch = [&](int c) {
@@ -1072,7 +1072,9 @@ struct TileCfg { int WM, WN, NT, KP, NBUF; };
     X(2, 2, 1, 16, 2) X(2, 2, 2, 16, 2) X(2, 2, 4, 16, 2) X(1, 4, 1, 16, 2) X(1, 4, 2, 16, 2)        \
     X(4, 1, 1, 32, 1) X(4, 1, 2, 32, 1) X(4, 1, 3, 32, 1) X(4, 1, 4, 32, 1)                          \
     X(2, 2, 1, 32, 1) X(2, 2, 2, 32, 1) X(1, 4, 1, 32, 1) X(1, 4, 2, 32, 1)                          \
-    X(2, 2, 1, 32, 2) X(2, 2, 2, 32, 2) X(1, 4, 1, 32, 2) X(4, 1, 1, 32, 2) X(4, 1, 2, 32, 2)
+    X(2, 2, 1, 32, 2) X(2, 2, 2, 32, 2) X(1, 4, 1, 32, 2) X(4, 1, 1, 32, 2) X(4, 1, 2, 32, 2)        \
+    X(1, 4, 1, 16, 1) X(2, 2, 1, 16, 1) X(4, 1, 1, 16, 1) X(1, 4, 2, 16, 1) X(4, 1, 3, 16, 1)        \
+    X(2, 2, 1, 8, 1) X(2, 2, 2, 8, 1) X(4, 1, 2, 8, 1) X(4, 1, 4, 8, 1) X(2, 2, 4, 8, 1) X(1, 4, 1, 8, 1)
 
 static const TileCfg g_pw_cfgs[] = {
 #define X(wm, wn, nt, kp, nb) {wm, wn, nt, kp, nb},
