@@ -454,3 +454,22 @@ def test_fused_shuffle_unit_kernel(golden, capi, monkeypatch):
     for i, t in enumerate(heads):
         np.testing.assert_allclose(nchw_np(t), case["head%d" % (i + 1)], atol=ATOL, rtol=0)
     h.close(); ref_h.close()
+
+
+@pytest.mark.parametrize("backbone,C", [("1.0x", 20), ("0.5x", 80)])
+def test_size_sweep_vs_torch_oracle(capi, backbone, C):
+    """Odd map sizes, partial tiles, batch 1..3, both widths: raw heads against the torch-CPU oracle at 1e-4 (the kernels pick
+    different run lengths / tile configurations / launch shapes per size)."""
+    from oracle.torch_port import TorchNet
+    sd = weights.make_state_dict(backbone, C)
+    net = TorchNet(sd, backbone, C)
+    for S, B in ((96, 3), (160, 2), (224, 1), (352, 1), (544, 2)):
+        x = weights.make_input(B, S, seed=S)
+        ref = net.forward_raw(x)
+        h = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE, backbone, max_batch=B)
+        h.load_state_dict(sd)
+        h.fold_bn()
+        got = h.forward_raw(dev(x))
+        for g, r in zip(got, ref):
+            np.testing.assert_allclose(nchw_np(g), np.asarray(r), atol=ATOL, rtol=0, err_msg="%s S=%d B=%d" % (backbone, S, B))
+        h.close()
