@@ -178,9 +178,11 @@ def main():
     rank, local_rank, world = parallel.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("YN_BENCH_ONE_GPU"):                   # test hook: all ranks on GPU 0 (use with YN_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    parallel.init("nccl", dev)                               # RCCL; used only for the barrier / max-over-ranks
+    parallel.init(os.environ.get("YN_BENCH_BACKEND", "nccl"), dev)     # RCCL; inference uses it only for the barrier / max-over-ranks
     dist = torch.distributed if world > 1 else None
     if args.train:
         train_bench(args, rank, world, dev, dist)
@@ -261,7 +263,9 @@ def main():
         if rank == 0:
             hb = torch.empty((B, h.N, 4), dtype=torch.float32).pin_memory()
             n_pc = max(5, args.steps // 10)
-            sync_all()
+            for st in streams:                         # local sync only: this block runs on rank 0 alone (no collective here)
+                st.synchronize()
+            torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(n_pc):                      # single stream, every kept row copied to pinned host memory
                 h.infer(x, out)
