@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured hipGraph instead of launching eagerly (measured 2-3 %% slower on this stack: "
                          "17.15 k vs 17.5 k images/s; the launch thread keeps up with ~75 kernels per 1.8 ms step)")
-    ap.add_argument("--no-graph", action="store_true", help="(default now) launch kernels eagerly")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly (no calibration)")
+    ap.add_argument("--launch", choices=("auto", "eager", "graph"), default="auto",
+                    help="auto (default): an untimed calibration before the warm-up times both launch modes and keeps eager unless "
+                         "hipGraph replay is >3 %% faster (i.e. the launch thread is not keeping up, e.g. contended host cores at N=8)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent inference streams per GPU (one handle + one HIP stream each); steps are dealt round-robin, "
                          "so one stream's NMS overlaps the other's convolutions")
@@ -51,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer HIP-event timings (stderr)")
+    ap.add_argument("--dump-layers", metavar="PATH", help="write the ordered launch list of one call (layer, kernel, algorithmic "
+                                                          "flops/bytes) as JSON: the join key of tools/pmc_layers.py")
     ap.add_argument("--train", action="store_true",
                     help="time the SGD training step instead (BASELINE configs[2] shape with --size 608): train-mode forward, "
                          "loss, backward, flat-bucket gradient all-reduce over RCCL when N>1, fused SGD")
@@ -195,6 +200,10 @@ def main():
     sd = weights.make_state_dict(args.backbone, args.classes)
     B, S = args.batch, args.size
     ns = max(1, args.streams if args.latency == 0 else 1)
+    mode = "graph" if args.graph else "eager" if args.no_graph else args.launch
+    if args.latency > 0 and mode == "auto":
+        mode = "eager"
+    use_graph = mode == "graph"
     streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
     handles, xs, outs, counts = [], [], [], []
     for k, st in enumerate(streams):
@@ -207,7 +216,7 @@ def main():
             xs.append(torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32))   # synthetic, resident in HBM
             outs.append(hk.alloc_outputs(B))
             counts.append(torch.empty((B,), dtype=torch.int32).pin_memory())
-            hk.use_graph(args.graph and not args.no_graph)
+            hk.use_graph(use_graph)
             handles.append(hk)
     stream, h, x, out, counts_host = streams[0], handles[0], xs[0], outs[0], counts[0]
     step_no = [0]
@@ -243,10 +252,30 @@ def main():
                                   "value": round(lat[len(lat) // 2], 4), "unit": "ms", "p99_ms": round(lat[int(len(lat) * 0.99)], 4),
                                   "min_ms": round(lat[0], 4), "n_gpus": world, "steps": args.latency, "warmup": max(args.warmup, 50),
                                   "higher_is_better": False, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-                                  "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, hipGraph replay, conf %.3g nms %.2f"
-                                                         % (args.backbone, S, S, B, args.conf, args.nms), "hipgraph": bool(args.graph and not args.no_graph)}}), flush=True)
+                                  "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, %s, conf %.3g nms %.2f"
+                                                         % (args.backbone, S, S, B, "hipGraph replay" if use_graph else "eager launches", args.conf, args.nms), "hipgraph": bool(use_graph)}}), flush=True)
             h.close()
             return
+        calib = None
+        if mode == "auto":                             # untimed: which launch mode keeps the GPU fed from THIS host thread?
+            def rate(g, n=30):
+                for hk in handles:
+                    hk.use_graph(g)
+                for _ in range(2 * ns):                # (re)capture / re-warm
+                    step()
+                for st in streams:
+                    st.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    step()
+                for st in streams:
+                    st.synchronize()
+                return n / (time.perf_counter() - t)
+            r_e, r_g = max(rate(False), rate(False)), max(rate(True), rate(True))
+            use_graph = r_g > 1.03 * r_e
+            calib = {"eager_steps_per_s": round(r_e, 1), "graph_steps_per_s": round(r_g, 1)}
+            for hk in handles:
+                hk.use_graph(use_graph)
         for _ in range(args.warmup):
             step()
         sync_all()
@@ -295,6 +324,10 @@ def main():
                 for layer, kern, ms, fl, by in recs:
                     print("%-28s %-28s %8.1f us  %7.2f GFLOP %7.1f MB  %6.1f TF/s %7.1f GB/s" % (
                         layer, kern, ms * 1e3, fl / 1e9, by / 1e6, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
+            if args.dump_layers:
+                json.dump([{"layer": layer, "kernel": kern, "flops": fl, "bytes": by,
+                            "workload": "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf)}
+                           for layer, kern, ms, fl, by in recs], open(args.dump_layers, "w"), indent=1)
             ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
             tot_ms = sum(a["ms"] for a in agg.values())
             for kern, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
@@ -310,12 +343,14 @@ def main():
                                 "share": round(a["ms"] / tot_ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
                                 "unit": unit, "frac": round(ach / peak, 4)})
             d = kernels[0]
-            traffic = None                 # HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE, KiB)
+            # HBM bytes per launch of the dominant symbol, from the committed per-LAYER PMC pass ((2*FETCH_SIZE + WRITE_SIZE) KiB,
+            # profiles/r01_pmc_layers.json, joined on the launch order of one call: the symbol a layer runs under is autotuned)
+            traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                key = d["kernel"].replace(",", ", ") if d["kernel"] not in pmc else d["kernel"]
-                if key in pmc and B == 32 and S == 416:
-                    traffic = round(pmc[key]["avg_hbm_mb_per_launch"] * 1e6)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_layers.json")))
+                if pmc["_meta"]["workload"] == "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf):
+                    per = [pmc["%d:%s" % (i, layer)]["hbm_bytes"] for i, (layer, kern, ms, fl, by) in enumerate(recs) if kern == d["kernel"]]
+                    traffic = round(sum(per) / len(per)) if per else None
             except Exception:
                 traffic = None
             roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
@@ -341,7 +376,7 @@ def main():
                 "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1])"
                                        % (args.backbone, S, S, B, args.classes),
                            "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
-                           "parallelism": "image-sharded x%d, no collective" % world, "hipgraph": bool(args.graph and not args.no_graph),
+                           "parallelism": "image-sharded x%d, no collective" % world, "hipgraph": bool(use_graph), "launch_mode": mode, "launch_calibration_rank0": calib,
                            "streams_per_gpu": ns,
                            "detections_per_step_rank0": kept},
                 "roofline": roof,

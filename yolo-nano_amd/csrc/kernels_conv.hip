@@ -152,8 +152,15 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid of (row tiles rounded up to a multiple of 8) x (column tiles), decoded XCD-aware (workgroup b runs on XCD
+    // b % 8): every XCD owns a contiguous eighth of the row tiles and runs ALL column tiles of a row tile back to back, so
+    // the A rows are fetched into one L2 once (with a 2-D grid the column tiles of a row land on different XCDs and A is
+    // fetched once per column tile: 2.2x the algorithmic bytes on the stage-3 layers in the PMC pass).
+    const unsigned gy = (unsigned)(a.Npad + BN - 1) / BN, gx8 = gridDim.x / gy;
+    const unsigned slot = blockIdx.x >> 3;
+    const int m0 = (int)((blockIdx.x & 7u) * (gx8 >> 3) + slot / gy) * BM;
+    const int n0 = (int)(slot % gy) * BN;
+    if (m0 >= a.M) return;
 
     const int Ktot = (MODE == 1) ? 9 * a.K : a.K;          // MODE 1: a.K = Cin
     const int nchunks = (Ktot + 2 * KP - 1) / (2 * KP);
@@ -674,7 +681,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int p0 = blockIdx.x * BM;
+    const int p0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;   // XCD-contiguous tile order: neighbouring tiles share their halo in ONE L2
+    if (p0 >= a.M) return;                                       // gridDim.x is rounded up to a multiple of 8
     const int n0 = blockIdx.y * BN;
     const int base = p0 - W - 1;
 
@@ -1138,7 +1146,7 @@ void launch_pw(const GemmArgs& a, hipStream_t s)
     if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
     const TileCfg& c = g_pw_cfgs[idx];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
-    dim3 grid((a.M + BM - 1) / BM, (a.Npad + BN - 1) / BN);
+    dim3 grid(xcd_grid((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN));        // decoded in the kernel (XCD-aware)
     g_last_kernel = g_pw_names[idx];
     int i = 0;
 #define X(wm, wn, nt, kp, nb)                                                                              \
@@ -1152,11 +1160,11 @@ static void launch_gemm_3x3(const GemmArgs& a, hipStream_t s)
 {
     const int nt32 = a.Npad / 32;
     if (nt32 % 3 == 0) {
-        dim3 grid((a.M + 127) / 128, a.Npad / 96);
+        dim3 grid(xcd_grid((a.M + 127) / 128) * (a.Npad / 96));
         g_last_kernel = "gemm_conv_kernel<4,1,3,1,16,2>";
         hipLaunchKernelGGL((gemm_conv_kernel<4, 1, 3, 1, 16, 2>), grid, dim3(256), 0, s, a);
     } else {
-        dim3 grid((a.M + 127) / 128, nt32);
+        dim3 grid(xcd_grid((a.M + 127) / 128) * nt32);
         g_last_kernel = "gemm_conv_kernel<4,1,1,1,16,2>";
         hipLaunchKernelGGL((gemm_conv_kernel<4, 1, 1, 1, 16, 2>), grid, dim3(256), 0, s, a);
     }
@@ -1180,10 +1188,10 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
         const int tiles = (a.M + 127) / 128;
         if (tiles * (a.Npad / 96) >= 256) {
             g_last_kernel = "conv3x3_halo_tap_kernel<3,96>";
-            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<3, 96>), dim3(tiles, a.Npad / 96), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 3), s, a);
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<3, 96>), dim3(xcd_grid(tiles), a.Npad / 96), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 3), s, a);
         } else {
             g_last_kernel = "conv3x3_halo_tap_kernel<1,96>";
-            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96>), dim3(tiles, a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1), s, a);
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96>), dim3(xcd_grid(tiles), a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1), s, a);
         }
         return;
     }
@@ -1231,7 +1239,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
     const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
     const int cv_n = a.C / VEC, segs = (Wo + R - 1) / R;
     const int total = a.B * Ho * segs * cv_n;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (i >= total) return;
     const int cv = i % cv_n;
     int q = i / cv_n;
@@ -1275,7 +1283,7 @@ void launch_dw(const DwArgs& a, hipStream_t s)
     // run length: 4 outputs per thread (8 for the 2-channel variant at stride 1) unless that leaves too few threads to fill the chip
     auto blocks_for = [&](int vec, int r) { return ((long)a.B * Ho * ((Wo + r - 1) / r) * (a.C / vec) + 255) / 256; };
 #define YN_DW(ST, V, R) { g_last_kernel = "dwconv3x3_kernel<" #ST "," #V "," #R ">"; \
-        hipLaunchKernelGGL((dwconv3x3_kernel<ST, V, R>), dim3((unsigned)blocks_for(V, R)), dim3(256), 0, s, a); return; }
+        hipLaunchKernelGGL((dwconv3x3_kernel<ST, V, R>), dim3(xcd_grid((unsigned)blocks_for(V, R))), dim3(256), 0, s, a); return; }
     if (a.stride == 1) {
         if (v4) { if (blocks_for(4, 4) >= 1024) YN_DW(1, 4, 4) else YN_DW(1, 4, 2) }
         else    { if (blocks_for(2, 8) >= 1024) YN_DW(1, 2, 8) else YN_DW(1, 2, 4) }
@@ -1387,7 +1395,9 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;               // conv output extent
     const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;             // pooled extent
     const int tiles_x = (Wp + PC - 1) / PC, tiles_y = (Hp + PR - 1) / PR;
-    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int vb = (int)xcd_block(blockIdx.x, gridDim.x);               // XCD-contiguous tile order (yn_internal.h)
+    if (vb >= tiles_x * tiles_y * B) return;                             // grid is rounded up to a multiple of 8
+    const int tile = vb % (tiles_x * tiles_y), b = vb / (tiles_x * tiles_y);
     const int py0 = (tile / tiles_x) * PR, px0 = (tile % tiles_x) * PC;
     const int t = threadIdx.x;
     const int r = t / CC, c = t - r * CC;
@@ -1471,7 +1481,7 @@ void launch_stem_pool(const float* x, int B, int H, int W, const float* w, const
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
     const int tiles = ((Wp + 6) / 7) * ((Hp + 7) / 8);
     g_last_kernel = "stem_pool_kernel<24>";
-    if (Cout == 24) hipLaunchKernelGGL(stem_pool_kernel<24>, dim3((unsigned)(tiles * B)), dim3(256), 0, s, x, B, H, W, w, bias, act, y);
+    if (Cout == 24) hipLaunchKernelGGL(stem_pool_kernel<24>, dim3(xcd_grid((unsigned)(tiles * B))), dim3(256), 0, s, x, B, H, W, w, bias, act, y);
 }
 
 // 3x3 stride-2 pad-1 max pool (implicit -inf padding), NHWC, thread = (output pixel, 4 channels).

@@ -164,4 +164,11 @@ void launch_pack_bwd(const float* w, int Cout, int Cin, int kind, int Npad, floa
 void launch_ema(float* v, const float* m, long n, float d, float one_minus_d, hipStream_t s);
 void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s);
 
+// XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so with the identity mapping the
+// three input rows of a 3x3 window are fetched by three different L2s (PMC: FETCH_SIZE = 3.3x the input for the stage-3
+// depthwise convs).  With the grid rounded up to a multiple of 8 (xcd_grid) this bijection hands every XCD one
+// CONTIGUOUS eighth of the tile range, so only the rows at the seven seams are fetched twice.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) { return (b & 7u) * (nb >> 3) + (b >> 3); }
+inline unsigned xcd_grid(unsigned blocks) { return (blocks + 7u) & ~7u; }
+
 }  // namespace ynk
