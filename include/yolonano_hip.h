@@ -63,6 +63,10 @@ int  yn_synchronize(yn_handle* h);
  * shape times every instantiated tile configuration on the handle's stream and caches the fastest.  All
  * configurations produce bit-identical results; disabling falls back to a static heuristic. */
 int  yn_autotune(yn_handle* h, int enable);
+/* Testing aid: pin every pointwise GEMM of this handle to tile configuration `index` (0 <= index < yn_pw_config_count();
+ * a configuration that does not cover a layer's strides falls back to the heuristic one); index < 0 restores the autotuner. */
+int  yn_set_pw_config(yn_handle* h, int index);
+int  yn_pw_config_count(void);
 
 /* ---- weights ------------------------------------------------------------------------------- */
 /* nn.Module.load_state_dict (eval.py:127, benchmark.py:132): one call per state-dict entry, using

@@ -115,6 +115,40 @@ def test_op_pointwise_shapes_vs_oracle(hvoc, M, cin, cout, act):
     np.testing.assert_allclose(nchw_np(y), orc.act(orc.conv2d(x, w, b), act), atol=3e-5, rtol=0)
 
 
+@pytest.mark.parametrize("M,cin,cout,act", [(127, 116, 116, 1), (1000, 232, 232, 1), (333, 24, 58, 1), (4096, 96, 255, 0),
+                                           (700, 464, 96, 2), (77, 48, 24, 1)])
+def test_op_pointwise_every_tile_configuration_bit_identical(hvoc, M, cin, cout, act):
+    """All instantiated GEMM configurations (LDS-tiled, persistent, register-direct) sum k in the same order: pinning any of
+    them must give bit-identical output (the autotuner's choice is a pure speed matter), and a shuffle unit with its
+    concat+shuffle epilogue and channel-offset input likewise."""
+    rs = np.random.RandomState(M * 3 + cin)
+    x = nhwc(rs.standard_normal((1, cin, 1, M)).astype(np.float32))
+    w = dev((rs.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))
+    b = dev(rs.standard_normal((cout,)).astype(np.float32))
+    try:
+        hvoc.set_pw_config(0)
+        ref = hvoc.op_pwconv(x, w, b, act).clone()
+        for c in range(1, hvoc.pw_config_count()):
+            hvoc.set_pw_config(c)
+            assert torch.equal(hvoc.op_pwconv(x, w, b, act), ref), "configuration %d" % c
+    finally:
+        hvoc.set_pw_config(-1)
+
+
+def test_shuffle_block_every_tile_configuration_bit_identical(golden, hvoc):
+    g = golden("blocks.npz")
+    try:
+        hvoc.set_pw_config(0)
+        r2 = hvoc.op_shuffle_block("backbone.stage2.0", nhwc(g["s2_x"]), 116, 2).clone()
+        r1 = hvoc.op_shuffle_block("backbone.stage2.1", nhwc(g["s1_x"]), 116, 1).clone()
+        for c in range(1, hvoc.pw_config_count()):
+            hvoc.set_pw_config(c)
+            assert torch.equal(hvoc.op_shuffle_block("backbone.stage2.0", nhwc(g["s2_x"]), 116, 2), r2), "configuration %d" % c
+            assert torch.equal(hvoc.op_shuffle_block("backbone.stage2.1", nhwc(g["s1_x"]), 116, 1), r1), "configuration %d" % c
+    finally:
+        hvoc.set_pw_config(-1)
+
+
 def test_shuffle_blocks(golden, hvoc):
     """ShuffleV2Block stride 2 and stride 1 incl. concat + channel_shuffle (backbone/shufflenetv2.py:69-78)."""
     g = golden("blocks.npz")

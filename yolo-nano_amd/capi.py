@@ -41,6 +41,8 @@ SIGNATURES = {
     "yn_use_graph": (_i32, [_vp, _i32]),
     "yn_synchronize": (_i32, [_vp]),
     "yn_autotune": (_i32, [_vp, _i32]),
+    "yn_set_pw_config": (_i32, [_vp, _i32]),
+    "yn_pw_config_count": (_i32, []),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -179,6 +181,13 @@ class Handle:
 
     def autotune(self, on=True):
         self._ck(self.lib.yn_autotune(self.h, int(bool(on))), "yn_autotune")
+
+    def set_pw_config(self, index):
+        """Testing aid: pin the pointwise GEMMs to one tile configuration (index < 0: back to the autotuner)."""
+        self._ck(self.lib.yn_set_pw_config(self.h, int(index)), "yn_set_pw_config")
+
+    def pw_config_count(self):
+        return int(self.lib.yn_pw_config_count())
 
     def synchronize(self):
         self._ck(self.lib.yn_synchronize(self.h), "yn_synchronize")

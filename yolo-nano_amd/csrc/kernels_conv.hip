@@ -327,6 +327,114 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
+// Register-direct pointwise GEMM: no LDS, no barriers.  A wave owns a 32 x (32*NT) output tile for the whole K and
+// feeds its MFMAs straight from global memory / L2:
+//   A: lane (row r, half h) loads the 16 bytes A[r][8g+4h .. 8g+4h+3] of k-group g; two v_permlane32_swap exchange the
+//      halves between lanes r and r+32, which leaves (x|y|z|w) = k (8g | 8g+1 | 8g+4 | 8g+5) in the low half and
+//      (8g+2 | 8g+3 | 8g+6 | 8g+7) in the high half — exactly the operand order of gemm_conv_kernel's LDS fragments, so
+//      the k-sum runs in the same order and the result is bit-identical to every tiled configuration;
+//   B: lane (column c, half h) loads the float2 Wp[kp = 4g+2h (+2)][c] of the packed weights (coalesced over c).
+// D k-groups are in flight per wave (loads for group g+D are issued when group g is consumed), so one wave hides the
+// memory latency on its own and the kernel has no block-wide synchronisation at all: the tiled kernel parks 40 % of
+// its wave-cycles in s_waitcnt/barriers on the small layers (profiles/r01_sq_counters.md).  Neighbouring waves of a
+// block re-read A (WN > 1) or B (WM > 1) through L1.  Requires K, in_ld, in_off multiples of 4 floats.
+// Measured (tools/direct_ablation.sh, stage-4 layer M=5408 K=N=232, 17.8 us): loads alone 19.8 us, MFMAs alone 14.7 us,
+// D = 8 / 15 slower than D = 4 — the row-strided A loads (32 cache lines per instruction, 32 bytes used of each) are
+// bound by L1/TA request throughput, not by latency, so this variant only edges out the LDS-tiled one (17.8 vs 19-20 us)
+// on the small stage-3/4 layers, where the autotuner picks it; it is NOT the way to a higher MFMA fraction.
+template <int WM, int WN, int NT, int D>
+__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs a)
+{
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const unsigned gy = (unsigned)(a.Npad + BN - 1) / BN, gx8 = gridDim.x / gy;     // XCD-aware decode (see gemm_conv_kernel)
+    const unsigned slot = blockIdx.x >> 3;
+    const int m0 = (int)((blockIdx.x & 7u) * (gx8 >> 3) + slot / gy) * BM;
+    const int n0 = (int)(slot % gy) * BN;
+    const int mbase = m0 + wm * 32, nbase = n0 + wn * NT * 32;
+    if (mbase >= a.M || nbase >= a.Npad) return;            // wave-uniform: no barriers below
+
+    const int mr = mbase + l31;
+    const float* ap = a.in + (size_t)(mr < a.M ? mr : a.M - 1) * a.in_ld + a.in_off + 4 * h;
+    const int ng = (a.K + 7) >> 3;
+    const float* bp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nbase + nt * 32 + l31;                // columns >= Npad (tile wider than the matrix): load column 0, never stored
+        bp[nt] = a.Wp + ((size_t)h * a.Npad + (n < a.Npad ? n : 0)) * 2;
+    }
+    const size_t bstep = (size_t)a.Npad * 2;                // floats per k-pair row of Wp
+
+    float4 av[D];
+    float2 bv[D][NT][2];
+    auto load = [&](int g, int d) {
+        // K % 8 == 4: the last group has no second k-quad.  Its loads are redirected to valid addresses (no masks: the
+        // values only reach the MFMAs of that quad, which are skipped below).
+        const int k = 8 * g;
+        av[d] = *reinterpret_cast<const float4*>(ap + (k + 4 * h < a.K ? k : k - 4 * h));
+        const size_t r0 = (size_t)(4 * g) * bstep, r1 = k + 4 < a.K ? 2 * bstep : 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bv[d][nt][0] = *reinterpret_cast<const float2*>(bp[nt] + r0);
+            bv[d][nt][1] = *reinterpret_cast<const float2*>(bp[nt] + r0 + r1);
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < ng) load(d, d);
+    for (int g0 = 0; g0 < ng; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int g = g0 + d;
+            if (g < ng) {                                    // wave-uniform
+                float4 x = av[d];
+                float2 b[NT][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { b[nt][0] = bv[d][nt][0]; b[nt][1] = bv[d][nt][1]; }
+#ifndef YN_EXP_NO_LOAD
+                if (g + D < ng) load(g + D, d);
+#endif
+                {   // (x,z) and (y,w): swap the high half of the first with the low half of the second
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(x.z), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(x.w), false, false);
+                    x = make_float4(__uint_as_float(s0[0]), __uint_as_float(s1[0]), __uint_as_float(s0[1]), __uint_as_float(s1[1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef YN_EXP_NO_MFMA
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][0] += x.x * b[nt][0].x + x.y * b[nt][0].y + x.z * b[nt][1].x + x.w * b[nt][1].y;
+#else
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, b[nt][0].x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, b[nt][0].y, acc[nt], 0, 0, 0);
+                }
+                if (8 * g + 4 < a.K) {                       // wave-uniform: the second k-quad of the group exists
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, b[nt][1].x, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, b[nt][1].y, acc[nt], 0, 0, 0);
+                    }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
+    gemm_epilogue<NT>(a, acc, mbase, nbase, vecO, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Persistent pointwise GEMM for thin K (K <= 128).  The tiled kernel above re-stages the K x BN weight slice for
 // every 32..128-row tile and runs "load -> barrier -> MFMA -> store" once per block, so a launch of a few hundred
 // blocks is mostly latency.  Here the weight slice of the block column is staged into LDS ONCE and a block walks
@@ -1096,8 +1204,41 @@ static const char* const g_pw_names[] = {
 };
 constexpr int N_PW_CFGS = (int)(sizeof(g_pw_cfgs) / sizeof(g_pw_cfgs[0]));
 
-// tile configurations of gemm_conv_kernel, then the two persistent variants (gemm_persist_kernel<1>, <2>)
-int pw_config_count() { return N_PW_CFGS + 2; }
+// register-direct configurations (gemm_direct_kernel<WM, WN, NT, D>): bit-identical to the tiled ones as well
+#define YN_PWD_CONFIGS(X)                                                                            \
+    X(4, 1, 1, 4) X(2, 2, 1, 4) X(1, 4, 1, 4) X(4, 1, 2, 4) X(2, 2, 2, 4) X(4, 1, 3, 4) X(4, 1, 4, 3) X(2, 2, 4, 3)
+struct DirectCfg { int WM, WN, NT, D; };
+static const DirectCfg g_pwd_cfgs[] = {
+#define X(wm, wn, nt, d) {wm, wn, nt, d},
+    YN_PWD_CONFIGS(X)
+#undef X
+};
+static const char* const g_pwd_names[] = {
+#define X(wm, wn, nt, d) "gemm_direct_kernel<" #wm "," #wn "," #nt "," #d ">",
+    YN_PWD_CONFIGS(X)
+#undef X
+};
+constexpr int N_PWD_CFGS = (int)(sizeof(g_pwd_cfgs) / sizeof(g_pwd_cfgs[0]));
+
+// tile configurations of gemm_conv_kernel, then the two persistent variants (gemm_persist_kernel<1>, <2>), then the
+// register-direct configurations
+int pw_config_count() { return N_PW_CFGS + 2 + N_PWD_CFGS; }
+
+// false when the layer's strides do not allow 16-byte A loads
+static bool launch_pw_direct(const GemmArgs& a, int idx, hipStream_t s)
+{
+    if (((a.K | a.in_ld | a.in_off) & 3) != 0 || a.K < 4) return false;
+    const DirectCfg& c = g_pwd_cfgs[idx];
+    const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+    dim3 grid(xcd_grid((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN));
+    g_last_kernel = g_pwd_names[idx];
+    int i = 0;
+#define X(wm, wn, nt, d)                                                                                   \
+    if (i++ == idx) { hipLaunchKernelGGL((gemm_direct_kernel<wm, wn, nt, d>), grid, dim3(256), 0, s, a); return true; }
+    YN_PWD_CONFIGS(X)
+#undef X
+    return false;
+}
 
 static int find_pw_cfg(int wm, int wn, int nt, int kp, int nb)
 {
@@ -1143,6 +1284,7 @@ void launch_pw(const GemmArgs& a, hipStream_t s)
 {
     int idx = a.cfg;
     if (idx >= N_PW_CFGS && idx < N_PW_CFGS + 2 && launch_pw_persist(a, idx - N_PW_CFGS + 1, s)) return;
+    if (idx >= N_PW_CFGS + 2 && idx < N_PW_CFGS + 2 + N_PWD_CFGS && launch_pw_direct(a, idx - N_PW_CFGS - 2, s)) return;
     if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
     const TileCfg& c = g_pw_cfgs[idx];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;

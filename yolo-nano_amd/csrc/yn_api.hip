@@ -104,6 +104,7 @@ struct yn_handle {
     bool autotune = true;
     bool fuse_dwpw = false;        // measured slower than dw + pw as two kernels (halo staging dominates thin-K layers)
     std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
+    int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
@@ -356,6 +357,7 @@ int tune_pw(yn_handle* h, GemmArgs a)
 {
     static const int forced = getenv("YN_PW_FORCE_CFG") ? atoi(getenv("YN_PW_FORCE_CFG")) : -1;     // debugging / A-B runs
     if (forced >= 0) return forced;
+    if (h->force_pw_cfg >= 0) return h->force_pw_cfg;
     const std::vector<int> key = {a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
     auto it = h->pw_tuned.find(key);
     if (it != h->pw_tuned.end()) return it->second;
@@ -744,6 +746,15 @@ int yn_autotune(yn_handle* h, int enable)
     if (!enable) h->pw_tuned.clear();
     return 0;
 }
+
+int yn_set_pw_config(yn_handle* h, int index)
+{
+    if (!h) return 1;
+    if (index >= pw_config_count()) return fail(h, "yn_set_pw_config: index %d out of range (%d configurations)", index, pw_config_count());
+    h->force_pw_cfg = index < 0 ? -1 : index;
+    return 0;
+}
+int yn_pw_config_count(void) { return pw_config_count(); }
 
 int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 
