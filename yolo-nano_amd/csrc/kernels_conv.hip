@@ -775,10 +775,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmArgs a)
 // Same algorithm, specialised for a compile-time Cin: the weight stream is chunked per TAP (Cin k-values, one
 // LDS buffer, next tap prefetched into registers) => 9 chunk boundaries instead of 9*Cin/32, and the halo is
 // staged with 16-byte global loads.
-template <int NT, int CIN>
+template <int NT, int CIN, int SPLIT>
 __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 {
-    constexpr int BM = 128, BN = 32 * NT, BS = BN * 2, KPT = CIN / 2;      // k-pairs per tap
+    constexpr int BM = 128, BN = 32 * NT, BS = BN * 2, KPT = CIN / 2 / SPLIT;   // k-pairs per weight chunk (a tap, or 1/SPLIT of one)
     constexpr int B_PER = (KPT * BN / 2 + 255) / 256;                      // float4 per thread per tap
     constexpr int CS = CIN + 2, NQ = CIN / 4;
     extern __shared__ __attribute__((aligned(16))) float c3t_smem[];
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
     const int npix = BM + 2 * W + 2;
     float* halo = c3t_smem;                                  // [npix][CS]
     float* Bs = c3t_smem + ((npix * CS + 3) & ~3);           // [KPT][BS]
+    constexpr int NQ_C = KPT / 2;                            // MFMA k-steps (of 4 k) per chunk
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
                     const int q = base + i;
                     v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     u2[u] = v[u];
-                    if (i < npix && q >= 0 && q < a.M) {
+                    if (i < npix && q >= 0 && q < a.M) {     // (measured: the unconditional masked form is 10 % SLOWER here)
                         v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)q * CIN + 4 * cq);
                         if (a.resample) {
                             const int b = q / HW, rem = q - b * HW;
@@ -874,22 +875,23 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
 
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) prefetch_b(tap + 1);
+    for (int chunk = 0; chunk < 9 * SPLIT; ++chunk) {
+        if (chunk + 1 < 9 * SPLIT) prefetch_b(chunk + 1);
+        const int tap = chunk / SPLIT, part = chunk - tap * SPLIT;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const bool ok = (tapmask >> tap) & 1u;
-        const float* Ab = halo + (W + 1 + r + dy * W + dx) * CS + 2 * h;
+        const float* Ab = halo + (W + 1 + r + dy * W + dx) * CS + 2 * h + part * (CIN / SPLIT);
         const float* Bb = Bs + l31 * 2 + h * BS;
         float2 av = *reinterpret_cast<const float2*>(Ab);
         float2 bv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
 #pragma unroll 8
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < NQ_C; ++q) {
             float2 av_n = av, bv_n[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-            if (q + 1 < NQ) {
+            if (q + 1 < NQ_C) {
                 av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
@@ -906,8 +908,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
         }
-        if (tap + 1 < 9) {
-            __syncthreads();                                 // everyone is done with this tap's weights
+        if (chunk + 1 < 9 * SPLIT) {
+            __syncthreads();                                 // everyone is done with this chunk's weights
             stage_b();
             __syncthreads();
         }
@@ -941,10 +943,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
     }
 }
 
-static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT)
+static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
 {
     const int npix = 128 + 2 * W + 2;
-    return ((size_t)((npix * (Cin + 2) + 3) & ~3) + (size_t)(Cin / 2) * (32 * NT * 2)) * sizeof(float);
+    return ((size_t)((npix * (Cin + 2) + 3) & ~3) + (size_t)(Cin / 2 / split) * (32 * NT * 2)) * sizeof(float);
 }
 
 static size_t conv3x3_halo_lds(int W, int Cin, int NT)
@@ -978,7 +980,8 @@ __global__ __launch_bounds__(256) void dwpw_halo_kernel(GemmArgs a)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
-    const int p0 = blockIdx.x * BM;
+    const int p0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;   // XCD-contiguous tile order (gridDim.x is a multiple of 8)
+    if (p0 >= a.M) return;
     const int n0 = blockIdx.y * BN;
     const int base = p0 - W - 1;
     const int nchunks = (Cin + 31) >> 5;
@@ -1163,7 +1166,7 @@ bool launch_dwpw(const GemmArgs& a, hipStream_t s)
     const int wm = cands[best].wm, nt = cands[best].nt;
     const int BM = 32 * wm, BN = 32 * nt * (4 / wm);
     const size_t lds = dwpw_lds(a.W, a.K, BM, BN);
-    dim3 grid((a.M + BM - 1) / BM, (a.Npad + BN - 1) / BN);
+    dim3 grid(xcd_grid((a.M + BM - 1) / BM), (a.Npad + BN - 1) / BN);
 #define YN_DWPW_CASE(WMv, NTv)                                                                                   \
     if (wm == WMv && nt == NTv) {                                                                                \
         static bool attr = false;                                                                                \
@@ -1323,17 +1326,23 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
         conv3x3_halo_tap_lds(a.W, 96, 3) <= 160 * 1024) {
         static bool attr_t = false;
         if (!attr_t) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<3, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<3, 96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_t = true;
         }
         const int tiles = (a.M + 127) / 128;
+        static const int two_per_cu = getenv("YN_C3_SPLIT") ? atoi(getenv("YN_C3_SPLIT")) : 1;
         if (tiles * (a.Npad / 96) >= 256) {
-            g_last_kernel = "conv3x3_halo_tap_kernel<3,96>";
-            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<3, 96>), dim3(xcd_grid(tiles), a.Npad / 96), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 3), s, a);
+            g_last_kernel = "conv3x3_halo_tap_kernel<3,96,1>";
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<3, 96, 1>), dim3(xcd_grid(tiles), a.Npad / 96), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 3), s, a);
+        } else if (two_per_cu && conv3x3_halo_tap_lds(a.W, 96, 1) > 80 * 1024 && conv3x3_halo_tap_lds(a.W, 96, 1, 2) <= 80 * 1024) {
+            // half-tap weight chunks: 6 KB less LDS, which is what lets TWO blocks share a CU on the 26x26 maps (83.6 -> 77.5 KB)
+            g_last_kernel = "conv3x3_halo_tap_kernel<1,96,2>";
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96, 2>), dim3(xcd_grid(tiles), a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1, 2), s, a);
         } else {
-            g_last_kernel = "conv3x3_halo_tap_kernel<1,96>";
-            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96>), dim3(xcd_grid(tiles), a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1), s, a);
+            g_last_kernel = "conv3x3_halo_tap_kernel<1,96,1>";
+            hipLaunchKernelGGL((conv3x3_halo_tap_kernel<1, 96, 1>), dim3(xcd_grid(tiles), a.Npad / 32), dim3(256), conv3x3_halo_tap_lds(a.W, 96, 1), s, a);
         }
         return;
     }

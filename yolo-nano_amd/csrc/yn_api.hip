@@ -671,6 +671,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
+    if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
     *out = h;
