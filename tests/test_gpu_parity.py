@@ -490,6 +490,32 @@ def test_fused_shuffle_unit_kernel(golden, capi, monkeypatch):
     h.close(); ref_h.close()
 
 
+@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 20, 96, 3), ("1.0x", 80, 160, 2), ("1.0x", 20, 352, 1), ("1.0x", 80, 416, 2),
+                                             ("0.5x", 80, 224, 2), ("0.5x", 20, 96, 1)])
+def test_unit_chain_bit_identical_to_three_kernel_path(capi, backbone, C, S, B):
+    """unit_chain_kernel (one kernel per stride-1 ShuffleV2 unit: depthwise -> pw2 -> concat+shuffle -> next pw1) runs the same
+    fma chain and the same k order as the separate kernels: raw heads must be bit-identical with the chain on and off (odd map
+    sizes => partial tiles and image borders inside a tile; both widths => every instantiated tile shape)."""
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
+    h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
+    h.load_state_dict(weights.make_state_dict(backbone, C))
+    h.fold_bn()
+    x = dev(weights.make_input(B, S, seed=S + B))
+    h.unit_chain(True)
+    a = [t.clone() for t in h.forward_raw(x)]
+    h.unit_chain(False)
+    b = [t.clone() for t in h.forward_raw(x)]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    h.profile_enable(True)                                   # the chain really ran (kernel names of the profiled call)
+    h.unit_chain(True)
+    h.forward_raw(x)
+    names = [r[1] for r in h.profile_records()]
+    h.profile_enable(False)
+    assert any(n.startswith("unit_chain_kernel") for n in names) or backbone == "0.5x", names
+    h.close()
+
+
 @pytest.mark.parametrize("backbone,C", [("1.0x", 20), ("0.5x", 80)])
 def test_size_sweep_vs_torch_oracle(capi, backbone, C):
     """Odd map sizes, partial tiles, batch 1..3, both widths: raw heads against the torch-CPU oracle at 1e-4 (the kernels pick

@@ -43,6 +43,7 @@ SIGNATURES = {
     "yn_autotune": (_i32, [_vp, _i32]),
     "yn_set_pw_config": (_i32, [_vp, _i32]),
     "yn_pw_config_count": (_i32, []),
+    "yn_unit_chain": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -185,6 +186,10 @@ class Handle:
     def set_pw_config(self, index):
         """Testing aid: pin the pointwise GEMMs to one tile configuration (index < 0: back to the autotuner)."""
         self._ck(self.lib.yn_set_pw_config(self.h, int(index)), "yn_set_pw_config")
+
+    def unit_chain(self, on=True):
+        """One kernel per stride-1 ShuffleV2 unit (default) or the three-kernel path; bit-identical results."""
+        self._ck(self.lib.yn_unit_chain(self.h, int(bool(on))), "yn_unit_chain")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

@@ -105,6 +105,7 @@ struct yn_handle {
     bool fuse_dwpw = false;        // measured slower than dw + pw as two kernels (halo staging dominates thin-K layers)
     std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
+    bool unit_chain = true;                        // stride-1 ShuffleV2 units as one kernel each (yn_unit_chain / YN_UNIT_CHAIN=0)
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
@@ -437,6 +438,59 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
     run_dwpw(h, dw, pw2, t1, bf, 0, B, H, W, t2, out, C, 0, x, C, 0);
 }
 
+// Units 1..R-1 of a stage as pw1(unit 1) + one unit_chain_kernel per unit.  oA = the stride-2 block's output [M][C] (unit 1's
+// input), oB = a second [M][C] buffer (holds the two [M][bf] pass-through halves in flight), tA / tB = [M][bf] scratch.
+// Returns false (nothing launched besides a harmless pw1) when the shape has no instantiated tile; *result = final [M][C].
+bool run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
+{
+    if (!h->unit_chain || h->fuse_unit || h->fuse_dwpw) return false;
+    const int bf = C / 2;
+    const long M = (long)B * H * W;
+    char nm[96];
+    auto name = [&](int bi) { snprintf(nm, sizeof nm, "backbone.stage%d.%d", stage, bi); return std::string(nm); };
+    {
+        const Layer& pw1 = L(h, name(1) + ".b2.pw1");
+        const Layer& dw = L(h, name(1) + ".b2.dw");
+        if (pw1.cin != bf || pw1.cout != bf || dw.stride != 1) return false;
+        run_pw(h, pw1, oA, C, bf, M, tA, bf, 0, nullptr, 0, 0);
+    }
+    float* pbuf[2] = {oB, oB + (size_t)M * bf};
+    const float* x1 = oA;
+    int x1_ld = C;
+    float* final_out = R > 2 ? oA : oB;
+    for (int bi = 1; bi < R; ++bi) {
+        const std::string P = name(bi);
+        const bool last = bi == R - 1;
+        const Layer& dw = L(h, P + ".b2.dw");
+        const Layer& pw2 = L(h, P + ".b2.pw2");
+        ChainArgs a{};
+        a.t1 = tA; a.t1_ld = bf; a.t1_off = 0;
+        a.x1 = x1; a.x1_ld = x1_ld; a.x1_off = 0;
+        a.wdw = dw.w_packed; a.bdw = dw.b_packed; a.dw_act = dw.act;
+        a.Wp2 = pw2.w_packed; a.b2 = pw2.b_packed; a.act2 = pw2.act;
+        if (!last) {
+            const Layer& pw1n = L(h, name(bi + 1) + ".b2.pw1");
+            a.Wp1n = pw1n.w_packed; a.b1n = pw1n.b_packed; a.act1n = pw1n.act;
+            a.out = pbuf[(bi - 1) & 1]; a.out_ld = bf; a.t1n = tB;
+        } else {
+            a.out = final_out; a.out_ld = C;
+        }
+        a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw2.Npad; a.M = (int)M;
+        Bracket br(h, P + (last ? ".dw+pw2" : ".dw+pw2+pw1n"), 2.0 * M * bf * (9.0 + bf + (last ? 0.0 : (double)bf)),
+                   4.0 * (4.0 * M * bf + (last ? 1.0 : 2.0) * bf * bf + 10.0 * bf));
+        if (!launch_unit_chain(a, h->cur)) {
+            br.cancel();
+            if (bi == 1) return false;
+            fail(h, "unit chain: tile coverage changed inside stage %d", stage);
+            return false;
+        }
+        x1 = a.out; x1_ld = bf;
+        float* tmp = tA; tA = tB; tB = tmp;
+    }
+    *result = final_out;
+    return true;
+}
+
 void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
               float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
 {
@@ -553,12 +607,16 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
         float* o_cur = oA;
         float* o_nxt = oB;
-        for (int bi = 1; bi < STAGE_REP[si]; ++bi) {
-            snprintf(nm, sizeof nm, "backbone.stage%d.%d", si + 2, bi);
-            const std::string P = nm;
-            // stride-1 block: backbone/shufflenetv2.py:70-72 — x1 = ch [0,bf) passes through, x2 = ch [bf,C)
-            run_unit(h, P, o_cur, B, Ho, Ho, o_nxt, t1, t2);
-            float* tmp = o_cur; o_cur = o_nxt; o_nxt = tmp;
+        // stride-1 blocks (backbone/shufflenetv2.py:70-72; x1 = ch [0,bf) passes through, x2 = ch [bf,C)): one kernel per
+        // unit, cut at the depthwise conv (unit_chain_kernel), after the first unit's pw1; else three kernels per unit
+        const int R = STAGE_REP[si];
+        if (!(R > 1 && run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t1, t2, &o_cur))) {
+            for (int bi = 1; bi < R; ++bi) {
+                snprintf(nm, sizeof nm, "backbone.stage%d.%d", si + 2, bi);
+                const std::string P = nm;
+                run_unit(h, P, o_cur, B, Ho, Ho, o_nxt, t1, t2);
+                float* tmp = o_cur; o_cur = o_nxt; o_nxt = tmp;
+            }
         }
         cfeat[si] = o_cur;
         cur = o_cur; curC = C; curH = Ho;
@@ -671,6 +729,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
+    if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) != 0;    // A/B switch for the one-kernel-per-unit chain
     if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
@@ -756,6 +815,7 @@ int yn_set_pw_config(yn_handle* h, int index)
     return 0;
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
+int yn_unit_chain(yn_handle* h, int enable) { if (!h) return 1; h->unit_chain = enable != 0; return 0; }
 
 int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 

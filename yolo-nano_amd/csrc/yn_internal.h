@@ -39,6 +39,20 @@ struct UnitArgs {
 };
 bool launch_shuffle_unit(const UnitArgs& a, hipStream_t s);
 
+// One kernel per stride-1 ShuffleV2 unit, cut at the unit's depthwise conv instead of at its input (kernels_conv.hip,
+// unit_chain_kernel): depthwise 3x3 -> pw2 -> concat+shuffle -> (the NEXT unit's pw1).
+struct ChainArgs {
+    const float* t1; int t1_ld, t1_off;         // depthwise input = this unit's pw1 output, [M][bf]
+    const float* x1; int x1_ld, x1_off;         // pass-through half of the unit's input, [M][bf]
+    const float* wdw; const float* bdw; int dw_act;     // depthwise [9][bf], [bf] (BN folded)
+    const float* Wp2; const float* b2; int act2;        // pw2: packed [bf/2][Npad][2], bias [Npad]
+    const float* Wp1n; const float* b1n; int act1n;     // next unit's pw1 (null: last unit of the stage)
+    float* out; int out_ld;                     // next != null: first half of the shuffled output, [M][bf]; else the whole output [M][2*bf]
+    float* t1n;                                 // next unit's depthwise input [M][bf]
+    int B, H, W, bf, Npad, M;
+};
+bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
+
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
 void set_last_kernel_name(const char* n);
 int  pw_config_count();
