@@ -516,6 +516,29 @@ def test_unit_chain_bit_identical_to_three_kernel_path(capi, backbone, C, S, B):
     h.close()
 
 
+@pytest.mark.parametrize("backbone,S,B", [("1.0x", 160, 2), ("0.5x", 224, 1), ("1.0x", 96, 3)])
+def test_dwpw_tile_kernel_bit_identical(capi, monkeypatch, backbone, S, B):
+    """dwpw_tile_kernel (depthwise fused into its pointwise consumer for the stride-2 units and the heads; default off because
+    it is slower, YN_DWPW_TILE=1) computes the same fma chain and k order: raw heads bit-identical to the default path."""
+    sd = weights.make_state_dict(backbone, 20)
+    x = dev(weights.make_input(B, S, seed=S))
+    ref_h = capi.Handle(S, 20, arch.MULTI_ANCHOR_SIZE, backbone, 0.001, 0.5, max_batch=B)
+    ref_h.load_state_dict(sd); ref_h.fold_bn()
+    ref = [t.clone() for t in ref_h.forward_raw(x)]
+    monkeypatch.setenv("YN_DWPW_TILE", "1")
+    h = capi.Handle(S, 20, arch.MULTI_ANCHOR_SIZE, backbone, 0.001, 0.5, max_batch=B)
+    monkeypatch.delenv("YN_DWPW_TILE")
+    h.load_state_dict(sd); h.fold_bn()
+    h.profile_enable(True)
+    got = h.forward_raw(x)
+    names = [r[1] for r in h.profile_records()]
+    h.profile_enable(False)
+    assert any(n.startswith("dwpw_tile_kernel") for n in names), names
+    for u, v in zip(got, ref):
+        assert torch.equal(u, v)
+    h.close(); ref_h.close()
+
+
 @pytest.mark.parametrize("backbone,C", [("1.0x", 20), ("0.5x", 80)])
 def test_size_sweep_vs_torch_oracle(capi, backbone, C):
     """Odd map sizes, partial tiles, batch 1..3, both widths: raw heads against the torch-CPU oracle at 1e-4 (the kernels pick

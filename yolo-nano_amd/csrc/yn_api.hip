@@ -106,6 +106,7 @@ struct yn_handle {
     std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     bool unit_chain = true;                        // stride-1 ShuffleV2 units as one kernel each (yn_unit_chain / YN_UNIT_CHAIN=0)
+    bool dwpw_tile = false;                        // other depthwise convs fused into their pointwise consumer (dwpw_tile_kernel): parity-tested, measured slower — YN_DWPW_TILE=1
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
@@ -494,7 +495,22 @@ bool run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int
 void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
               float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off)
 {
-    const long M = (long)B * H * W;
+    const int Ho = (H - 1) / dw.stride + 1, Wo = (W - 1) / dw.stride + 1;
+    const long M = (long)B * Ho * Wo;                       // output pixels
+    if (h->dwpw_tile && !h->fuse_dwpw) {
+        // dwpw_tile_kernel: the depthwise output lives in an LDS tile only (kernels_conv.hip)
+        GemmArgs a{};
+        a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
+        a.Wp = pw.w_packed; a.bias = pw.b_packed;
+        a.out = out; a.out_ld = out_ld; a.out_off = out_off;
+        a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
+        a.M = (int)M; a.K = pw.cin; a.N = pw.cout; a.Npad = pw.Npad; a.act = pw.act; a.cfg = -1;
+        a.dw_w = dw.w_packed; a.dw_b = dw.b_packed; a.dw_act = dw.act; a.dw_stride = dw.stride;
+        Bracket br(h, dw.name + "+" + pw.name, 2.0 * M * (9.0 * dw.cout + (double)pw.cin * pw.cout),
+                   4.0 * ((double)B * H * W * pw.cin + M * (double)(pw.cout + (pass ? 2 * pw.cout : 0)) + (double)pw.cin * pw.cout));
+        if (dw.cout == pw.cin && launch_dwpw_tile(a, h->cur)) return;
+        br.cancel();
+    }
     if (dw.stride == 1 && h->fuse_dwpw) {
         GemmArgs a{};
         a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
@@ -598,13 +614,21 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         const std::string P0 = nm;
         // stride-2 block: backbone/shufflenetv2.py:73-74
         fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
-        run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
-        run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
-        back_to_main(h);
-        run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
-        run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
-        join_from(h, 0);
-        run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
+        if (h->dwpw_tile) {                                 // depthwise fused into its pointwise consumer (default off: slower)
+            run_dwpw(h, L(h, P0 + ".b1.dw"), L(h, P0 + ".b1.pw"), cur, curC, 0, B, curH, curH, tdw1, tb1, bf, 0, nullptr, 0, 0);
+            back_to_main(h);
+            run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
+            join_from(h, 0);
+            run_dwpw(h, L(h, P0 + ".b2.dw"), L(h, P0 + ".b2.pw2"), t1, bf, 0, B, curH, curH, t2, oA, C, 0, tb1, bf, 0);
+        } else {
+            run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
+            run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+            back_to_main(h);
+            run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
+            run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
+            join_from(h, 0);
+            run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
+        }
         float* o_cur = oA;
         float* o_nxt = oB;
         // stride-1 blocks (backbone/shufflenetv2.py:70-72; x1 = ch [0,bf) passes through, x2 = ch [bf,C)): one kernel per
@@ -729,6 +753,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
+    if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) != 0;    // A/B switch for the one-kernel-per-unit chain
     if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
     build_layers(h);

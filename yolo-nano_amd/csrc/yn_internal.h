@@ -19,6 +19,7 @@ struct GemmArgs {
     int cfg;                                    // pointwise tile configuration index, -1 = heuristic
     const float* dw_w; const float* dw_b;       // fused depthwise prologue (dwpw kernel): [9][K], [K]
     int dw_act;                                 // activation between the depthwise and the pointwise conv
+    int dw_stride;                              // dwpw_tile_kernel: stride of the depthwise conv (H, W = its INPUT extent, M = output pixels)
 };
 
 struct DwArgs {
@@ -60,6 +61,7 @@ void launch_pw(const GemmArgs& a, hipStream_t s);
 void launch_conv3x3(const GemmArgs& a, hipStream_t s);
 // depthwise 3x3 (stride 1, pad 1) + pointwise 1x1 in one kernel; returns false when the shape does not fit
 bool launch_dwpw(const GemmArgs& a, hipStream_t s);
+bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s);
 void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
                  int Cout, int act, float* y, hipStream_t s);
