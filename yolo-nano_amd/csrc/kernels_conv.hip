@@ -1474,7 +1474,8 @@ void launch_dw(const DwArgs& a, hipStream_t s)
 // 49 vs 45).  All blocks of the launch are resident at once and run their phases in lockstep, so the depthwise phase is the
 // whole chip fetching its ~35 MB at the same time (bandwidth-bound, MFMAs idle) and the GEMM phases leave the memory system
 // idle; overlapping them needs a persistent block that requests tile i+1's window (direct-to-LDS loads) while tile i is in
-// its GEMMs — the next step for this kernel.
+// its GEMMs — the next step for this kernel.  (Tried: the GEMM weights register-direct from L2 instead of through LDS, which
+// removes the chunk barriers — GEMM phase 13.7 k -> 22 k cycles: the 8-byte per-lane weight loads are slower than the barriers.)
 // -------------------------------------------------------------------------------------------------
 template <int WM, int WN, int NT, int V>
 __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
