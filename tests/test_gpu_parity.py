@@ -352,6 +352,41 @@ def test_infer_config2_bs32(hcoco, conf_t, nms_t):
     assert int(again[4][0].item()) == k
 
 
+def test_three_handles_on_three_streams_agree(capi):
+    """bench.py's default mode: three independent handles, one HIP stream each, steps dealt round-robin without host syncs in
+    between.  Every handle must produce exactly what a lone handle produces for its input (bit-identical boxes, scores, classes,
+    indices and counts), also when the three pipelines overlap on the device."""
+    S, B, n = 416, 8, 3
+    sd = weights.make_state_dict("1.0x", 80)
+    xs = [dev(weights.make_input(B, S, seed=40 + k)) for k in range(n)]
+    ref_h = capi.Handle(S, 80, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", 0.001, 0.5, max_batch=B)
+    ref_h.load_state_dict(sd); ref_h.fold_bn()
+    refs = [[t.clone() for t in ref_h.infer(x)] for x in xs]
+    ref_h.close()
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    handles, outs = [], []
+    for k, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            hk = capi.Handle(S, 80, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", 0.001, 0.5, max_batch=B, stream=st)
+            hk.load_state_dict(sd); hk.fold_bn()
+            handles.append(hk); outs.append(hk.alloc_outputs(B))
+    for rep in range(6):                                      # 18 overlapping steps, no synchronisation in between
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                handles[k].infer(xs[k], outs[k])
+    for st in streams:
+        st.synchronize()
+    for k in range(n):
+        cnt = refs[k][4]
+        assert torch.equal(outs[k][4], cnt)
+        for b in range(B):
+            kk = int(cnt[b].item())
+            for i in range(4):
+                assert torch.equal(outs[k][i][b, :kk], refs[k][i][b, :kk]), (k, b, i)
+    for hk in handles:
+        hk.close()
+
+
 def test_infer_matches_reference_detections_416(golden, hcoco):
     """End to end against the reference's own detections at 416/COCO.  Float pipelines differ by ~1e-6, which can
     flip a handful of NMS decisions, so: every box/score within 1e-4 for the matched candidates and the
