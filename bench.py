@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="time the SGD training step instead (BASELINE configs[2] shape with --size 608): train-mode forward, "
                          "loss, backward, flat-bucket gradient all-reduce over RCCL when N>1, fused SGD")
+    ap.add_argument("--preprocess", action="store_true",
+                    help="time ValTransforms on the device instead (SURVEY 8(f) rank 2): --batch uint8 500x375 BGR images resident in "
+                         "HBM -> normalised letterboxed [B,3,S,S] float32; reports images/s and the HBM fraction")
     ap.add_argument("--latency", type=int, default=0, metavar="N",
                     help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
@@ -107,6 +110,53 @@ def synthetic_labels(B, C, seed):
         box = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32).astype(np.float64)
         out.append(np.concatenate([box, rs.randint(0, C, (8, 1)).astype(np.float64)], 1).tolist())
     return out
+
+
+def preprocess_bench(args, rank, world, dev, dist):
+    """ValTransforms (data/transforms.py:445-458) on the device: one yn_preprocess launch per image, images already in HBM."""
+    from yolo_nano_amd import ValTransforms, parallel
+    B, S, h0, w0 = args.batch, args.size, 375, 500                        # a VOC-sized frame
+    tf = ValTransforms(S, device=dev)
+    hd = tf._h()
+    g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+    imgs = [torch.randint(0, 256, (h0, w0, 3), generator=g, device=dev, dtype=torch.uint8) for _ in range(B)]
+    rw, rh, left, top, _, _ = tf.geometry(h0, w0)
+    x = torch.empty((B, 3, S, S), device=dev)
+
+    geoms = [(rw, rh, left, top)] * B
+
+    def step():
+        hd.preprocess_batch(imgs, geoms, S, tf.mean, tf.std, out=x)        # one launch per 32 images
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)    # on the launch stream (torch's current one)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    sync_all()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    us = e0.elapsed_time(e1) * 1e3 / args.steps / ((B + 31) // 32)         # HIP events over the timed region: per launch (32 images)
+    alg = min(B, 32) * (h0 * w0 * 3 + 3 * S * S * 4)                       # source frames read once (u8) + the float tensors written
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec ValTransforms %dx%d -> %dx%d (device preprocess)" % (w0, h0, S, S),
+                          "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32", "data": "synthetic",
+                          "config": {"workload": "ValTransforms(size=%d) on %d uint8 %dx%d BGR frames resident in HBM, one launch per 32 images" % (S, B, w0, h0)},
+                          "roofline": {"kernel": "preprocess_batch_kernel", "bound": "hbm", "achieved": round(alg / us / 1e3, 1), "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": round(alg / us / 1e3 / PEAK_HBM_GBS, 4), "traffic": None,
+                                       "alg_bytes_per_launch": alg, "avg_us": round(us, 2)},
+                          "cpu_baseline": None}), flush=True)
+    hd.close()
 
 
 def train_bench(args, rank, world, dev, dist):
@@ -189,6 +239,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     parallel.init(os.environ.get("YN_BENCH_BACKEND", "nccl"), dev)     # RCCL; inference uses it only for the barrier / max-over-ranks
     dist = torch.distributed if world > 1 else None
+    if args.preprocess:
+        preprocess_bench(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.train:
         train_bench(args, rank, world, dev, dist)
         if dist is not None:

@@ -116,6 +116,19 @@ int  yn_nms(yn_handle* h, const float* dets_dev, const float* scores_dev, int n,
 int  yn_nms_merge(yn_handle* h, const float* boxes_dev, const float* scores_dev, const int32_t* cls_dev, int n, int num_classes,
                   float nms_thresh, int diou, float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count_dev);
 
+/* ValTransforms (data/transforms.py:445-458 = Resize :73-119 + Normalize :59-70 + ToTensor :394-398; call sites
+ * benchmark.py:58, evaluator/vocapi_evaluator.py:64): img_dev = uint8 [h0][w0][3] BGR on the device -> x_dev float32
+ * [3][side][side] RGB, normalised, letterboxed.  The caller supplies Resize's integer geometry (rw x rh resized extent placed
+ * at (left, top) inside the side x side square, padded with mean*255) — it is host arithmetic the reference does in Python
+ * (`int(r * size)`, `//`); the resize itself is cv2's 8-bit INTER_LINEAR.  mean / std: 3 host floats each, BGR order. */
+int  yn_preprocess(yn_handle* h, const uint8_t* img_dev, int h0, int w0, int rw, int rh, int left, int top, int side,
+                   const float* mean_host, const float* std_host, float* x_dev);
+
+/* The same for n images in one launch per 32: imgs_host[i] = device pointer of image i, geom_host[i] = {h0, w0, rw, rh, left,
+ * top}; x_dev = float32 [n][3][side][side] (the network's input batch). */
+int  yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs_host, const int32_t* geom_host, int side,
+                         const float* mean_host, const float* std_host, float* x_dev);
+
 /* YOLONano.postprocess :245-279, batched: all_local [B,N,4], all_conf [B,N,C] ->
  * per image b: count[b] = K_b and, in ascending candidate order, out_boxes[b,0:K_b,4],
  * out_scores[b,0:K_b], out_cls[b,0:K_b], out_index[b,0:K_b] (candidate index; may be NULL).

@@ -276,3 +276,51 @@ def test_tta_merge_oracle_matches_reference(golden):
     np.testing.assert_array_equal(bb, g["boxes"])
     np.testing.assert_array_equal(sc, g["scores"])
     np.testing.assert_array_equal(lb, g["labels"])
+
+
+# ---- ValTransforms oracle.  PARITY UNPINNED (oracle/preprocess.py header): cv2 is not in this image, so these
+#      tests pin what can be pinned without it — geometry, exact cases, the letterbox arithmetic.
+def test_preprocess_oracle_resize_geometry_and_exact_cases():
+    import torch
+    from oracle import preprocess as pp
+    rs = np.random.RandomState(0)
+    img = (rs.rand(37, 53, 3) * 255).astype(np.uint8)
+    for dsz in [(80, 61), (20, 17), (106, 74), (27, 19), (416, 290), (9, 416)]:
+        out = pp.cv2_resize_linear_u8(img, dsz)
+        assert out.shape == (dsz[1], dsz[0], 3) and out.dtype == np.uint8
+        t = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = torch.nn.functional.interpolate(t, size=(dsz[1], dsz[0]), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(out.astype(np.float32) - ref).max() <= 1.0          # 11-bit weights: within one grey level of float bilinear
+    assert np.array_equal(pp.cv2_resize_linear_u8(img, (53, 37)), img)    # same size: copy
+    const = np.full((10, 12, 3), 77, np.uint8)
+    assert np.unique(pp.cv2_resize_linear_u8(const, (31, 29))).tolist() == [77]
+    big = (rs.rand(40, 60, 3) * 255).astype(np.uint8)                     # exact 2:1 reduction: 2x2 box average, rounded
+    half = pp.cv2_resize_linear_u8(big, (30, 20))
+    v = big.astype(np.int32)
+    assert np.array_equal(half, ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+
+
+def test_preprocess_oracle_letterbox_and_normalisation():
+    from oracle import preprocess as pp
+    rs = np.random.RandomState(1)
+    wide = (rs.rand(30, 48, 3) * 255).astype(np.uint8)                    # h0 < w0: resized to 64 x int(30/48*64) = 64 x 40, top = 12
+    x, boxes, scale, offset = pp.val_transforms(wide, 64, boxes=np.array([[0.1, 0.2, 0.5, 0.6]]))
+    assert x.shape == (3, 64, 64) and x.dtype == np.float32
+    np.testing.assert_allclose(scale, [1., 40 / 64, 1., 40 / 64]); np.testing.assert_allclose(offset, [[0., 12 / 64, 0., 12 / 64]])
+    np.testing.assert_allclose(boxes, [[0.1, 0.2 * 0.625 + 0.1875, 0.5, 0.6 * 0.625 + 0.1875]])
+    mean, std = np.array((0.406, 0.456, 0.485), np.float32), np.array((0.225, 0.224, 0.229), np.float32)
+    pad = ((mean * 255).astype(np.float32) / np.float32(255.) - mean) / std        # padded rows: mean*255, then normalised
+    for c in range(3):
+        np.testing.assert_array_equal(x[2 - c, :12, :], np.full((12, 64), pad[c], np.float32))
+        np.testing.assert_array_equal(x[2 - c, 52:, :], np.full((12, 64), pad[c], np.float32))
+    res = pp.cv2_resize_linear_u8(wide, (64, 40)).astype(np.float32)
+    np.testing.assert_array_equal(x[0, 12:52, :], ((res[..., 2] / np.float32(255.)) - mean[2]) / std[2])   # channel 0 = R = BGR index 2
+    tall = (rs.rand(50, 20, 3) * 255).astype(np.uint8)                    # h0 > w0: int(20/50*64) = 25 wide, left = 19
+    x, _, scale, offset = pp.val_transforms(tall, 64)
+    np.testing.assert_allclose(scale, [[25 / 64, 1., 25 / 64, 1.]]); np.testing.assert_allclose(offset, [[19 / 64, 0., 19 / 64, 0.]])
+    sq = (rs.rand(64, 64, 3) * 255).astype(np.uint8)                      # square at the target size: no resize at all
+    x, _, scale, offset = pp.val_transforms(sq, 64)
+    assert scale == 1. and not offset.any()
+    np.testing.assert_array_equal(x[1], (sq[..., 1].astype(np.float32) / np.float32(255.) - mean[1]) / std[1])
+    b = pp.rescale_boxes(np.array([[0.25, 0.5, 0.75, 0.75]], np.float32), np.array([1., 0.625, 1., 0.625]), np.array([[0., 0.1875, 0., 0.1875]]), 480, 300)
+    np.testing.assert_allclose(b, [[120., 150., 360., 270.]], rtol=1e-6)

@@ -63,6 +63,8 @@ SIGNATURES = {
     "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "yn_preprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "yn_preprocess_batch": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_nms_merge": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_ema_update": (_i32, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_double]),
     "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
@@ -328,6 +330,38 @@ class Handle:
         assert params.is_contiguous() and grads.is_contiguous() and momentum_buf.is_contiguous() and params.numel() == grads.numel() == momentum_buf.numel()
         self._ck(self.lib.yn_sgd_step(self.h, params.data_ptr(), grads.data_ptr(), momentum_buf.data_ptr(), params.numel(),
                                       float(lr), float(momentum), float(weight_decay), float(grad_scale), int(bool(first_step))), "yn_sgd_step")
+
+    def preprocess(self, img_u8, rw, rh, left, top, side, mean, std, out=None):
+        """ValTransforms on the device: uint8 [h0,w0,3] BGR CUDA tensor -> float32 [3,side,side] (yn_preprocess)."""
+        assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous() and img_u8.is_cuda
+        h0, w0 = int(img_u8.shape[0]), int(img_u8.shape[1])
+        if out is None:
+            out = torch.empty((3, side, side), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == 3 * side * side
+        m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+        sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+        self._ck(self.lib.yn_preprocess(self.h, img_u8.data_ptr(), h0, w0, int(rw), int(rh), int(left), int(top), int(side),
+                                        ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), out.data_ptr()), "yn_preprocess")
+        return out
+
+    def preprocess_batch(self, imgs_u8, geoms, side, mean, std, out=None):
+        """n images in one launch per 32 (yn_preprocess_batch): imgs_u8 = list of uint8 [h0,w0,3] CUDA tensors, geoms = list of
+        (rw, rh, left, top) -> float32 [n,3,side,side]."""
+        n = len(imgs_u8)
+        if out is None:
+            out = torch.empty((n, 3, side, side), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == n * 3 * side * side
+        ptrs = (ctypes.c_void_p * max(n, 1))()
+        geom = (ctypes.c_int32 * (6 * max(n, 1)))()
+        for i, (im, g) in enumerate(zip(imgs_u8, geoms)):
+            assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == 3 and im.is_contiguous() and im.is_cuda
+            ptrs[i] = im.data_ptr()
+            geom[6 * i:6 * i + 6] = [int(im.shape[0]), int(im.shape[1]), int(g[0]), int(g[1]), int(g[2]), int(g[3])]
+        m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+        sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+        self._ck(self.lib.yn_preprocess_batch(self.h, n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(geom, ctypes.c_void_p), int(side),
+                                              ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), out.data_ptr()), "yn_preprocess_batch")
+        return out
 
     def nms_merge(self, boxes, scores, cls, num_classes, nms_thresh, diou=False):
         """Per-class NMS over a detection list (TTA merge, utils/misc.py:132-146) -> (boxes [K,4], scores [K], cls [K], index [K])."""

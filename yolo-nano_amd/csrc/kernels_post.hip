@@ -775,4 +775,117 @@ void launch_nms_single(const float* dets, const float* scores, int n, float thre
     hipLaunchKernelGGL(single_resolve_kernel, dim3(1), dim3(256), 0, s, ids_scratch, n, M, keep, count);
 }
 
+// -------------------------------------------------------------------------------------------------
+// ValTransforms on the device (data/transforms.py:59-70, 73-119, 394-398, 445-458): uint8 HWC BGR image -> letterbox resize
+// (cv2.resize INTER_LINEAR, 8-bit fixed point: modules/imgproc/src/resize.cpp, restated in oracle/preprocess.py — the oracle's
+// header says why this path's parity is UNPINNED) -> mean padding -> /255, -mean, /std -> RGB CHW float32, written straight
+// into one image slot of the network input.  Thread = one output pixel (three channels); HBM-bound: 3 bytes read per resized
+// pixel (4 taps from L1/L2), 12 bytes written.  mode: 0 copy, 1 exact 2:1 reduction (2x2 box), 2 linear.
+// -------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const unsigned char* img; int h0, w0;       // source
+    int rw, rh, left, top, side, mode;          // resized extent, placement inside the side x side square
+    float mean[3], std[3];                      // BGR order, as the reference passes them
+    float* out;                                 // [3][side][side], channel 0 = R
+};
+
+__device__ __forceinline__ void preprocess_pixel(const PrepArgs& a, int i)
+{
+    if (i >= a.side * a.side) return;
+    const int y = i / a.side, x = i - y * a.side;
+    const int ry = y - a.top, rx = x - a.left;
+    float v[3];
+    if (ry >= 0 && ry < a.rh && rx >= 0 && rx < a.rw) {
+        int u[3];
+        if (a.mode == 0) {
+            const unsigned char* p = a.img + ((size_t)ry * a.w0 + rx) * 3;
+            u[0] = p[0]; u[1] = p[1]; u[2] = p[2];
+        } else if (a.mode == 1) {
+            const unsigned char* p = a.img + ((size_t)(2 * ry) * a.w0 + 2 * rx) * 3;
+            const unsigned char* q = p + (size_t)a.w0 * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u[c] = (p[c] + p[3 + c] + q[c] + q[3 + c] + 2) >> 2;
+        } else {
+            // resizeGeneric_ (ksize 2): fx = (float)((dx + 0.5) * scale - 0.5), scale = 1 / (dsize / ssize) in double
+            const double scx = 1.0 / ((double)a.rw / (double)a.w0), scy = 1.0 / ((double)a.rh / (double)a.h0);
+            float fx = (float)(((double)rx + 0.5) * scx - 0.5), fy = (float)(((double)ry + 0.5) * scy - 0.5);
+            int sx = (int)floorf(fx), sy = (int)floorf(fy);
+            fx -= (float)sx; fy -= (float)sy;
+            if (sx < 0) { fx = 0.0f; sx = 0; }
+            if (sx >= a.w0 - 1) { fx = 0.0f; sx = a.w0 - 1; }
+            const int a0 = __float2int_rn((1.0f - fx) * 2048.0f), a1 = __float2int_rn(fx * 2048.0f);   // cvRound -> short
+            const int b0 = __float2int_rn((1.0f - fy) * 2048.0f), b1 = __float2int_rn(fy * 2048.0f);
+            const int sx1 = min(sx + 1, a.w0 - 1);
+            const int r0 = min(max(sy, 0), a.h0 - 1), r1 = min(max(sy + 1, 0), a.h0 - 1);
+            const unsigned char* p0 = a.img + (size_t)r0 * a.w0 * 3;
+            const unsigned char* p1 = a.img + (size_t)r1 * a.w0 * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int s0 = p0[sx * 3 + c] * a0 + p0[sx1 * 3 + c] * a1;          // HResizeLinear (scale 2048)
+                const int s1 = p1[sx * 3 + c] * a0 + p1[sx1 * 3 + c] * a1;
+                const int r = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;   // VResizeLinear 8u
+                u[c] = min(max(r, 0), 255);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)u[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = a.mean[c] * 255.0f;                     // Resize.mean = [v * 255 for v in mean]
+    }
+    const size_t plane = (size_t)a.side * a.side;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = v[c] / 255.0f;                                                   // Normalize: image /= 255.; -= mean; /= std
+        t = t - a.mean[c];
+        t = t / a.std[c];
+        a.out[(size_t)(2 - c) * plane + i] = t;                                    // ToTensor: BGR -> RGB, HWC -> CHW
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PrepArgs a) { preprocess_pixel(a, blockIdx.x * 256 + threadIdx.x); }
+
+// up to PREP_MAX images per launch (descriptors by value in the kernel arguments): blockIdx.y = image
+constexpr int PREP_MAX = 32;
+struct PrepImg { const unsigned char* img; int h0, w0, rw, rh, left, top; };
+struct PrepBatchArgs { PrepImg im[PREP_MAX]; int side; float mean[3], std[3]; float* out; };
+__global__ __launch_bounds__(256) void preprocess_batch_kernel(PrepBatchArgs b)
+{
+    const PrepImg& d = b.im[blockIdx.y];
+    PrepArgs a;
+    a.img = d.img; a.h0 = d.h0; a.w0 = d.w0; a.rw = d.rw; a.rh = d.rh; a.left = d.left; a.top = d.top; a.side = b.side;
+    a.mode = (d.rw == d.w0 && d.rh == d.h0) ? 0 : ((d.w0 == 2 * d.rw && d.h0 == 2 * d.rh) ? 1 : 2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.mean[c] = b.mean[c]; a.std[c] = b.std[c]; }
+    a.out = b.out + (size_t)blockIdx.y * 3 * b.side * b.side;
+    preprocess_pixel(a, blockIdx.x * 256 + threadIdx.x);
+}
+
+void launch_preprocess_batch(int n, const unsigned char* const* imgs, const int* geom, int side, const float* mean, const float* stdv,
+                             float* out, hipStream_t s)
+{
+    for (int i0 = 0; i0 < n; i0 += PREP_MAX) {
+        const int m = n - i0 < PREP_MAX ? n - i0 : PREP_MAX;
+        PrepBatchArgs b{};
+        for (int i = 0; i < m; ++i) {
+            const int* g = geom + (size_t)(i0 + i) * 6;
+            b.im[i] = PrepImg{imgs[i0 + i], g[0], g[1], g[2], g[3], g[4], g[5]};
+        }
+        b.side = side; b.out = out + (size_t)i0 * 3 * side * side;
+        for (int c = 0; c < 3; ++c) { b.mean[c] = mean[c]; b.std[c] = stdv[c]; }
+        hipLaunchKernelGGL(preprocess_batch_kernel, dim3((side * side + 255) / 256, m), dim3(256), 0, s, b);
+    }
+}
+
+void launch_preprocess(const unsigned char* img, int h0, int w0, int rw, int rh, int left, int top, int side,
+                       const float* mean, const float* stdv, float* out, hipStream_t s)
+{
+    PrepArgs a;
+    a.img = img; a.h0 = h0; a.w0 = w0; a.rw = rw; a.rh = rh; a.left = left; a.top = top; a.side = side; a.out = out;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = stdv[c]; }
+    a.mode = (rw == w0 && rh == h0) ? 0 : ((w0 == 2 * rw && h0 == 2 * rh) ? 1 : 2);
+    const int n = side * side;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
 }  // namespace ynk

@@ -1038,6 +1038,37 @@ int yn_postprocess(yn_handle* h, const float* all_local, const float* all_conf, 
     return 0;
 }
 
+int yn_preprocess(yn_handle* h, const uint8_t* img, int h0, int w0, int rw, int rh, int left, int top, int side,
+                  const float* mean, const float* stdv, float* x)
+{
+    if (!h) return 1;
+    if (!img || !x || !mean || !stdv) return fail(h, "yn_preprocess: null pointer");
+    if (h0 <= 0 || w0 <= 0 || rw <= 0 || rh <= 0 || side <= 0 || left < 0 || top < 0 || left + rw > side || top + rh > side)
+        return fail(h, "yn_preprocess: bad geometry (%dx%d -> %dx%d at (%d,%d) in %d)", w0, h0, rw, rh, left, top, side);
+    for (int c = 0; c < 3; ++c)
+        if (!(stdv[c] > 0.0f)) return fail(h, "yn_preprocess: std must be positive");
+    launch_preprocess(img, h0, w0, rw, rh, left, top, side, mean, stdv, x, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs, const int32_t* geom, int side, const float* mean, const float* stdv, float* x)
+{
+    if (!h) return 1;
+    if (n < 0 || (n > 0 && (!imgs || !geom)) || !x || !mean || !stdv || side <= 0) return fail(h, "yn_preprocess_batch: bad arguments");
+    for (int c = 0; c < 3; ++c)
+        if (!(stdv[c] > 0.0f)) return fail(h, "yn_preprocess_batch: std must be positive");
+    for (int i = 0; i < n; ++i) {
+        const int32_t* g = geom + (size_t)i * 6;
+        if (!imgs[i] || g[0] <= 0 || g[1] <= 0 || g[2] <= 0 || g[3] <= 0 || g[4] < 0 || g[5] < 0 || g[4] + g[2] > side || g[5] + g[3] > side)
+            return fail(h, "yn_preprocess_batch: bad geometry for image %d", i);
+    }
+    if (n == 0) return 0;
+    launch_preprocess_batch(n, imgs, geom, side, mean, stdv, x, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int yn_nms_merge(yn_handle* h, const float* boxes, const float* scores, const int32_t* cls, int n, int num_classes, float nms_thresh, int diou,
                  float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count)
 {

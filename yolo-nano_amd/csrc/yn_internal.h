@@ -177,6 +177,10 @@ void launch_strided_copy(const float* src, int src_ld, int src_off, int src_cs, 
                          long M, int n, int accumulate, hipStream_t s);
 void launch_pack_bwd(const float* w, int Cout, int Cin, int kind, int Npad, float* out, hipStream_t s);
 
+void launch_preprocess(const unsigned char* img, int h0, int w0, int rw, int rh, int left, int top, int side,
+                       const float* mean, const float* stdv, float* out, hipStream_t s);
+void launch_preprocess_batch(int n, const unsigned char* const* imgs, const int* geom, int side, const float* mean, const float* stdv,
+                             float* out, hipStream_t s);
 void launch_ema(float* v, const float* m, long n, float d, float one_minus_d, hipStream_t s);
 void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s);
 

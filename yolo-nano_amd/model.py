@@ -454,6 +454,79 @@ class ModelEMA(object):
             self.ema._sig = None                               # the EMA copy's folded weights are stale now
 
 
+class ValTransforms(object):
+    """data/transforms.py:445-458 (Resize :73-119 -> Normalize :59-70 -> ToTensor :394-398) with the pixel work on the device.
+
+        x, boxes, labels, scale, offset = ValTransforms(size)(image, boxes, labels)
+
+    Same constructor, call signature and return tuple as the reference; `image` is the uint8 HxWx3 BGR array cv2.imread gives.
+    The image travels to the GPU as uint8 (3 bytes per pixel instead of the 12 of the float tensor the reference uploads) and
+    yn_preprocess writes the normalised letterboxed RGB CHW float32 tensor (cv2.resize's 8-bit INTER_LINEAR arithmetic,
+    restated: oracle/preprocess.py explains why that parity is unpinned).  Resize's integer geometry, `scale` and `offset` are
+    computed here with the reference's own expressions.  `out=` writes straight into one [3,size,size] slot of a batch."""
+
+    def __init__(self, size=640, mean=(0.406, 0.456, 0.485), std=(0.225, 0.224, 0.229), handle=None, device=None):
+        self.size = size
+        self.mean = np.array(mean, dtype=np.float32)
+        self.std = np.array(std, dtype=np.float32)
+        self._handle = handle
+        self._device = device
+
+    def _h(self):
+        if self._handle is None:                               # a bare handle: only its stream / error plumbing is used
+            from . import capi
+            from . import arch
+            dev = self._device if self._device is not None else torch.device("cuda", torch.cuda.current_device())
+            self._handle = capi.Handle(32, 1, arch.MULTI_ANCHOR_SIZE, "1.0x", device=dev)
+        return self._handle
+
+    def geometry(self, h0, w0):
+        """Resize.__call__ (data/transforms.py:79-116): (rw, rh, left, top, scale, offset)."""
+        size = self.size
+        if h0 > w0:
+            r = w0 / h0
+            w, h = int(r * size), size
+            left = (h - w) // 2
+            return w, h, left, 0, np.array([[w / h, 1., w / h, 1.]]), np.array([[left / h, 0., left / h, 0.]])
+        if h0 < w0:
+            r = h0 / w0
+            w, h = size, int(r * size)
+            top = (w - h) // 2
+            return w, h, 0, top, np.array([1., h / w, 1., h / w]), np.array([[0., top / w, 0., top / w]])
+        return size, size, 0, 0, 1., np.zeros([1, 4])
+
+    def __call__(self, image, boxes=None, labels=None, scale=None, offset=None, out=None):
+        h0, w0, _ = image.shape
+        rw, rh, left, top, scale, offset = self.geometry(h0, w0)
+        hd = self._h()
+        img = torch.as_tensor(np.ascontiguousarray(image, dtype=np.uint8)).to(hd.device, non_blocking=True)
+        x = hd.preprocess(img, rw, rh, left, top, self.size, self.mean, self.std, out=out)
+        if boxes is not None:
+            boxes = boxes * scale + offset
+        return x, boxes, labels, scale, offset
+
+
+    def batch(self, images, out=None):
+        """A list of uint8 HxWx3 BGR arrays (any sizes) -> (x float32 [n,3,size,size] on the device, scales, offsets): the loop
+        of benchmark.py:58 / vocapi_evaluator.py:64 over a batch, one kernel launch per 32 images."""
+        hd = self._h()
+        dev_imgs, geoms, scales, offsets = [], [], [], []
+        for im in images:
+            rw, rh, left, top, scale, offset = self.geometry(im.shape[0], im.shape[1])
+            dev_imgs.append(torch.as_tensor(np.ascontiguousarray(im, dtype=np.uint8)).to(hd.device, non_blocking=True))
+            geoms.append((rw, rh, left, top)); scales.append(scale); offsets.append(offset)
+        return hd.preprocess_batch(dev_imgs, geoms, self.size, self.mean, self.std, out=out), scales, offsets
+
+
+def rescale_boxes(bboxes, scale, offset, size):
+    """benchmark.py:66-69 / evaluator/vocapi_evaluator.py:72-75: detections of the letterboxed square back to pixels of the
+    original image (`size` = np.array([[w, h, w, h]])); in place, like the reference."""
+    bboxes -= offset
+    bboxes /= scale
+    bboxes *= size
+    return bboxes
+
+
 class TestTimeAugmentation(object):
     """utils/misc.py:90-148: multi-scale (scale_range) x horizontal flip forwards of image 0, merged by per-class NMS.
     Same constructor and call signature; the forwards run through the model's handle, the merge through yn_nms_merge."""
