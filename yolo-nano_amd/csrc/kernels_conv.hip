@@ -1469,9 +1469,9 @@ void launch_dw(const DwArgs& a, hipStream_t s)
 //   4. GEMM t_{i+1} = relu(T * W1' + b1') -> global.
 // Per unit: 1 launch instead of 3, 4 tensors of [M][bf] through memory instead of 8, no halo recompute.  All sums run in the
 // order of the separate kernels (same fma chain in the depthwise conv, same k order in the GEMMs): bit-identical results.
-// Measured (tools/chain_timing.sh, stage 3, M = 21 632, bf = 116; cycles per block): depthwise phase 25 k, GEMM 13.7 k each,
-// y->T 5 k, interleave 3.4 k, epilogue 5.7 k = 41 us per unit against 46 us for the three kernels (stage 2: 46 vs 66, stage 4:
-// 49 vs 45).  All blocks of the launch are resident at once and run their phases in lockstep, so the depthwise phase is the
+// Measured (tools/chain_timing.sh, stage 3, M = 21 632, bf = 116; cycles per block): depthwise phase 20 k, GEMM 13.1 k each (two
+// co-resident blocks share the MFMA pipe: 2 x 7.4 k of MFMA issue), y->T 5.5 k, interleave 3.2 k, epilogue 5.6 k = 39 us per unit
+// against 46 us for the three kernels (stage 2: 42 vs 66, stage 4: 47 vs 45).  All blocks of the launch are resident at once and run their phases in lockstep, so the depthwise phase is the
 // whole chip fetching its ~35 MB at the same time (bandwidth-bound, MFMAs idle) and the GEMM phases leave the memory system
 // idle; overlapping them needs a persistent block that requests tile i+1's window (direct-to-LDS loads) while tile i is in
 // its GEMMs — the next step for this kernel.  (Tried: the GEMM weights register-direct from L2 instead of through LDS, which
@@ -1487,8 +1487,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
     extern __shared__ __attribute__((aligned(16))) float uc_smem[];
     const int bf = a.bf, CS = bf + 2, W = a.W, H = a.H, HW = H * W;
     float* T = uc_smem;                                      // [BM][CS]
-    float* Bs = uc_smem + ((BM * CS + 3) & ~3);              // [KP][BS]
-    float* Wd = Bs + KP * BS;                                // [10][bf]: the nine depthwise taps and the bias (kept out of the register file)
+    float* Bs = uc_smem + ((BM * CS + 3) & ~3);              // [2][KP][BS]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
@@ -1496,8 +1495,10 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
     if (m0 >= a.M) return;
     const int nchunks = (bf + 2 * KP - 1) / (2 * KP), kp_total = bf >> 1;
 
-    float4 b_reg[B_PER];
-    auto prefetch_b = [&](const float* Wp, int c) {
+    // GEMM weights: chunks of KP k-pairs through TWO LDS buffers, requested TWO chunks ahead into two register sets, so a
+    // chunk's loads have two chunk-times (~4 k cycles) to arrive and there is one barrier per chunk.
+    float4 regA[B_PER], regB[B_PER];
+    auto prefetch_b = [&](float4 (&reg)[B_PER], const float* Wp, int c) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int idx = t + 256 * i;
@@ -1505,15 +1506,15 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
             const int kpg = c * KP + kp;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (kpg < kp_total) v = *reinterpret_cast<const float4*>(Wp + ((size_t)kpg * a.Npad + c4 * 2) * 2);
-            b_reg[i] = v;
+            reg[i] = v;
         }
     };
-    auto stage_b = [&]() {
+    auto stage_b = [&](float4 (&reg)[B_PER], int buf) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int idx = t + 256 * i;
             const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + kp * BS + c4 * 4) = b_reg[i];
+            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = reg[i];
         }
     };
 #ifdef YN_EXP_TIMING
@@ -1523,13 +1524,13 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 #define YN_TS()
 #endif
     YN_TS();
-    prefetch_b(a.Wp2, 0);
 
     // The pass-through half x1 is only needed by the interleave pass after the first GEMM: request it now, so that its
     // latency hides behind the depthwise conv and the GEMM.  Item it = (row, G consecutive j of the first half-row); the same
     // item also owns the j + bf/2 of the second half-row (xg / xl).
     const int hipr = bf / (2 * G), jhi = bf >> 1;          // items per half row; first j of the second half (bf/2 is a multiple of G)
     float2 xg[MAXB], xl[MAXB];                               // G == 1 uses .x only
+    auto x1_prefetch = [&]() {
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
         const int it = t + 256 * i;
@@ -1547,12 +1548,12 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
             }
         }
     }
+    };
 
     // ---- 1. depthwise 3x3 of the block's pixels -> T ---------------------------------------------------------
     {
         const int cgn = bf / V, ppl = 256 / cgn;
         const int cg = t % cgn, pl = t / cgn, c = cg * V;
-        for (int i = t; i < 10 * bf; i += 256) Wd[i] = i < 9 * bf ? a.wdw[i] : a.bdw[i - 9 * bf];
         const bool worker = pl < ppl;                        // 256 is not a multiple of the channel groups: a few threads idle
         {
             // Thread = (channel group, runs of R consecutive flat pixels).  Neighbour (dy, dx) of flat pixel p is flat pixel
@@ -1571,24 +1572,32 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
                         win[dy][i] = *reinterpret_cast<const vec*>(a.t1 + (size_t)q * a.t1_ld + a.t1_off + c);
                     }
             };
+            // the nine taps and the bias of this thread's channel group live in registers (the kernel runs at two waves per SIMD
+            // either way; from LDS they cost 72 ds_read_b128 per thread)
+            vec w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const vec*>(a.wdw + k * bf + c);
+            const vec bias = *reinterpret_cast<const vec*>(a.bdw + c);
             auto finish = [&](int run, vec (&win)[3][R + 2]) {
+                const int mrun = m0 + run * R;
+                const int rem0 = (mrun < a.M ? mrun : m0) % HW;  // one division per run; the R pixels advance by one column
+                int y = rem0 / W, x = rem0 - y * W;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const int r = run * R + i, m = m0 + r;
-                    const bool live = m < a.M;
-                    const int mc = live ? m : m0;
-                    const int rem = mc % HW;
-                    const int y = rem / W, x = rem - y * W;
-                    vec acc = *reinterpret_cast<const vec*>(Wd + 9 * bf + c);
+                    const int r = run * R + i;
+                    const bool live = mrun + i < a.M;
+                    const bool yk[3] = {live && y >= 1, live, live && y + 1 < H};
+                    const bool xk[3] = {x >= 1, true, x + 1 < W};
+                    vec acc = bias;
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const bool ok = live && (unsigned)(y + ky - 1) < (unsigned)H && (unsigned)(x + kx - 1) < (unsigned)W;
+                            const bool ok = yk[ky] && xk[kx];
                             vec v = win[ky][i + kx];
                             if constexpr (V == 4) v = make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
                             else v = make_float2(ok ? v.x : 0.0f, ok ? v.y : 0.0f);
-                            vfma(acc, v, *reinterpret_cast<const vec*>(Wd + (ky * 3 + kx) * bf + c));
+                            vfma(acc, v, w[ky * 3 + kx]);
                         }
                     acc = vact(acc, a.dw_act);
                     float* d = T + r * CS + c;                   // row stride CS*4 bytes is only 8-byte aligned
@@ -1598,14 +1607,18 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
                     } else {
                         *reinterpret_cast<float2*>(d) = acc;
                     }
+                    if (++x == W) { x = 0; if (++y == H) y = 0; }
                 }
             };
             // One window in flight per thread: the latency is hidden by the other blocks of the CU (a second window in flight
             // costs 72 registers and an occupancy step: measured 2x slower).
             vec win[3][R + 2];
+            // request order = completion order (vmcnt is in-order): the first window, then the GEMM's first weight chunk, then x1
             if (worker) issue(pl, win);
-            stage_b();                                       // first weight chunk of the GEMM: requested before everything else, its registers are free from here on
-            __syncthreads();                                 // Wd visible
+            prefetch_b(regA, a.Wp2, 0);
+            x1_prefetch();
+            stage_b(regA, 0);                                // GEMM entry state: chunk 0 in buffer 0, chunk 1 requested into regA
+            if (nchunks > 1) prefetch_b(regA, a.Wp2, 1);
             if (worker) {
                 for (int run = pl; run < BM / R; run += ppl) {
                     finish(run, win);
@@ -1620,54 +1633,62 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 
     // ---- GEMM: acc = T[BM][bf] * Wp (chunk 0 already staged in Bs) --------------------------------------------
     f32x16 acc[NT];
+    auto mfma_chunk = [&](int c, int buf) {
+        const int krem = bf - c * 2 * KP;
+        const int nq = krem >= 2 * KP ? KP / 2 : ((krem + 3) >> 2);
+        const float* Ab = T + (wm * 32 + l31) * CS + c * 2 * KP + 2 * h;
+        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2 + h * BS;
+        float2 av = *reinterpret_cast<const float2*>(Ab);
+        float2 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
+#pragma unroll
+        for (int q = 0; q < KP / 2; ++q) {
+            if (q < nq) {                                   // wave-uniform
+                float2 av_n = av, bv_n[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
+                if (q + 1 < nq) {
+                    av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                av = av_n;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
+            }
+        }
+    };
+    // entry state: chunk 0 staged in buffer 0 (visible), chunk 1 requested into regA
     auto gemm = [&](const float* Wp) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
-        for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks) prefetch_b(Wp, c + 1);
-            const int krem = bf - c * 2 * KP;
-            const int nq = krem >= 2 * KP ? KP / 2 : ((krem + 3) >> 2);
-            const float* Ab = T + (wm * 32 + l31) * CS + c * 2 * KP + 2 * h;
-            const float* Bb = Bs + (wn * NT * 32 + l31) * 2 + h * BS;
-            float2 av = *reinterpret_cast<const float2*>(Ab);
-            float2 bv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-#pragma unroll
-            for (int q = 0; q < KP / 2; ++q) {
-                if (q < nq) {                               // wave-uniform
-                    float2 av_n = av, bv_n[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-                    if (q + 1 < nq) {
-                        av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    av = av_n;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-                }
-            }
-            if (c + 1 < nchunks) {
-                __syncthreads();                            // everyone is done with this chunk's weights
-                stage_b();
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 2 < nchunks) prefetch_b(regB, Wp, c + 2);
+            mfma_chunk(c, 0);
+            if (c + 1 >= nchunks) break;
+            stage_b(regA, 1);                               // buffer 1 was last read two chunks ago, before the previous barrier
+            __syncthreads();
+            if (c + 3 < nchunks) prefetch_b(regA, Wp, c + 3);
+            mfma_chunk(c + 1, 1);
+            if (c + 2 < nchunks) {
+                stage_b(regB, 0);
                 __syncthreads();
             }
         }
     };
     gemm(a.Wp2);
     YN_TS();
-    if (a.Wp1n) prefetch_b(a.Wp1n, 0);
+    if (a.Wp1n) prefetch_b(regA, a.Wp1n, 0);
     __syncthreads();                                        // all waves are done reading T and Bs
 
     // ---- 3. y = act(acc + b2) -> T (in place) -----------------------------------------------------------------
@@ -1680,7 +1701,10 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
             for (int r = 0; r < 16; ++r) T[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + n] = apply_act(acc[nt][r] + bias, a.act2);
         }
     }
-    if (a.Wp1n) stage_b();
+    if (a.Wp1n) {
+        stage_b(regA, 0);
+        if (nchunks > 1) prefetch_b(regA, a.Wp1n, 1);
+    }
     __syncthreads();
     YN_TS();
 
@@ -1736,7 +1760,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 #undef YN_TS
 }
 
-static size_t unit_chain_lds(int bf, int BM, int BN) { return ((size_t)((BM * (bf + 2) + 3) & ~3) + (size_t)16 * BN * 2 + 10 * (size_t)bf) * sizeof(float); }
+static size_t unit_chain_lds(int bf, int BM, int BN) { return ((size_t)((BM * (bf + 2) + 3) & ~3) + (size_t)2 * 16 * BN * 2) * sizeof(float); }
 
 // false when no instantiated tile covers the shape (Npad must be one block column; bf % 4 == 0 or the 2-channel variant)
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s)
