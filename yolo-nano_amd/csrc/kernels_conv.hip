@@ -50,7 +50,8 @@ __device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
 // ---- GEMM epilogue shared by the tiled and the persistent kernel: bias + activation (+ concat/shuffle interleave with
 //      the pass-through half).  mbase / nbase = first row / column of this wave's 32 x (32*NT) accumulator block.
 template <int NT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane,
+                                              const float* pre_bias = nullptr)   // pre_bias[nt]: bias of this lane's column, loaded earlier
 {
     const int l31 = lane & 31, h = lane >> 5;
     if (vecO) {
@@ -60,7 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int ncol = nbase + nt * 32 + l31;            // this lane's column before the transpose
-            const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
+            const float bias = pre_bias ? pre_bias[nt] : (ncol < a.N ? a.bias[ncol] : 0.0f);
             const int nq = nbase + nt * 32 + (l31 & ~3);       // first column of the quad
             // the pass-through half of the four row groups: requested together, before the transposes (issued one by one
             // inside the `if (m < M)` below, each load is followed by a full wait)
@@ -106,7 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nbase + nt * 32 + l31;
         if (n >= a.N) continue;
-        const float bias = a.bias[n];
+        const float bias = pre_bias ? pre_bias[nt] : a.bias[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1524,6 +1525,15 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 #define YN_TS()
 #endif
     YN_TS();
+    // the two GEMM biases of this lane's columns: requested now, used tens of microseconds later (a dependent load at the start
+    // of an epilogue is a full memory latency with nothing to hide it)
+    float bias2[NT], bias1n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias1n[nt] = (a.Wp1n && n < bf) ? a.b1n[n] : 0.0f;
+    }
 
     // The pass-through half x1 is only needed by the interleave pass after the first GEMM: request it now, so that its
     // latency hides behind the depthwise conv and the GEMM.  Item it = (row, G consecutive j of the first half-row); the same
@@ -1696,7 +1706,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
     for (int nt = 0; nt < NT; ++nt) {
         const int n = wn * NT * 32 + nt * 32 + l31;
         if (n < bf) {
-            const float bias = a.b2[n];
+            const float bias = bias2[nt];
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + n] = apply_act(acc[nt][r] + bias, a.act2);
         }
@@ -1751,7 +1761,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
     YN_TS();
     GemmArgs e{};
     e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = a.M; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
-    gemm_epilogue<NT>(e, acc, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane);
+    gemm_epilogue<NT>(e, acc, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
 #ifdef YN_EXP_TIMING
     YN_TS();
     if (t == 0 && (blockIdx.x % 97) == 5)
