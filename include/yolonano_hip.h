@@ -67,9 +67,10 @@ int  yn_autotune(yn_handle* h, int enable);
  * a configuration that does not cover a layer's strides falls back to the heuristic one); index < 0 restores the autotuner. */
 int  yn_set_pw_config(yn_handle* h, int index);
 int  yn_pw_config_count(void);
-/* The stride-1 ShuffleV2 units run as one kernel each (depthwise -> pw2 -> concat+shuffle -> next unit's pw1; default on).
- * enable = 0 selects the three-kernels-per-unit path; both give bit-identical results (A/B measurements, tests). */
-int  yn_unit_chain(yn_handle* h, int enable);
+/* The stride-1 ShuffleV2 units run as one kernel each (depthwise -> pw2 -> concat+shuffle -> next unit's pw1).  mode 1
+ * (default): on the stages whose map is large enough for that to pay; 0: three kernels per unit everywhere; 2: one kernel per
+ * unit everywhere.  All three give bit-identical results (A/B measurements, tests). */
+int  yn_unit_chain(yn_handle* h, int mode);
 
 /* ---- weights ------------------------------------------------------------------------------- */
 /* nn.Module.load_state_dict (eval.py:127, benchmark.py:132): one call per state-dict entry, using

@@ -189,9 +189,10 @@ class Handle:
         """Testing aid: pin the pointwise GEMMs to one tile configuration (index < 0: back to the autotuner)."""
         self._ck(self.lib.yn_set_pw_config(self.h, int(index)), "yn_set_pw_config")
 
-    def unit_chain(self, on=True):
-        """One kernel per stride-1 ShuffleV2 unit (default) or the three-kernel path; bit-identical results."""
-        self._ck(self.lib.yn_unit_chain(self.h, int(bool(on))), "yn_unit_chain")
+    def unit_chain(self, mode=1):
+        """One kernel per stride-1 ShuffleV2 unit: 1 = where the map is large enough (default), 0 = never, 2 = always (True = 2);
+        bit-identical results either way."""
+        self._ck(self.lib.yn_unit_chain(self.h, 2 if mode is True else int(mode)), "yn_unit_chain")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

@@ -105,7 +105,7 @@ struct yn_handle {
     bool fuse_dwpw = false;        // measured slower than dw + pw as two kernels (halo staging dominates thin-K layers)
     std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
-    bool unit_chain = true;                        // stride-1 ShuffleV2 units as one kernel each (yn_unit_chain / YN_UNIT_CHAIN=0)
+    int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
     bool dwpw_tile = false;                        // other depthwise convs fused into their pointwise consumer (dwpw_tile_kernel): parity-tested, measured slower — YN_DWPW_TILE=1
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
@@ -447,6 +447,10 @@ bool run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int
     if (!h->unit_chain || h->fuse_unit || h->fuse_dwpw) return false;
     const int bf = C / 2;
     const long M = (long)B * H * W;
+    // A chain kernel's block runs its five phases back to back (17 / 27 / 47 us for bf = 58 / 116 / 232) whatever M is, so on
+    // small maps three latency-bound kernels with many small blocks win: bs=1 608x608 stage 3, M = 5 776: 29 vs 27 us; stage 4 at
+    // bs=32 416x416, M = 5 408: 47 vs 45 us.  unit_chain == 2 (tests) skips the size rule.
+    if (h->unit_chain != 2 && M < (bf <= 64 ? 8192 : (bf <= 128 ? 16384 : 32768))) return false;
     char nm[96];
     auto name = [&](int bi) { snprintf(nm, sizeof nm, "backbone.stage%d.%d", stage, bi); return std::string(nm); };
     {
@@ -754,7 +758,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->cur = h->stream;
     if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
     if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
-    if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) != 0;    // A/B switch for the one-kernel-per-unit chain
+    if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
@@ -840,7 +844,7 @@ int yn_set_pw_config(yn_handle* h, int index)
     return 0;
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
-int yn_unit_chain(yn_handle* h, int enable) { if (!h) return 1; h->unit_chain = enable != 0; return 0; }
+int yn_unit_chain(yn_handle* h, int mode) { if (!h) return 1; h->unit_chain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 
 int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 
