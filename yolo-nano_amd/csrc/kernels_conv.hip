@@ -1773,7 +1773,8 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 static size_t unit_chain_lds(int bf, int BM, int BN) { return ((size_t)((BM * (bf + 2) + 3) & ~3) + (size_t)2 * 16 * BN * 2) * sizeof(float); }
 
 // false when no instantiated tile covers the shape (Npad must be one block column; bf % 4 == 0 or the 2-channel variant)
-bool launch_unit_chain(const ChainArgs& a, hipStream_t s)
+// s == nullptr && dry: only answer whether an instantiated tile covers the shape (run_unit_chain asks before it launches anything)
+static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
 {
     if ((a.bf & 1) || a.Npad < a.bf) return false;
     const bool v4 = (a.bf & 3) == 0 && ((a.t1_ld | a.t1_off | a.x1_ld | a.x1_off | a.out_ld) & 3) == 0;
@@ -1783,6 +1784,8 @@ bool launch_unit_chain(const ChainArgs& a, hipStream_t s)
     {                                                                                                                  \
         constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
         const size_t lds = unit_chain_lds(a.bf, BM, BN);                                                               \
+        if (lds > 160 * 1024) return false;                                                                            \
+        if (dry) return true;                                                                                          \
         static bool attr = false;                                                                                      \
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain_kernel<WMv, WNv, NTv, Vv>),    \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
@@ -1800,6 +1803,8 @@ bool launch_unit_chain(const ChainArgs& a, hipStream_t s)
 #undef YN_UC
     return false;
 }
+bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
+bool unit_chain_covers(const ChainArgs& a) { return unit_chain_dispatch(a, nullptr, true); }
 
 // -------------------------------------------------------------------------------------------------
 // Depthwise 3x3 (stride 1 or 2) + the pointwise conv that consumes it, as one kernel: the first two phases of

@@ -441,22 +441,32 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
 
 // Units 1..R-1 of a stage as pw1(unit 1) + one unit_chain_kernel per unit.  oA = the stride-2 block's output [M][C] (unit 1's
 // input), oB = a second [M][C] buffer (holds the two [M][bf] pass-through halves in flight), tA / tB = [M][bf] scratch.
-// Returns false (nothing launched besides a harmless pw1) when the shape has no instantiated tile; *result = final [M][C].
-bool run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
+// Returns 0 (nothing launched) when the chain is off, the map is too small or no instantiated tile covers the shape; 1 when
+// the stage ran, *result = final [M][C]; -1 on an error (latched in the handle).
+int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
 {
-    if (!h->unit_chain || h->fuse_unit || h->fuse_dwpw) return false;
+    if (!h->unit_chain || h->fuse_unit || h->fuse_dwpw) return 0;
     const int bf = C / 2;
     const long M = (long)B * H * W;
     // A chain kernel's block runs its five phases back to back (17 / 27 / 47 us for bf = 58 / 116 / 232) whatever M is, so on
     // small maps three latency-bound kernels with many small blocks win: bs=1 608x608 stage 3, M = 5 776: 29 vs 27 us; stage 4 at
     // bs=32 416x416, M = 5 408: 47 vs 45 us.  unit_chain == 2 (tests) skips the size rule.
-    if (h->unit_chain != 2 && M < (bf <= 64 ? 8192 : (bf <= 128 ? 16384 : 32768))) return false;
+    if (h->unit_chain != 2 && M < (bf <= 64 ? 8192 : (bf <= 128 ? 16384 : 32768))) return 0;
     char nm[96];
     auto name = [&](int bi) { snprintf(nm, sizeof nm, "backbone.stage%d.%d", stage, bi); return std::string(nm); };
     {
         const Layer& pw1 = L(h, name(1) + ".b2.pw1");
         const Layer& dw = L(h, name(1) + ".b2.dw");
-        if (pw1.cin != bf || pw1.cout != bf || dw.stride != 1) return false;
+        if (pw1.cin != bf || pw1.cout != bf || dw.stride != 1) return 0;
+        // every unit of the stage must be covered by an instantiated tile BEFORE anything is launched: the chain consumes its
+        // input buffers, so there is no falling back half way (unit 1 reads x1 with ld = C, the others with ld = bf)
+        for (int first = 0; first < 2; ++first) {
+            ChainArgs q{};
+            q.t1_ld = bf; q.x1_ld = first ? C : bf; q.out_ld = bf; q.bf = bf; q.Npad = L(h, name(1) + ".b2.pw2").Npad; q.M = (int)M;
+            if (!unit_chain_covers(q)) return 0;
+            q.out_ld = C;
+            if (!unit_chain_covers(q)) return 0;
+        }
         run_pw(h, pw1, oA, C, bf, M, tA, bf, 0, nullptr, 0, 0);
     }
     float* pbuf[2] = {oB, oB + (size_t)M * bf};
@@ -483,17 +493,16 @@ bool run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int
         a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw2.Npad; a.M = (int)M;
         Bracket br(h, P + (last ? ".dw+pw2" : ".dw+pw2+pw1n"), 2.0 * M * bf * (9.0 + bf + (last ? 0.0 : (double)bf)),
                    4.0 * (4.0 * M * bf + (last ? 1.0 : 2.0) * bf * bf + 10.0 * bf));
-        if (!launch_unit_chain(a, h->cur)) {
+        if (!launch_unit_chain(a, h->cur)) {                 // cannot happen after the coverage check above
             br.cancel();
-            if (bi == 1) return false;
-            fail(h, "unit chain: tile coverage changed inside stage %d", stage);
-            return false;
+            fail(h, "unit chain: no tile for stage %d unit %d after the coverage check", stage, bi);
+            return -1;                                         // never fall back here: the chain has consumed its input buffers
         }
         x1 = a.out; x1_ld = bf;
         float* tmp = tA; tA = tB; tB = tmp;
     }
     *result = final_out;
-    return true;
+    return 1;
 }
 
 void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
@@ -638,7 +647,9 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         // stride-1 blocks (backbone/shufflenetv2.py:70-72; x1 = ch [0,bf) passes through, x2 = ch [bf,C)): one kernel per
         // unit, cut at the depthwise conv (unit_chain_kernel), after the first unit's pw1; else three kernels per unit
         const int R = STAGE_REP[si];
-        if (!(R > 1 && run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t1, t2, &o_cur))) {
+        const int chained = R > 1 ? run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t1, t2, &o_cur) : 0;
+        if (chained < 0) return 1;
+        if (!chained) {
             for (int bi = 1; bi < R; ++bi) {
                 snprintf(nm, sizeof nm, "backbone.stage%d.%d", si + 2, bi);
                 const std::string P = nm;

@@ -53,6 +53,7 @@ struct ChainArgs {
     int B, H, W, bf, Npad, M;
 };
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
+bool unit_chain_covers(const ChainArgs& a);     // same selection, nothing launched
 
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
 void set_last_kernel_name(const char* n);
