@@ -51,6 +51,7 @@ def parse():
                     help="independent inference streams per GPU (one handle + one HIP stream each); steps are dealt round-robin, "
                          "so one stream's NMS overlaps the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the bs=1 p50/p99 latency block of the default run")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--layers", action="store_true", help="also print the per-layer HIP-event timings (stderr)")
@@ -419,6 +420,31 @@ def main():
             pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
                         "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
 
+        # ---- the second half of BASELINE's metric: p50 latency at bs=1 (rank 0, after the timed region; benchmark.py:62-75 protocol:
+        #      launch, wait for the device, repeat), at the bench resolution and at BASELINE config 5's 608x608
+        latency = None
+        if rank == 0 and not args.no_latency:
+            latency = {}
+            for LS in sorted({S, 608}):
+                hl = capi.Handle(LS, args.classes, anchors, args.backbone, args.conf, args.nms, max_batch=1, device=dev, stream=stream)
+                hl.load_state_dict(sd)
+                hl.fold_bn()
+                gl = torch.Generator(device=dev); gl.manual_seed(99)
+                xl = torch.randn((1, 3, LS, LS), generator=gl, device=dev, dtype=torch.float32)
+                ol = hl.alloc_outputs(1)
+                for _ in range(60):
+                    hl.infer(xl, ol)
+                stream.synchronize()
+                lat = []
+                for _ in range(300):
+                    t1 = time.perf_counter()
+                    hl.infer(xl, ol)
+                    stream.synchronize()
+                    lat.append((time.perf_counter() - t1) * 1e3)
+                lat.sort()
+                latency["%dx%d" % (LS, LS)] = {"p50_ms": round(lat[len(lat) // 2], 4), "p99_ms": round(lat[int(len(lat) * 0.99)], 4), "calls": len(lat)}
+                hl.close()
+
         for hk in handles:
             hk.use_graph(False)
         ms_per_step = elapsed / args.steps * 1e3
@@ -439,6 +465,7 @@ def main():
                 "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
                 "pipeline": dict(pipeline or {}, frac_of_floor=round((pipeline["roofline_floor_ms"] / ms_per_step), 4) if pipeline else None),
                 "pcie_inclusive_images_per_s": round(pcie, 1) if pcie else None,
+                "latency_bs1_eager": latency,
                 "kernels": kernels,
             }
             print(json.dumps(line), flush=True)

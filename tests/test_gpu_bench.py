@@ -30,7 +30,7 @@ def _run(extra):
 
 
 def test_two_rank_inference_bench():
-    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--batch", "8"])
+    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-latency", "--batch", "8"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
 

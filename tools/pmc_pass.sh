@@ -3,7 +3,7 @@
 # Run on the GPU box from the repo root:  bash tools/pmc_pass.sh   -> gpurun_out/pmc_layers.{json,md}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 2 --streams 1 --launch eager --profile-steps 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 2 --streams 1 --launch eager --profile-steps 1 --no-cpu-baseline --no-latency"
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $R/gpurun_out/pl_$c
     rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pl_$c -o run --output-format csv -- python3 $R/bench.py $ARGS --dump-layers $R/gpurun_out/layers_$c.json > $R/gpurun_out/pl_$c.log 2>&1
