@@ -352,6 +352,30 @@ def test_infer_config2_bs32(hcoco, conf_t, nms_t):
     assert int(again[4][0].item()) == k
 
 
+def test_autotune_off_is_bit_identical(capi):
+    """yn_autotune(0): the static tile heuristic instead of the timed per-layer choice — a pure speed switch."""
+    sd = weights.make_state_dict("1.0x", 20)
+    x = dev(weights.make_input(2, 224, seed=5))
+    outs = []
+    for tune in (True, False):
+        h = capi.Handle(224, 20, arch.MULTI_ANCHOR_SIZE, "1.0x", 0.001, 0.5, max_batch=2)
+        h.autotune(tune)
+        h.load_state_dict(sd); h.fold_bn()
+        heads = [t.clone() for t in h.forward_raw(x)]
+        det = [t.clone() for t in h.infer(x)]
+        outs.append((heads, det))
+        assert h.N == arch.num_predictions(224)
+        h.close()
+    (ha, da), (hb, db) = outs
+    for u, v in zip(ha, hb):
+        assert torch.equal(u, v)
+    assert torch.equal(da[4], db[4])
+    for b in range(2):                                        # rows beyond the count are unspecified
+        k = int(da[4][b].item())
+        for i in range(4):
+            assert torch.equal(da[i][b, :k], db[i][b, :k])
+
+
 def test_three_handles_on_three_streams_agree(capi):
     """bench.py's default mode: three independent handles, one HIP stream each, steps dealt round-robin without host syncs in
     between.  Every handle must produce exactly what a lone handle produces for its input (bit-identical boxes, scores, classes,

@@ -534,7 +534,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 18; ++k) acc[k] = 0.0f;
         if (live) {
-            for (int u = blockIdx.x * rowsPer + rl; u < totalRuns; u += gridDim.x * rowsPer) {
+            // a block owns a CONTIGUOUS range of runs, and blocks are ordered XCD-contiguously: vertically adjacent runs share two
+            // of their three input rows, which a strided assignment fetched into every XCD's L2 (3x the tensor)
+            const int per = (totalRuns + (int)gridDim.x * rowsPer - 1) / ((int)gridDim.x * rowsPer);
+            const int ubase = (int)xcd_block(blockIdx.x, gridDim.x) * per * rowsPer;
+            for (int it = 0; it < per; ++it) {
+                const int u = ubase + it * rowsPer + rl;
+                if (u >= totalRuns) break;
                 const int row = u / runsPerRow, seg = u - row * runsPerRow;
                 const int b = row / Ho, oy = row - b * Ho;
                 const int ox0 = seg * RUN;
@@ -602,6 +608,7 @@ void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B
     static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 128;
     if (G > gmax) G = gmax;
     if (G < 1) G = 1;
+    G = (int)xcd_grid((unsigned)G);                         // multiple of 8 for xcd_block
     const bool vec = !(C & 1) && !(x_ld & 1) && !(x_off & 1);
 #define YN_DWW(ST, V) hipLaunchKernelGGL((dw_wgrad_kernel<ST, V>), dim3(G), dim3(256), 0, s, dy, x, x_ld, x_off, B, H, W, C, dw, slot_stride, L.lanesC)
     if (stride == 1) { if (vec) YN_DWW(1, true); else YN_DWW(1, false); }
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restric
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int cpn = C >> 1;
     const int total = B * H * W * cpn;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;     // XCD-contiguous (yn_internal.h): stencil neighbours share an L2
     if (i >= total) return;
     const int cp = i % cpn;
     int p = i / cpn;
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restric
 void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s)
 {
     const long total = (long)B * H * W * (C >> 1);
-    hipLaunchKernelGGL(dw_dgrad_s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, w, B, H, W, C, dx, dx_ld, dx_off, accumulate);
+    hipLaunchKernelGGL(dw_dgrad_s2_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, w, B, H, W, C, dx, dx_ld, dx_off, accumulate);
 }
 
 // ---- stem weight gradient: dW[co][ci][ky][kx] += sum_p dY[p][co] * x_nchw[b][ci][2oy-1+ky][2ox-1+kx]
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int cpn = C >> 1;
     const int total = B * H * W * cpn;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;     // XCD-contiguous (yn_internal.h): stencil neighbours share an L2
     if (i >= total) return;
     const int cp = i % cpn;
     int p = i / cpn;
@@ -823,7 +830,7 @@ void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, in
 void launch_maxpool_bwd(const float* dy, const int32_t* idx, int B, int H, int W, int C, float* dx, hipStream_t s)
 {
     long blocks = ((long)B * H * W * (C >> 1) + 255) / 256;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, idx, B, H, W, C, dx);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, s, dy, idx, B, H, W, C, dx);
 }
 
 // ---- element-wise glue --------------------------------------------------------------------------------
