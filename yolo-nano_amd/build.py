@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libyolonano_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_unit.hip", []), ("yn_api.hip", [])]
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_unit.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
           "-Wno-pass-failed"]
 
@@ -39,7 +39,7 @@ def _compile(item):
 def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in _deps()):
         return OUT
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     subprocess.check_call(cmd)

@@ -7,122 +7,19 @@
 //   dwconv3x3_kernel   depthwise 3x3 (stride 1/2), one thread per (pixel, channel pair)
 //   stem_kernel        3->24 3x3 stride-2 conv reading NCHW input, writing NHWC
 //   maxpool_kernel     3x3 stride-2 max pool
+//   (+ gemm_direct_kernel, gemm_persist_kernel, conv3x3_halo*_kernel, dwpw_halo_kernel, stem_pool_kernel: see their headers;
+//    the multi-layer tile kernels live in kernels_chain.hip / kernels_unit.hip, the shared device helpers in yn_device.h)
 //
 // Reference semantics: backbone/shufflenetv2.py:31-78,109-116, utils/modules.py:8-18,
 // models/yolo_nano.py:286-301 — with BatchNorm folded into the weights (utils/fuse_conv_bn.py:6-22).
 #include "yn_internal.h"
+#include "yn_device.h"
 
 namespace ynk {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static thread_local const char* g_last_kernel = "";
 const char* last_kernel_name() { return g_last_kernel; }
 void set_last_kernel_name(const char* n) { g_last_kernel = n; }
-
-__device__ __forceinline__ float apply_act(float v, int act)
-{
-    if (act == 1) return v > 0.0f ? v : 0.0f;
-    if (act == 2) return v > 0.0f ? v : 0.1f * v;
-    return v;
-}
-
-// Loads whose result is only sometimes wanted are issued UNCONDITIONALLY at a clamped (always legal) address and the
-// unwanted values are zeroed with a bit mask the optimiser cannot see through.  `if (ok) v = load` — and `ok ? load : 0`,
-// and `load & mask` with a visible mask — all compile to a branch around the load followed by s_waitcnt vmcnt(0), i.e.
-// one full memory latency per load instead of one per batch of loads.
-__device__ __forceinline__ unsigned opaque_mask(bool ok)
-{
-    unsigned mk = ok ? 0xffffffffu : 0u;
-    asm volatile("" : "+v"(mk));
-    return mk;
-}
-__device__ __forceinline__ float2 vmask(float2 v, unsigned mk)
-{
-    return make_float2(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk));
-}
-__device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
-{
-    return make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
-                       __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
-}
-
-// ---- GEMM epilogue shared by the tiled and the persistent kernel: bias + activation (+ concat/shuffle interleave with
-//      the pass-through half).  mbase / nbase = first row / column of this wave's 32 x (32*NT) accumulator block.
-template <int NT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane,
-                                              const float* pre_bias = nullptr)   // pre_bias[nt]: bias of this lane's column, loaded earlier
-{
-    const int l31 = lane & 31, h = lane >> 5;
-    if (vecO) {
-        // 16-byte stores: an accumulator quad (regs 4g..4g+3 = 4 consecutive rows, lanes 4q'..4q'+3 = 4 consecutive
-        // columns) is transposed inside its 4 lanes with two xor-shuffles, so lane j ends up with row j x 4 columns.
-        const int j = lane & 3;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int ncol = nbase + nt * 32 + l31;            // this lane's column before the transpose
-            const float bias = pre_bias ? pre_bias[nt] : (ncol < a.N ? a.bias[ncol] : 0.0f);
-            const int nq = nbase + nt * 32 + (l31 & ~3);       // first column of the quad
-            // the pass-through half of the four row groups: requested together, before the transposes (issued one by one
-            // inside the `if (m < M)` below, each load is followed by a full wait)
-            float4 pv[4];
-            if (a.pass) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m = mbase + 8 * g + 4 * h + j;
-                    const bool ok = m < a.M && nq < a.N;
-                    pv[g] = *reinterpret_cast<const float4*>(a.pass + (size_t)(ok ? m : 0) * a.pass_ld + a.pass_off + (ok ? nq : 0));
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v0 = apply_act(acc[nt][4 * g + 0] + bias, a.act), v1 = apply_act(acc[nt][4 * g + 1] + bias, a.act);
-                float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
-                {   // 2x2 blocks
-                    const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
-                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
-                    if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
-                }
-                {   // 4x4
-                    const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
-                    const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
-                    if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
-                }
-                const int m = mbase + 8 * g + 4 * h + j;
-                if (m < a.M && nq < a.N) {
-                    if (a.pass) {
-                        const float4 p = pv[g];
-                        float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
-                        *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
-                        *reinterpret_cast<float4*>(o + 4) = make_float4(p.z, v2, p.w, v3);
-                    } else {
-                        *reinterpret_cast<float4*>(a.out + (size_t)m * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = nbase + nt * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias = pre_bias ? pre_bias[nt] : a.bias[n];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = mbase + row;
-            if (m >= a.M) continue;
-            const float v = apply_act(acc[nt][r] + bias, a.act);
-            if (a.pass) {
-                const float p = a.pass[(size_t)m * a.pass_ld + a.pass_off + n];
-                *reinterpret_cast<float2*>(a.out + (size_t)m * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
-            } else {
-                a.out[(size_t)m * a.out_ld + a.out_off + n] = v;
-            }
-        }
-    }
-}
 
 // -------------------------------------------------------------------------------------------------
 // GEMM convolution.  Block = 4 waves laid out WM x WN; each wave owns a 32 x (32*NT) output tile and
@@ -1370,21 +1267,6 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
 // the channel pairs of one pixel and then the next pixel, so loads and stores are fully coalesced in
 // NHWC.  The nine taps of neighbouring pixels overlap in L1/L2.
 // -------------------------------------------------------------------------------------------------
-template <int V> struct VecT;
-template <> struct VecT<2> { typedef float2 type; };
-template <> struct VecT<4> { typedef float4 type; };
-// explicit fused multiply-adds: with `acc += v * w` the compiler is free to contract or not per instance (it split the first
-// tap into v_pk_mul + v_add in one kernel and fused it in another), and the depthwise conv must round identically wherever
-// it is evaluated (dwconv3x3_kernel, unit_chain_kernel)
-__device__ __forceinline__ void vfma(float2& acc, const float2 v, const float2 w) { acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.y, acc.y); }
-__device__ __forceinline__ void vfma(float4& acc, const float4 v, const float4 w)
-{
-    acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.y, acc.y);
-    acc.z = __builtin_fmaf(v.z, w.z, acc.z); acc.w = __builtin_fmaf(v.w, w.w, acc.w);
-}
-__device__ __forceinline__ float2 vact(float2 v, int act) { return make_float2(apply_act(v.x, act), apply_act(v.y, act)); }
-__device__ __forceinline__ float4 vact(float4 v, int act) { return make_float4(apply_act(v.x, act), apply_act(v.y, act), apply_act(v.z, act), apply_act(v.w, act)); }
-
 // Depthwise 3x3, one thread = VEC channels x a RUN of R horizontally adjacent output pixels.  The whole input window
 // of the run (3 rows x (R+2) or (2R+1) columns) is fetched with unconditional loads at clamped addresses before any of
 // it is used — with `if (inside) load` the compiler emits one branch + one vmcnt(0) wait per tap and the kernel sits at
@@ -1451,554 +1333,6 @@ void launch_dw(const DwArgs& a, hipStream_t s)
         else    { if (blocks_for(2, 4) >= 1024) YN_DW(2, 2, 4) else YN_DW(2, 2, 2) }
     }
 #undef YN_DW
-}
-
-// -------------------------------------------------------------------------------------------------
-// Stride-1 ShuffleV2 units as a chain of ONE kernel per unit (backbone/shufflenetv2.py:53-63, 70-72, 14-28).
-//
-//   unit i:   x = [x1 | x2],  t = relu(pw1_i(x2)),  y = relu(pw2_i(dw_i(t))),  out = shuffle(cat(x1, y))
-//
-// Cutting the chain at the unit INPUT needs pw1 on a halo (shuffle_unit_kernel: slower than three kernels).  Cutting it at the
-// depthwise conv does not: everything after dw_i is pixel-local, including the next unit's pw1, because the shuffle makes
-// x2_{i+1} = interleave(x1[bf/2:], y[bf/2:]) of the SAME pixel.  So the kernel of unit i is
-//   1. dw_i on the block's BM pixels, read from global (t_i, neighbours through L1/L2; XCD-contiguous tiles keep them in one
-//      L2), each output computed once -> LDS tile T [BM][bf+2];
-//   2. GEMM y = relu(T * W2 + b2) (f32 MFMA, A fragments from T, W2 streamed through one LDS buffer with register prefetch);
-//   3. y -> T (in place, after a barrier);  interleave pass: out[:, 0:bf] = interleave(x1[0:bf/2], y[0:bf/2]) -> global (the
-//      next unit's pass-through half — the only part of `out` a later kernel reads), x2' = interleave(x1[bf/2:], y[bf/2:])
-//      -> registers -> T;  (last unit of a stage: the whole `out` row goes to global and the kernel ends here)
-//   4. GEMM t_{i+1} = relu(T * W1' + b1') -> global.
-// Per unit: 1 launch instead of 3, 4 tensors of [M][bf] through memory instead of 8, no halo recompute.  All sums run in the
-// order of the separate kernels (same fma chain in the depthwise conv, same k order in the GEMMs): bit-identical results.
-// Measured (tools/chain_timing.sh, stage 3, M = 21 632, bf = 116; cycles per block): depthwise phase 20 k, GEMM 13.1 k each (two
-// co-resident blocks share the MFMA pipe: 2 x 7.4 k of MFMA issue), y->T 5.5 k, interleave 3.2 k, epilogue 5.6 k = 39 us per unit
-// against 46 us for the three kernels (stage 2: 42 vs 66, stage 4: 47 vs 45).  All blocks of the launch are resident at once and run their phases in lockstep, so the depthwise phase is the
-// whole chip fetching its ~35 MB at the same time (bandwidth-bound, MFMAs idle) and the GEMM phases leave the memory system
-// idle; overlapping them needs a persistent block that requests tile i+1's window (direct-to-LDS loads) while tile i is in
-// its GEMMs — the next step for this kernel.  (Tried: the GEMM weights register-direct from L2 instead of through LDS, which
-// removes the chunk barriers — GEMM phase 13.7 k -> 22 k cycles: the 8-byte per-lane weight loads are slower than the barriers.)
-// -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT, int V>
-__global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
-{
-    typedef typename VecT<V>::type vec;
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KP = 16, BS = BN * 2, B_PER = KP * BN / 512, G = V / 2;
-    constexpr int MAXB = (BM * (BN / (2 * G)) + 255) / 256;     // interleave items per thread and half (upper bound: bf <= BN)
-    static_assert(WM * WN == 4 && B_PER >= 1, "4 waves");
-    extern __shared__ __attribute__((aligned(16))) float uc_smem[];
-    const int bf = a.bf, CS = bf + 2, W = a.W, H = a.H, HW = H * W;
-    float* T = uc_smem;                                      // [BM][CS]
-    float* Bs = uc_smem + ((BM * CS + 3) & ~3);              // [2][KP][BS]
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = wave % WM, wn = wave / WM;
-    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
-    if (m0 >= a.M) return;
-    const int nchunks = (bf + 2 * KP - 1) / (2 * KP), kp_total = bf >> 1;
-
-    // GEMM weights: chunks of KP k-pairs through TWO LDS buffers, requested TWO chunks ahead into two register sets, so a
-    // chunk's loads have two chunk-times (~4 k cycles) to arrive and there is one barrier per chunk.
-    float4 regA[B_PER], regB[B_PER];
-    auto prefetch_b = [&](float4 (&reg)[B_PER], const float* Wp, int c) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            const int kpg = c * KP + kp;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kpg < kp_total) v = *reinterpret_cast<const float4*>(Wp + ((size_t)kpg * a.Npad + c4 * 2) * 2);
-            reg[i] = v;
-        }
-    };
-    auto stage_b = [&](float4 (&reg)[B_PER], int buf) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = reg[i];
-        }
-    };
-#ifdef YN_EXP_TIMING
-    long long TS[8]; int tsn = 0;
-#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
-#else
-#define YN_TS()
-#endif
-    YN_TS();
-    // the two GEMM biases of this lane's columns: requested now, used tens of microseconds later (a dependent load at the start
-    // of an epilogue is a full memory latency with nothing to hide it)
-    float bias2[NT], bias1n[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = wn * NT * 32 + nt * 32 + l31;
-        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
-        bias1n[nt] = (a.Wp1n && n < bf) ? a.b1n[n] : 0.0f;
-    }
-
-    // The pass-through half x1 is only needed by the interleave pass after the first GEMM: request it now, so that its
-    // latency hides behind the depthwise conv and the GEMM.  Item it = (row, G consecutive j of the first half-row); the same
-    // item also owns the j + bf/2 of the second half-row (xg / xl).
-    const int hipr = bf / (2 * G), jhi = bf >> 1;          // items per half row; first j of the second half (bf/2 is a multiple of G)
-    float2 xg[MAXB], xl[MAXB];                               // G == 1 uses .x only
-    auto x1_prefetch = [&]() {
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int it = t + 256 * i;
-        const int r = it / hipr, j0 = (it - r * hipr) * G;
-        const int m = m0 + r < a.M ? m0 + r : a.M - 1;
-        xg[i] = make_float2(0.0f, 0.0f); xl[i] = xg[i];
-        if (it < BM * hipr) {
-            const float* px = a.x1 + (size_t)m * a.x1_ld + a.x1_off + j0;
-            if constexpr (G == 2) {
-                xg[i] = *reinterpret_cast<const float2*>(px);
-                xl[i] = *reinterpret_cast<const float2*>(px + jhi);
-            } else {
-                xg[i].x = px[0];
-                xl[i].x = px[jhi];
-            }
-        }
-    }
-    };
-
-    // ---- 1. depthwise 3x3 of the block's pixels -> T ---------------------------------------------------------
-    {
-        const int cgn = bf / V, ppl = 256 / cgn;
-        const int cg = t % cgn, pl = t / cgn, c = cg * V;
-        const bool worker = pl < ppl;                        // 256 is not a multiple of the channel groups: a few threads idle
-        {
-            // Thread = (channel group, runs of R consecutive flat pixels).  Neighbour (dy, dx) of flat pixel p is flat pixel
-            // p + dy*W + dx wherever it exists, so the 3 x (R+2) window of a run is three runs of consecutive pixels: 18 loads
-            // (one batch, no masks: addresses clamped into the tensor) feed R = 4 outputs; image borders are handled when the
-            // window is used (select 0 per output and tap).
-            constexpr int R = 4;
-            auto issue = [&](int run, vec (&win)[3][R + 2]) {
-                const int q0 = m0 + run * R - 1;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int i = 0; i < R + 2; ++i) {
-                        int q = q0 + (dy - 1) * W + i;
-                        q = q < 0 ? 0 : (q >= a.M ? a.M - 1 : q);
-                        win[dy][i] = *reinterpret_cast<const vec*>(a.t1 + (size_t)q * a.t1_ld + a.t1_off + c);
-                    }
-            };
-            // the nine taps and the bias of this thread's channel group live in registers (the kernel runs at two waves per SIMD
-            // either way; from LDS they cost 72 ds_read_b128 per thread)
-            vec w[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const vec*>(a.wdw + k * bf + c);
-            const vec bias = *reinterpret_cast<const vec*>(a.bdw + c);
-            auto finish = [&](int run, vec (&win)[3][R + 2]) {
-                const int mrun = m0 + run * R;
-                const int rem0 = (mrun < a.M ? mrun : m0) % HW;  // one division per run; the R pixels advance by one column
-                int y = rem0 / W, x = rem0 - y * W;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int r = run * R + i;
-                    const bool live = mrun + i < a.M;
-                    const bool yk[3] = {live && y >= 1, live, live && y + 1 < H};
-                    const bool xk[3] = {x >= 1, true, x + 1 < W};
-                    vec acc = bias;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const bool ok = yk[ky] && xk[kx];
-                            vec v = win[ky][i + kx];
-                            if constexpr (V == 4) v = make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
-                            else v = make_float2(ok ? v.x : 0.0f, ok ? v.y : 0.0f);
-                            vfma(acc, v, w[ky * 3 + kx]);
-                        }
-                    acc = vact(acc, a.dw_act);
-                    float* d = T + r * CS + c;                   // row stride CS*4 bytes is only 8-byte aligned
-                    if constexpr (V == 4) {
-                        *reinterpret_cast<float2*>(d) = make_float2(acc.x, acc.y);
-                        *reinterpret_cast<float2*>(d + 2) = make_float2(acc.z, acc.w);
-                    } else {
-                        *reinterpret_cast<float2*>(d) = acc;
-                    }
-                    if (++x == W) { x = 0; if (++y == H) y = 0; }
-                }
-            };
-            // One window in flight per thread: the latency is hidden by the other blocks of the CU (a second window in flight
-            // costs 72 registers and an occupancy step: measured 2x slower).
-            vec win[3][R + 2];
-            // request order = completion order (vmcnt is in-order): the first window, then the GEMM's first weight chunk, then x1
-            if (worker) issue(pl, win);
-            prefetch_b(regA, a.Wp2, 0);
-            x1_prefetch();
-            stage_b(regA, 0);                                // GEMM entry state: chunk 0 in buffer 0, chunk 1 requested into regA
-            if (nchunks > 1) prefetch_b(regA, a.Wp2, 1);
-            if (worker) {
-                for (int run = pl; run < BM / R; run += ppl) {
-                    finish(run, win);
-                    if (run + ppl < BM / R) issue(run + ppl, win);
-                }
-            }
-        }
-        for (int r = t; r < BM; r += 256) *reinterpret_cast<float2*>(T + r * CS + bf) = make_float2(0.0f, 0.0f);   // pad columns (K tail)
-    }
-    __syncthreads();
-    YN_TS();
-
-    // ---- GEMM: acc = T[BM][bf] * Wp (chunk 0 already staged in Bs) --------------------------------------------
-    f32x16 acc[NT];
-    auto mfma_chunk = [&](int c, int buf) {
-        const int krem = bf - c * 2 * KP;
-        const int nq = krem >= 2 * KP ? KP / 2 : ((krem + 3) >> 2);
-        const float* Ab = T + (wm * 32 + l31) * CS + c * 2 * KP + 2 * h;
-        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2 + h * BS;
-        float2 av = *reinterpret_cast<const float2*>(Ab);
-        float2 bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-#pragma unroll
-        for (int q = 0; q < KP / 2; ++q) {
-            if (q < nq) {                                   // wave-uniform
-                float2 av_n = av, bv_n[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-                if (q + 1 < nq) {
-                    av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                av = av_n;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-            }
-        }
-    };
-    // entry state: chunk 0 staged in buffer 0 (visible), chunk 1 requested into regA
-    auto gemm = [&](const float* Wp) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
-        for (int c = 0; c < nchunks; c += 2) {
-            if (c + 2 < nchunks) prefetch_b(regB, Wp, c + 2);
-            mfma_chunk(c, 0);
-            if (c + 1 >= nchunks) break;
-            stage_b(regA, 1);                               // buffer 1 was last read two chunks ago, before the previous barrier
-            __syncthreads();
-            if (c + 3 < nchunks) prefetch_b(regA, Wp, c + 3);
-            mfma_chunk(c + 1, 1);
-            if (c + 2 < nchunks) {
-                stage_b(regB, 0);
-                __syncthreads();
-            }
-        }
-    };
-    gemm(a.Wp2);
-    YN_TS();
-    if (a.Wp1n) prefetch_b(regA, a.Wp1n, 0);
-    __syncthreads();                                        // all waves are done reading T and Bs
-
-    // ---- 3. y = act(acc + b2) -> T (in place) -----------------------------------------------------------------
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = wn * NT * 32 + nt * 32 + l31;
-        if (n < bf) {
-            const float bias = bias2[nt];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + n] = apply_act(acc[nt][r] + bias, a.act2);
-        }
-    }
-    if (a.Wp1n) {
-        stage_b(regA, 0);
-        if (nchunks > 1) prefetch_b(regA, a.Wp1n, 1);
-    }
-    __syncthreads();
-    YN_TS();
-
-    // interleave pass.  Item = (row, G consecutive j): (x1[j], y[j], ...) -> 2G consecutive output channels 2j..
-    // First half-row (j < bf/2) -> global; second half-row -> global too (last unit: whole `out` row) or -> x2' in T.
-    float2 yl[MAXB];
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int it = t + 256 * i;
-        const int r = it / hipr, j0 = (it - r * hipr) * G, m = m0 + r;
-        yl[i] = make_float2(0.0f, 0.0f);
-        if (it < BM * hipr) {
-            float2 y = make_float2(0.0f, 0.0f);
-            if constexpr (G == 2) { y = *reinterpret_cast<const float2*>(T + r * CS + j0); yl[i] = *reinterpret_cast<const float2*>(T + r * CS + jhi + j0); }
-            else { y.x = T[r * CS + j0]; yl[i].x = T[r * CS + jhi + j0]; }
-            if (m < a.M) {
-                float* o = a.out + (size_t)m * a.out_ld + 2 * j0;
-                if constexpr (G == 2) {
-                    *reinterpret_cast<float4*>(o) = make_float4(xg[i].x, y.x, xg[i].y, y.y);
-                    if (!a.Wp1n) *reinterpret_cast<float4*>(o + 2 * jhi) = make_float4(xl[i].x, yl[i].x, xl[i].y, yl[i].y);
-                } else {
-                    *reinterpret_cast<float2*>(o) = make_float2(xg[i].x, y.x);
-                    if (!a.Wp1n) *reinterpret_cast<float2*>(o + 2 * jhi) = make_float2(xl[i].x, yl[i].x);
-                }
-            }
-        }
-    }
-    if (!a.Wp1n) return;
-    __syncthreads();                                        // every read of y is done: T may be overwritten
-#pragma unroll
-    for (int i = 0; i < MAXB; ++i) {                        // ... and x2' = interleave(x1[bf/2:], y[bf/2:]) into T
-        const int it = t + 256 * i;
-        const int r = it / hipr, c0 = 2 * (it - r * hipr) * G;
-        if (it < BM * hipr) {
-            *reinterpret_cast<float2*>(T + r * CS + c0) = make_float2(xl[i].x, yl[i].x);
-            if constexpr (G == 2) *reinterpret_cast<float2*>(T + r * CS + c0 + 2) = make_float2(xl[i].y, yl[i].y);
-        }
-    }
-    __syncthreads();
-
-    YN_TS();
-    // ---- 4. the next unit's pw1 on x2' -> global ------------------------------------------------------------------
-    gemm(a.Wp1n);
-    YN_TS();
-    GemmArgs e{};
-    e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = a.M; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
-    gemm_epilogue<NT>(e, acc, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
-#ifdef YN_EXP_TIMING
-    YN_TS();
-    if (t == 0 && (blockIdx.x % 97) == 5)
-        printf("chain bf %d blk %d start %lld dw %lld gemm1 %lld y %lld interleave %lld gemm2 %lld epi %lld\n", bf, (int)blockIdx.x, TS[0], TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2], TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5]);
-#endif
-#undef YN_TS
-}
-
-static size_t unit_chain_lds(int bf, int BM, int BN) { return ((size_t)((BM * (bf + 2) + 3) & ~3) + (size_t)2 * 16 * BN * 2) * sizeof(float); }
-
-// false when no instantiated tile covers the shape (Npad must be one block column; bf % 4 == 0 or the 2-channel variant)
-// s == nullptr && dry: only answer whether an instantiated tile covers the shape (run_unit_chain asks before it launches anything)
-static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
-{
-    if ((a.bf & 1) || a.Npad < a.bf) return false;
-    const bool v4 = (a.bf & 3) == 0 && ((a.t1_ld | a.t1_off | a.x1_ld | a.x1_off | a.out_ld) & 3) == 0;
-    if (!v4 && (((a.t1_ld | a.t1_off | a.out_ld) & 1) != 0 || 256 / (a.bf / 2) < 1)) return false;
-    if (v4 && 256 / (a.bf / 4) < 1) return false;
-#define YN_UC(WMv, WNv, NTv, Vv)                                                                                       \
-    {                                                                                                                  \
-        constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
-        const size_t lds = unit_chain_lds(a.bf, BM, BN);                                                               \
-        if (lds > 160 * 1024) return false;                                                                            \
-        if (dry) return true;                                                                                          \
-        static bool attr = false;                                                                                      \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain_kernel<WMv, WNv, NTv, Vv>),    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        g_last_kernel = "unit_chain_kernel<" #WMv "," #WNv "," #NTv "," #Vv ">";                                       \
-        hipLaunchKernelGGL((unit_chain_kernel<WMv, WNv, NTv, Vv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
-        return true;                                                                                                   \
-    }
-    const int tiles64 = (a.M + 63) / 64;
-    if (a.Npad == 64 && !v4) YN_UC(2, 2, 1, 2)
-    if (a.Npad == 64 && v4) YN_UC(2, 2, 1, 4)
-    if (a.Npad == 128 && v4) YN_UC(2, 2, 2, 4)                 // (a 32-row tile, <1,4,1,4>, measured the same: 42.4 vs 41.4 us)
-    if (a.Npad == 256 && v4) { if (tiles64 >= 256) YN_UC(2, 2, 4, 4) else YN_UC(1, 4, 2, 4) }
-    if (a.Npad == 32 && v4) YN_UC(4, 1, 1, 4)
-    if (a.Npad == 96 && v4) YN_UC(4, 1, 3, 4)
-#undef YN_UC
-    return false;
-}
-bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
-bool unit_chain_covers(const ChainArgs& a) { return unit_chain_dispatch(a, nullptr, true); }
-
-// -------------------------------------------------------------------------------------------------
-// Depthwise 3x3 (stride 1 or 2) + the pointwise conv that consumes it, as one kernel: the first two phases of
-// unit_chain_kernel with the GEMM's ordinary epilogue (bias, activation, optional concat+shuffle with a pass-through
-// tensor).  Each depthwise output is computed ONCE from global memory into the LDS tile T [BM][K+2] (dwpw_halo_kernel, the
-// earlier attempt, recomputed it per MFMA fragment from an LDS halo and lost to two kernels); the depthwise activation never
-// reaches memory.  Used for branch1 / the tail of branch2 of the stride-2 ShuffleV2 units and for the heads' dw -> pw pairs.
-// Same fma chain and same k order as dwconv3x3_kernel + gemm_conv_kernel: bit-identical.
-// -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT, int V, int STRIDE>
-__global__ __launch_bounds__(256, 2) void dwpw_tile_kernel(GemmArgs a)
-{
-    typedef typename VecT<V>::type vec;
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KP = 16, BS = BN * 2, B_PER = KP * BN / 512;
-    static_assert(WM * WN == 4 && B_PER >= 1, "4 waves");
-    extern __shared__ __attribute__((aligned(16))) float dt_smem[];
-    const int K = a.K, CS = K + 2, W = a.W, H = a.H;
-    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1, HWo = Ho * Wo;
-    float* T = dt_smem;                                      // [BM][CS]
-    float* Bs = dt_smem + ((BM * CS + 3) & ~3);              // [KP][BS]
-    float* Wd = Bs + KP * BS;                                // [10][K]
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = wave % WM, wn = wave / WM;
-    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
-    if (m0 >= a.M) return;
-    const int nchunks = (K + 2 * KP - 1) / (2 * KP), kp_total = K >> 1;
-
-    float4 b_reg[B_PER];
-    auto prefetch_b = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            const int kpg = c * KP + kp;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kpg < kp_total) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + c4 * 2) * 2);
-            b_reg[i] = v;
-        }
-    };
-    auto stage_b = [&]() {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + kp * BS + c4 * 4) = b_reg[i];
-        }
-    };
-    prefetch_b(0);
-
-    // ---- depthwise conv of the block's BM output pixels -> T ---------------------------------------------------
-    {
-        const int cgn = K / V, ppl = 256 / cgn;
-        const int cg = t % cgn, pl = t / cgn, c = cg * V;
-        for (int i = t; i < 10 * K; i += 256) Wd[i] = i < 9 * K ? a.dw_w[i] : a.dw_b[i - 9 * K];
-        const bool worker = pl < ppl;
-        constexpr int U = 2;                                 // output pixels per batch of loads (18 loads in flight)
-        vec col[U][9];
-        auto issue = [&](int r0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * ppl;
-                const int m = m0 + r;
-                const bool live = r < BM && m < a.M;
-                const int mc = live ? m : m0;
-                const int b = mc / HWo, rem = mc - b * HWo;
-                const int oy = rem / Wo, ox = rem - oy * Wo;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = oy * STRIDE - 1 + ky;
-                    const bool yok = live && iy >= 0 && iy < H;
-                    const float* row = a.in + ((size_t)(b * H + (yok ? iy : 0)) * W) * a.in_ld + a.in_off + c;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = ox * STRIDE - 1 + kx;
-                        const unsigned mk = opaque_mask(yok && ix >= 0 && ix < W);
-                        col[u][ky * 3 + kx] = vmask(*reinterpret_cast<const vec*>(row + (size_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * a.in_ld), mk);
-                    }
-                }
-            }
-        };
-        auto finish = [&](int r0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * ppl;
-                if (r < BM) {
-                    vec acc = *reinterpret_cast<const vec*>(Wd + 9 * K + c);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) vfma(acc, col[u][k], *reinterpret_cast<const vec*>(Wd + k * K + c));
-                    acc = vact(acc, a.dw_act);
-                    float* d = T + r * CS + c;               // row stride CS*4 bytes is only 8-byte aligned
-                    if constexpr (V == 4) {
-                        *reinterpret_cast<float2*>(d) = make_float2(acc.x, acc.y);
-                        *reinterpret_cast<float2*>(d + 2) = make_float2(acc.z, acc.w);
-                    } else {
-                        *reinterpret_cast<float2*>(d) = acc;
-                    }
-                }
-            }
-        };
-        if (worker) issue(pl);
-        stage_b();
-        __syncthreads();                                     // Wd visible
-        if (worker) {
-            for (int r0 = pl; r0 < BM; r0 += ppl * U) {
-                finish(r0);
-                if (r0 + ppl * U < BM) issue(r0 + ppl * U);
-            }
-        }
-        for (int r = t; r < BM; r += 256) *reinterpret_cast<float2*>(T + r * CS + K) = make_float2(0.0f, 0.0f);   // pad columns (K tail)
-    }
-    __syncthreads();
-
-    // ---- pointwise GEMM from the LDS tile ------------------------------------------------------------------------
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) prefetch_b(c + 1);
-        const int krem = K - c * 2 * KP;
-        const int nq = krem >= 2 * KP ? KP / 2 : ((krem + 3) >> 2);
-        const float* Ab = T + (wm * 32 + l31) * CS + c * 2 * KP + 2 * h;
-        const float* Bb = Bs + (wn * NT * 32 + l31) * 2 + h * BS;
-        float2 av = *reinterpret_cast<const float2*>(Ab);
-        float2 bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-#pragma unroll
-        for (int q = 0; q < KP / 2; ++q) {
-            if (q < nq) {                                   // wave-uniform
-                float2 av_n = av, bv_n[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-                if (q + 1 < nq) {
-                    av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                av = av_n;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-            }
-        }
-        if (c + 1 < nchunks) {
-            __syncthreads();
-            stage_b();
-            __syncthreads();
-        }
-    }
-    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
-    gemm_epilogue<NT>(a, acc, m0 + wm * 32, wn * NT * 32, vecO, lane);
-}
-
-static size_t dwpw_tile_lds(int K, int BM, int BN) { return ((size_t)((BM * (K + 2) + 3) & ~3) + (size_t)16 * BN * 2 + 10 * (size_t)K) * sizeof(float); }
-
-// false when no instantiated tile covers the shape (Npad must be one block column)
-bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s)
-{
-    const int stride = a.dw_stride == 2 ? 2 : 1;
-    if ((a.K & 1) || a.K > 256) return false;
-    const bool v4 = (a.K & 3) == 0 && ((a.in_ld | a.in_off) & 3) == 0;
-    if (!v4 && ((a.in_ld | a.in_off) & 1)) return false;
-#define YN_DT(WMv, WNv, NTv, Vv, Sv)                                                                                   \
-    {                                                                                                                  \
-        constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
-        const size_t lds = dwpw_tile_lds(a.K, BM, BN);                                                                 \
-        static bool attr = false;                                                                                      \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        g_last_kernel = "dwpw_tile_kernel<" #WMv "," #WNv "," #NTv "," #Vv "," #Sv ">";                                \
-        hipLaunchKernelGGL((dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
-        return true;                                                                                                   \
-    }
-    if (stride == 2) {
-        if (a.Npad == 64 && !v4) YN_DT(2, 2, 1, 2, 2)
-        if (a.Npad == 64 && v4) YN_DT(2, 2, 1, 4, 2)
-        if (a.Npad == 128 && v4) YN_DT(2, 2, 2, 4, 2)
-        if (a.Npad == 256 && v4) YN_DT(1, 4, 2, 4, 2)
-        if (a.Npad == 32 && v4) YN_DT(4, 1, 1, 4, 2)
-        if (a.Npad == 96 && v4) YN_DT(4, 1, 3, 4, 2)
-    } else {
-        if (a.Npad == 96 && v4) YN_DT(4, 1, 3, 4, 1)
-    }
-#undef YN_DT
-    return false;
 }
 
 // -------------------------------------------------------------------------------------------------
