@@ -14,17 +14,12 @@
 //   4. the epilogue interleaves the pass-through half: out[2j] = x1[j], out[2j+1] = relu(pw2[j]).
 // HBM traffic per unit: x2 (with ~1.3x halo overlap) + x1 in, out written once — about half of the three-kernel version.
 #include "yn_internal.h"
+#include "yn_device.h"
 
 namespace ynk {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ unsigned unit_mask(bool ok)
-{
-    unsigned mk = ok ? 0xffffffffu : 0u;
-    asm volatile("" : "+v"(mk));                            // opaque: keeps the masked load unconditional (see kernels_conv.hip)
-    return mk;
-}
+// the opaque-mask load idiom of yn_device.h under this file's historical names
+__device__ __forceinline__ unsigned unit_mask(bool ok) { return opaque_mask(ok); }
 __device__ __forceinline__ float unit_keep(float v, unsigned mk) { return __uint_as_float(__float_as_uint(v) & mk); }
 
 template <int NT, int KP>
