@@ -38,3 +38,31 @@ def test_two_rank_inference_bench():
 def test_two_rank_training_bench():
     d = _run(["--train", "--size", "224", "--batch", "4", "--steps", "4", "--warmup", "2"])
     assert d["n_gpus"] == 2 and d["finite"] and d["config"]["global_batch"] == 8
+
+
+def _run_single(extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_contract_line():
+    """The driver's contract for the default mode: one JSON line with the required keys, the roofline and cpu_baseline blocks and
+    the bs=1 latency block (small workload here to keep the test short)."""
+    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["latency_bs1_eager"]["224x224"]["p50_ms"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_preprocess_and_latency_modes():
+    d = _run_single(["--preprocess", "--steps", "10", "--warmup", "3", "--batch", "8", "--size", "224"])
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+    d = _run_single(["--latency", "50", "--batch", "1", "--size", "224", "--no-cpu-baseline"])
+    assert d["unit"] == "ms" and d["higher_is_better"] is False and d["value"] > 0
