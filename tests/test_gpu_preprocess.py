@@ -65,6 +65,12 @@ def test_val_transforms_batch_equals_per_image():
         np.testing.assert_array_equal(np.asarray(scales[k]), np.asarray(rscale)); np.testing.assert_array_equal(offsets[k], roffset)
 
 
+def test_val_transforms_empty_batch():
+    from yolo_nano_amd import ValTransforms
+    x, scales, offsets = ValTransforms(64).batch([])
+    assert tuple(x.shape) == (0, 3, 64, 64) and scales == [] and offsets == []
+
+
 def test_preprocess_rejects_bad_geometry():
     from yolo_nano_amd import arch, capi
     h = capi.Handle(32, 1, arch.MULTI_ANCHOR_SIZE)

@@ -1070,7 +1070,8 @@ int yn_preprocess(yn_handle* h, const uint8_t* img, int h0, int w0, int rw, int 
 int yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs, const int32_t* geom, int side, const float* mean, const float* stdv, float* x)
 {
     if (!h) return 1;
-    if (n < 0 || (n > 0 && (!imgs || !geom)) || !x || !mean || !stdv || side <= 0) return fail(h, "yn_preprocess_batch: bad arguments");
+    if (n == 0) return 0;                                   // an empty batch is not an error
+    if (n < 0 || !imgs || !geom || !x || !mean || !stdv || side <= 0) return fail(h, "yn_preprocess_batch: bad arguments");
     for (int c = 0; c < 3; ++c)
         if (!(stdv[c] > 0.0f)) return fail(h, "yn_preprocess_batch: std must be positive");
     for (int i = 0; i < n; ++i) {
@@ -1078,7 +1079,6 @@ int yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs, const i
         if (!imgs[i] || g[0] <= 0 || g[1] <= 0 || g[2] <= 0 || g[3] <= 0 || g[4] < 0 || g[5] < 0 || g[4] + g[2] > side || g[5] + g[3] > side)
             return fail(h, "yn_preprocess_batch: bad geometry for image %d", i);
     }
-    if (n == 0) return 0;
     launch_preprocess_batch(n, imgs, geom, side, mean, stdv, x, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
