@@ -30,7 +30,9 @@ namespace ynk {
 // whole chip fetching its ~35 MB at the same time (bandwidth-bound, MFMAs idle) and the GEMM phases leave the memory system
 // idle; overlapping them needs a persistent block that requests tile i+1's window (direct-to-LDS loads) while tile i is in
 // its GEMMs — the next step for this kernel.  (Tried: the GEMM weights register-direct from L2 instead of through LDS, which
-// removes the chunk barriers — GEMM phase 13.7 k -> 22 k cycles: the 8-byte per-lane weight loads are slower than the barriers.)
+// removes the chunk barriers — GEMM phase 13.7 k -> 22 k cycles: the 8-byte per-lane weight loads are slower than the barriers;
+// and starting the second block of a CU 8 k / 16 k / 24 k cycles late (s_sleep on odd HW wave slots) so that co-resident blocks
+// are out of phase: 40.5 / 42.7 / 44.8 us against 42 us, i.e. nothing — with 338 blocks only a third of the CUs hold two.)
 // -------------------------------------------------------------------------------------------------
 template <int WM, int WN, int NT, int V>
 __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
