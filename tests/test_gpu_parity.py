@@ -376,7 +376,8 @@ def test_autotune_off_is_bit_identical(capi):
             assert torch.equal(da[i][b, :k], db[i][b, :k])
 
 
-def test_three_handles_on_three_streams_agree(capi):
+@pytest.mark.parametrize("forks", [False, True])
+def test_three_handles_on_three_streams_agree(capi, forks):
     """bench.py's default mode: three independent handles, one HIP stream each, steps dealt round-robin without host syncs in
     between.  Every handle must produce exactly what a lone handle produces for its input (bit-identical boxes, scores, classes,
     indices and counts), also when the three pipelines overlap on the device."""
@@ -393,6 +394,7 @@ def test_three_handles_on_three_streams_agree(capi):
         with torch.cuda.stream(st):
             hk = capi.Handle(S, 80, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", 0.001, 0.5, max_batch=B, stream=st)
             hk.load_state_dict(sd); hk.fold_bn()
+            hk.multi_stream(forks)                            # bench.py switches the intra-forward side streams off (yn_multi_stream)
             handles.append(hk); outs.append(hk.alloc_outputs(B))
     for rep in range(6):                                      # 18 overlapping steps, no synchronisation in between
         for k, st in enumerate(streams):

@@ -44,6 +44,7 @@ SIGNATURES = {
     "yn_set_pw_config": (_i32, [_vp, _i32]),
     "yn_pw_config_count": (_i32, []),
     "yn_unit_chain": (_i32, [_vp, _i32]),
+    "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -193,6 +194,11 @@ class Handle:
         """One kernel per stride-1 ShuffleV2 unit: 1 = where the map is large enough (default), 0 = never, 2 = always (True = 2);
         bit-identical results either way."""
         self._ck(self.lib.yn_unit_chain(self.h, 2 if mode is True else int(mode)), "yn_unit_chain")
+
+    def multi_stream(self, on=True):
+        """Fork independent kernel chains of one forward onto the handle's side streams (default on).  Turn off when several
+        handles already run concurrently on their own streams."""
+        self._ck(self.lib.yn_multi_stream(self.h, int(bool(on))), "yn_multi_stream")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

@@ -768,6 +768,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
+    if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
@@ -855,6 +856,7 @@ int yn_set_pw_config(yn_handle* h, int index)
     return 0;
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
+int yn_multi_stream(yn_handle* h, int enable) { if (!h) return 1; h->multi_stream = enable != 0; return 0; }
 int yn_unit_chain(yn_handle* h, int mode) { if (!h) return 1; h->unit_chain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 
 int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
