@@ -27,6 +27,20 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
+PMC_LAYERS_FILE = "r02_pmc_layers.json"
+
+
+def source_hash():
+    """sha1 over the kernel sources: stamps the committed PMC traffic table (tools/pmc_layers.py) so that `roofline.traffic`
+    is dropped, not silently stale, once a kernel has changed since the counters were collected."""
+    import hashlib
+    d = os.path.join(ROOT, "yolo-nano_amd", "csrc")
+    hsh = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def parse():
@@ -41,8 +55,8 @@ def parse():
     ap.add_argument("--conf", type=float, default=0.001)
     ap.add_argument("--nms", type=float, default=0.5)
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as a captured hipGraph instead of launching eagerly (measured 2-3 %% slower on this stack: "
-                         "17.15 k vs 17.5 k images/s; the launch thread keeps up with ~75 kernels per 1.8 ms step)")
+                    help="replay the step as a captured hipGraph instead of launching eagerly (on par with eager on the 1-GPU box: "
+                         "the launch thread issues the ~65 kernels of a step well inside the time they take; same as --launch graph)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly (no calibration)")
     ap.add_argument("--launch", choices=("auto", "eager", "graph"), default="auto",
                     help="auto (default): an untimed calibration before the warm-up times both launch modes and keeps eager unless "
@@ -64,6 +78,11 @@ def parse():
     ap.add_argument("--preprocess", action="store_true",
                     help="time ValTransforms on the device instead (SURVEY 8(f) rank 2): --batch uint8 500x375 BGR images resident in "
                          "HBM -> normalised letterboxed [B,3,S,S] float32; reports images/s and the HBM fraction")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f16",
+                    help="--train: storage type of activations and activation gradients (f16 = BASELINE configs[2] as named: fp16 storage + "
+                         "f16 MFMA with fp32 accumulation, fp32 master weights, loss scaling; f32 = the reference's own arithmetic)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run: skip the extra witnessed workloads (single stream, 608x608 bs=32, 0.5x bs=128, the training steps)")
     ap.add_argument("--latency", type=int, default=0, metavar="N",
                     help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
@@ -161,8 +180,9 @@ def preprocess_bench(args, rank, world, dev, dist):
     hd.close()
 
 
-def train_bench(args, rank, world, dev, dist):
-    """Secondary line (not BASELINE's headline metric): images/s of the full training step, data-parallel over ranks."""
+def train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
+    """Secondary line (not BASELINE's headline metric): images/s of the full training step, data-parallel over ranks.
+    -> the JSON line as a dict (brief: the few keys the default run embeds)."""
     from yolo_nano_amd import arch, capi, parallel, weights
     B, S = args.batch, args.size
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
@@ -170,6 +190,7 @@ def train_bench(args, rank, world, dev, dist):
     h = capi.Handle(S, args.classes, anchors, args.backbone, max_batch=B, device=dev)
     h.load_state_dict(sd)
     n_param = h.train_bind()
+    h.train_precision(dtype)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     x = torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32)
@@ -200,7 +221,7 @@ def train_bench(args, rank, world, dev, dist):
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     lv = [float(v) for v in losses.tolist()]
     assign = None
-    if rank == 0:                                            # the label assigner alone, and the CPU restatement of the reference beside it
+    if rank == 0 and not brief:                              # the label assigner alone, and the CPU restatement of the reference beside it
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(20):
@@ -213,160 +234,251 @@ def train_bench(args, rank, world, dev, dist):
         cpu_ms = (time.perf_counter() - t1) * 1e3
         assign = {"gpu_ms_incl_h2d": round(gpu_ms, 4), "cpu_oracle_ms": round(cpu_ms, 2), "cores": 1,
                   "objects": sum(len(l) for l in labels), "matches_oracle": bool(torch.equal(target.cpu(), torch.from_numpy(ref)))}
-    if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d SGD training step" % (args.backbone, S, S, B),
-            "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 training step: train-mode forward (BN batch statistics), "
-                                   "loss, backward, SGD(0.9, 5e-4), label assignment on the device; %d-class head (BASELINE configs[2] shape, fp32 not fp16)"
-                                   % (args.backbone, S, S, B, args.classes),
-                       "global_batch": world * B, "parameters": n_param,
-                       "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
-            "label_assigner": assign,
-            "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}), flush=True)
+    prec = "fp16 storage of activations / activation gradients, f16 MFMA with fp32 accumulation, fp32 master weights, static loss scale" if dtype == "f16" else "fp32 end to end"
+    line = {
+        "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d SGD training step %s" % (args.backbone, S, S, B, dtype),
+        "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU training step (%s): train-mode forward (BN batch statistics), "
+                               "loss, backward, SGD(0.9, 5e-4), label assignment on the device; %d-class head (BASELINE configs[2])"
+                               % (args.backbone, S, S, B, prec, args.classes),
+                   "global_batch": world * B, "parameters": n_param, "rccl_ranks": world,
+                   "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
+        "label_assigner": assign,
+        "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}
     h.close()
+    if brief:
+        return {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite")}
+    return line
+
+
+class InferRig:
+    """`ns` independent inference streams of one GPU: one handle + HIP stream + synthetic batch each.  A step = yn_infer
+    (network + decode + NMS) + yn_pack_detections + the hand-over of models/yolo_nano.py:370-376 to the host: the B+1
+    offsets, then (one visit of that stream later, once the host knows the total) the kept records into a pinned buffer."""
+
+    def __init__(self, args, dev, rank, S, B, backbone, ns, use_graph, sd=None, deliver=True):
+        from yolo_nano_amd import arch, capi, weights
+        self.anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
+        self.sd = weights.make_state_dict(backbone, args.classes) if sd is None else sd
+        self.dev, self.S, self.B, self.ns, self.deliver = dev, S, B, ns, deliver
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        self.handles, self.xs, self.outs, self.recs, self.offs, self.offs_h, self.recs_h, self.ev, self.pending = [], [], [], [], [], [], [], [], []
+        for k, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                hk = capi.Handle(S, args.classes, self.anchors, backbone, args.conf, args.nms, max_batch=B, device=dev, stream=st)
+                hk.load_state_dict(self.sd)
+                hk.fold_bn()
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(1234 + rank * 16 + k)
+                self.xs.append(torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32))   # synthetic, resident in HBM
+                self.outs.append(hk.alloc_outputs(B))
+                self.recs.append(torch.empty((B * hk.N, 6), dtype=torch.float32, device=dev))
+                self.offs.append(torch.empty((B + 1,), dtype=torch.int32, device=dev))
+                self.offs_h.append(torch.zeros((B + 1,), dtype=torch.int32).pin_memory())
+                self.recs_h.append(torch.empty((B * hk.N, 6), dtype=torch.float32).pin_memory())
+                self.ev.append(torch.cuda.Event())
+                self.pending.append(False)
+                hk.use_graph(use_graph)
+                if ns > 1:
+                    hk.multi_stream(False)               # the batches already overlap across handles: 24.1 k vs 21.7 k images/s
+                self.handles.append(hk)
+        self.step_no = 0
+        self.delivered = 0                               # detections that reached the host
+
+    def use_graph(self, on):
+        for hk in self.handles:
+            hk.use_graph(on)
+
+    def _collect(self, k):
+        """The kept records of stream k's previous step -> pinned host memory (the offsets already arrived)."""
+        if not self.pending[k]:
+            return
+        self.ev[k].synchronize()                         # offsets of that step are on the host
+        total = int(self.offs_h[k][self.B])
+        if total:
+            self.recs_h[k][:total].copy_(self.recs[k][:total], non_blocking=True)
+        self.delivered += total
+        self.pending[k] = False
+
+    def step(self):
+        k = self.step_no % self.ns
+        self.step_no += 1
+        with torch.cuda.stream(self.streams[k]):
+            if self.deliver:
+                self._collect(k)                         # issued BEFORE this step overwrites the device buffers (stream order)
+            self.handles[k].infer(self.xs[k], self.outs[k])
+            if self.deliver:
+                self.handles[k].pack_detections(self.outs[k], self.recs[k], self.offs[k])
+                self.offs_h[k].copy_(self.offs[k], non_blocking=True)
+                self.ev[k].record()
+                self.pending[k] = True
+            else:
+                self.offs_h[k][:self.B].copy_(self.outs[k][4], non_blocking=True)
+
+    def drain(self):
+        for k, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                if self.deliver:
+                    self._collect(k)
+            st.synchronize()
+
+    def close(self):
+        for hk in self.handles:
+            hk.close()
+
+
+def timed_infer(rig, steps, warmup, dev, dist):
+    from yolo_nano_amd import parallel
+
+    def sync_all():
+        rig.drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        rig.step()
+    sync_all()
+    rig.delivered = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rig.step()
+    sync_all()                                           # includes the last steps' record copies
+    return parallel.max_over_ranks(time.perf_counter() - t0, dev)
+
+
+def side_workload(args, dev, rank, world, dist, S, B, backbone, steps, warmup, ns):
+    """A further named workload measured the same way as the headline one (host delivery included): -> dict."""
+    rig = InferRig(args, dev, rank, S, B, backbone, ns, False)
+    el = timed_infer(rig, steps, warmup, dev, dist)
+    out = {"images_per_s": round(world * B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "streams_per_gpu": ns,
+           "detections_per_step_rank0": rig.delivered // steps,
+           "workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference + NMS + host delivery" % (backbone, S, S, B)}
+    rig.close()
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (no launcher): start the N ranks ourselves — a CHILD `python -m torch.distributed.run`
+    process (this one has not touched the GPU and never will; no exec) — relay its output and exit with its code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not os.environ.get("YN_BENCH_ONE_GPU") and torch.cuda.device_count() < args.gpus:     # device_count() does not initialise the GPU
+            raise SystemExit("bench.py --gpus %d: only %d GPUs visible" % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(spawn_ranks(args))
     from yolo_nano_amd import arch, capi, parallel, weights
     rank, local_rank, world = parallel.env_rank()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if os.environ.get("YN_BENCH_ONE_GPU"):                   # test hook: all ranks on GPU 0 (use with YN_BENCH_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    parallel.init(os.environ.get("YN_BENCH_BACKEND", "nccl"), dev)     # RCCL; inference uses it only for the barrier / max-over-ranks
+    backend = os.environ.get("YN_BENCH_BACKEND", "nccl")
+    parallel.init(backend, dev)                              # RCCL; inference uses it only for the barrier / max-over-ranks
     dist = torch.distributed if world > 1 else None
+
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
     if args.preprocess:
         preprocess_bench(args, rank, world, dev, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish()
     if args.train:
-        train_bench(args, rank, world, dev, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        line = train_bench(args, rank, world, dev, dist, args.dtype)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return finish()
 
-    anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
-    sd = weights.make_state_dict(args.backbone, args.classes)
     B, S = args.batch, args.size
     ns = max(1, args.streams if args.latency == 0 else 1)
     mode = "graph" if args.graph else "eager" if args.no_graph else args.launch
     if args.latency > 0 and mode == "auto":
         mode = "eager"
     use_graph = mode == "graph"
-    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-    handles, xs, outs, counts = [], [], [], []
-    for k, st in enumerate(streams):
-        with torch.cuda.stream(st):
-            hk = capi.Handle(S, args.classes, anchors, args.backbone, args.conf, args.nms, max_batch=B, device=dev, stream=st)
-            hk.load_state_dict(sd)
-            hk.fold_bn()
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(1234 + rank * 16 + k)
-            xs.append(torch.randn((B, 3, S, S), generator=gen, device=dev, dtype=torch.float32))   # synthetic, resident in HBM
-            outs.append(hk.alloc_outputs(B))
-            counts.append(torch.empty((B,), dtype=torch.int32).pin_memory())
-            hk.use_graph(use_graph)
-            if ns > 1:
-                hk.multi_stream(False)                       # the batches already overlap across handles: 24.1 k vs 21.7 k images/s
-            handles.append(hk)
-    stream, h, x, out, counts_host = streams[0], handles[0], xs[0], outs[0], counts[0]
-    step_no = [0]
-    with torch.cuda.stream(stream):
-        def step():
-            k = step_no[0] % ns
-            step_no[0] += 1
-            with torch.cuda.stream(streams[k]):
-                handles[k].infer(xs[k], outs[k])
-                counts[k].copy_(outs[k][4], non_blocking=True)
+    rig = InferRig(args, dev, rank, S, B, args.backbone, ns, use_graph, deliver=args.latency == 0)
+    sd, anchors = rig.sd, rig.anchors
+    stream, h, x, out = rig.streams[0], rig.handles[0], rig.xs[0], rig.outs[0]
 
-        def sync_all():
-            for st in streams:
-                st.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize(dev)
-
-        if args.latency > 0:
-            # per-call latency: launch (graph replay), wait for the device, repeat — the protocol of benchmark.py:62-75
-            for _ in range(max(args.warmup, 50)):
-                step()
-            stream.synchronize()
-            lat = []
-            for _ in range(args.latency):
-                t1 = time.perf_counter()
-                step()
-                stream.synchronize()
-                lat.append((time.perf_counter() - t1) * 1e3)
-            lat.sort()
-            if rank == 0:
-                print(json.dumps({"metric": "p50 latency YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
-                                  "value": round(lat[len(lat) // 2], 4), "unit": "ms", "p99_ms": round(lat[int(len(lat) * 0.99)], 4),
-                                  "min_ms": round(lat[0], 4), "n_gpus": world, "steps": args.latency, "warmup": max(args.warmup, 50),
-                                  "higher_is_better": False, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-                                  "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, %s, conf %.3g nms %.2f"
-                                                         % (args.backbone, S, S, B, "hipGraph replay" if use_graph else "eager launches", args.conf, args.nms), "hipgraph": bool(use_graph)}}), flush=True)
-            h.close()
-            return
-        calib = None
-        if mode == "auto":                             # untimed: which launch mode keeps the GPU fed from THIS host thread?
-            def rate(g, n=30):
-                for hk in handles:
-                    hk.use_graph(g)
-                for _ in range(2 * ns):                # (re)capture / re-warm
-                    step()
-                for st in streams:
-                    st.synchronize()
-                t = time.perf_counter()
-                for _ in range(n):
-                    step()
-                for st in streams:
-                    st.synchronize()
-                return n / (time.perf_counter() - t)
-            r_e, r_g = max(rate(False), rate(False)), max(rate(True), rate(True))
-            use_graph = r_g > 1.03 * r_e
-            calib = {"eager_steps_per_s": round(r_e, 1), "graph_steps_per_s": round(r_g, 1)}
-            for hk in handles:
-                hk.use_graph(use_graph)
-        for _ in range(args.warmup):
-            step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        elapsed = parallel.max_over_ranks(elapsed, dev)
-        kept = int(counts_host.sum().item())
-
-        # PCIe-inclusive variant (not `value`): also bring the kept rows of every image to the host
-        pcie = None
-        if rank == 0:
-            hb = torch.empty((B, h.N, 4), dtype=torch.float32).pin_memory()
-            n_pc = max(5, args.steps // 10)
-            for st in streams:                         # local sync only: this block runs on rank 0 alone (no collective here)
-                st.synchronize()
-            torch.cuda.synchronize(dev)
+    if args.latency > 0:
+        # per-call latency: launch (or graph replay), wait for the device, repeat — the protocol of benchmark.py:62-75
+        for _ in range(max(args.warmup, 50)):
+            rig.step()
+        stream.synchronize()
+        lat = []
+        for _ in range(args.latency):
             t1 = time.perf_counter()
-            for _ in range(n_pc):                      # single stream, every kept row copied to pinned host memory
-                h.infer(x, out)
-                counts_host.copy_(out[4], non_blocking=True)
-                stream.synchronize()
-                for b, k in enumerate(counts_host.tolist()):
-                    hb[b, :k].copy_(out[0][b, :k], non_blocking=True)
+            rig.step()
             stream.synchronize()
-            pcie = B * n_pc / (time.perf_counter() - t1)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        if rank == 0:
+            print(json.dumps({"metric": "p50 latency YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
+                              "value": round(lat[len(lat) // 2], 4), "unit": "ms", "p99_ms": round(lat[int(len(lat) * 0.99)], 4),
+                              "min_ms": round(lat[0], 4), "n_gpus": world, "steps": args.latency, "warmup": max(args.warmup, 50),
+                              "higher_is_better": False, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                              "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, %s, conf %.3g nms %.2f"
+                                                     % (args.backbone, S, S, B, "hipGraph replay" if use_graph else "eager launches", args.conf, args.nms), "hipgraph": bool(use_graph)}}), flush=True)
+        rig.close()
+        return finish()
 
-        # ---- per-kernel durations measured live with HIP events on the launch stream --------------------
-        roof, kernels, pipeline = None, [], None
+    calib = None
+    if mode == "auto":                                 # untimed: which launch mode keeps the GPU fed from THIS host thread?
+        def rate(g, n=30):
+            rig.use_graph(g)
+            for _ in range(2 * ns):                    # (re)capture / re-warm
+                rig.step()
+            rig.drain()
+            t = time.perf_counter()
+            for _ in range(n):
+                rig.step()
+            rig.drain()
+            return n / (time.perf_counter() - t)
+        r_e, r_g = max(rate(False), rate(False)), max(rate(True), rate(True))
+        use_graph = r_g > 1.03 * r_e
+        calib = {"eager_steps_per_s": round(r_e, 1), "graph_steps_per_s": round(r_g, 1)}
+        rig.use_graph(use_graph)
+    elapsed = timed_infer(rig, args.steps, args.warmup, dev, dist)
+    kept = rig.delivered // max(1, args.steps)
+
+    # the same step without the host delivery (detections stay in HBM; only the 32 counts cross PCIe): the round-1 definition
+    rig.deliver = False
+    elapsed_dev = timed_infer(rig, max(20, args.steps // 2), 4, dev, dist)
+    dev_only = world * B * max(20, args.steps // 2) / elapsed_dev
+    rig.deliver = True
+
+    # one stream, one batch in flight (the handle's intra-forward side streams back on): what a lone caller of yn_infer gets
+    single = None
+    if not args.no_extras:
+        r1 = InferRig(args, dev, rank, S, B, args.backbone, 1, False, sd=sd)
+        n1 = max(20, args.steps // 2)
+        el1 = timed_infer(r1, n1, 5, dev, dist)
+        single = {"images_per_s": round(world * B * n1 / el1, 1), "ms_per_step": round(el1 / n1 * 1e3, 4),
+                  "note": "one handle, one batch in flight: ms_per_step here is a true step latency; the headline ms_per_step is inverse throughput with %d batches in flight" % ns}
+        r1.close()
+
+    # ---- per-kernel durations measured live with HIP events on the launch stream --------------------
+    roof, kernels, pipeline = None, [], None
+    with torch.cuda.stream(stream):
         if rank == 0:
             h.use_graph(False)
             h.profile_enable(True)
@@ -385,7 +497,7 @@ def main():
                     print("%-28s %-28s %8.1f us  %7.2f GFLOP %7.1f MB  %6.1f TF/s %7.1f GB/s" % (
                         layer, kern, ms * 1e3, fl / 1e9, by / 1e6, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
             if args.dump_layers:
-                json.dump([{"layer": layer, "kernel": kern, "flops": fl, "bytes": by,
+                json.dump([{"layer": layer, "kernel": kern, "flops": fl, "bytes": by, "source_hash": source_hash(),
                             "workload": "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf)}
                            for layer, kern, ms, fl, by in recs], open(args.dump_layers, "w"), indent=1)
             ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
@@ -404,17 +516,23 @@ def main():
                                 "unit": unit, "frac": round(ach / peak, 4)})
             d = kernels[0]
             # HBM bytes per launch of the dominant symbol, from the committed per-LAYER PMC pass ((2*FETCH_SIZE + WRITE_SIZE) KiB,
-            # profiles/r01_pmc_layers.json, joined on the launch order of one call: the symbol a layer runs under is autotuned)
-            traffic = None
+            # joined on the launch order of one call: the symbol a layer runs under is autotuned).  PMC counters need rocprofv3
+            # around the process, so they cannot be taken inside this run; the file is stamped with the hash of the kernel
+            # sources it was measured on and is ignored (traffic = null) when the sources have changed since.
+            traffic, traffic_src = None, None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_layers.json")))
-                if pmc["_meta"]["workload"] == "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf):
+                pf = os.path.join(ROOT, "profiles", PMC_LAYERS_FILE)
+                pmc = json.load(open(pf))
+                if (pmc["_meta"]["workload"] == "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf)
+                        and pmc["_meta"].get("source_hash") == source_hash()):
                     per = [pmc["%d:%s" % (i, layer)]["hbm_bytes"] for i, (layer, kern, ms, fl, by) in enumerate(recs) if kern == d["kernel"]]
                     traffic = round(sum(per) / len(per)) if per else None
+                    traffic_src = "profiles/" + PMC_LAYERS_FILE
             except Exception:
                 traffic = None
             roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": traffic, "alg_bytes_per_launch": round(agg[d["kernel"]]["bytes"] / agg[d["kernel"]]["launches"]),
+                    "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    "alg_bytes_per_launch": round(agg[d["kernel"]]["bytes"] / agg[d["kernel"]]["launches"]),
                     "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
                     "avg_us": d["avg_us"], "share_of_step": d["share"]}
             fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
@@ -424,7 +542,7 @@ def main():
                         "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
 
         # ---- the second half of BASELINE's metric: p50 latency at bs=1 (rank 0, after the timed region; benchmark.py:62-75 protocol:
-        #      launch, wait for the device, repeat), at the bench resolution and at BASELINE config 5's 608x608
+        #      launch, wait for the device, repeat), at the bench resolution and at BASELINE config 5's 608x608 (eager and hipGraph)
         latency = None
         if rank == 0 and not args.no_latency:
             latency = {}
@@ -435,48 +553,67 @@ def main():
                 gl = torch.Generator(device=dev); gl.manual_seed(99)
                 xl = torch.randn((1, 3, LS, LS), generator=gl, device=dev, dtype=torch.float32)
                 ol = hl.alloc_outputs(1)
-                for _ in range(60):
-                    hl.infer(xl, ol)
-                stream.synchronize()
-                lat = []
-                for _ in range(300):
-                    t1 = time.perf_counter()
-                    hl.infer(xl, ol)
+                ent = {}
+                for tag, g in (("eager", False), ("hipgraph", True)):
+                    hl.use_graph(g)
+                    for _ in range(60):
+                        hl.infer(xl, ol)
                     stream.synchronize()
-                    lat.append((time.perf_counter() - t1) * 1e3)
-                lat.sort()
-                latency["%dx%d" % (LS, LS)] = {"p50_ms": round(lat[len(lat) // 2], 4), "p99_ms": round(lat[int(len(lat) * 0.99)], 4), "calls": len(lat)}
+                    lat = []
+                    for _ in range(300):
+                        t1 = time.perf_counter()
+                        hl.infer(xl, ol)
+                        stream.synchronize()
+                        lat.append((time.perf_counter() - t1) * 1e3)
+                    lat.sort()
+                    ent[tag] = {"p50_ms": round(lat[len(lat) // 2], 4), "p99_ms": round(lat[int(len(lat) * 0.99)], 4), "calls": len(lat)}
+                latency["%dx%d" % (LS, LS)] = ent
                 hl.close()
+    rig.use_graph(False)
+    rig.close()
 
-        for hk in handles:
-            hk.use_graph(False)
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        if rank == 0:
-            line = {
-                "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
-                "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1])"
-                                       % (args.backbone, S, S, B, args.classes),
-                           "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
-                           "parallelism": "image-sharded x%d, no collective" % world, "hipgraph": bool(use_graph), "launch_mode": mode, "launch_calibration_rank0": calib,
-                           "streams_per_gpu": ns,
-                           "detections_per_step_rank0": kept},
-                "roofline": roof,
-                "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
-                "pipeline": dict(pipeline or {}, frac_of_floor=round((pipeline["roofline_floor_ms"] / ms_per_step), 4) if pipeline else None),
-                "pcie_inclusive_images_per_s": round(pcie, 1) if pcie else None,
-                "latency_bs1_eager": latency,
-                "kernels": kernels,
-            }
-            print(json.dumps(line), flush=True)
-        for hk in handles:
-            hk.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    # ---- the other named workloads, witnessed in the same run (all ranks take part: same barriers) ----
+    extras = None
+    if not args.no_extras:
+        extras = {}
+        if (S, B, args.backbone) != (608, 32, "1.0x"):
+            extras["infer_608_bs32"] = side_workload(args, dev, rank, world, dist, 608, 32, "1.0x", 40, 8, ns)                 # north_star: "416x416 and 608x608"
+        if (S, B, args.backbone) != (416, 128, "0.5x"):
+            extras["infer_0.5x_416_bs128"] = side_workload(args, dev, rank, world, dist, 416, 128, "0.5x", 30, 6, ns)          # BASELINE configs[3]
+        targs = argparse.Namespace(**vars(args))
+        targs.size, targs.batch, targs.steps, targs.warmup, targs.backbone = 608, 32, 12, 3, "1.0x"
+        for dt in ("f16", "f32"):                                                                                               # BASELINE configs[2]
+            try:
+                extras["train_608_bs32_" + dt] = train_bench(targs, rank, world, dev, dist, dt, brief=True)
+            except Exception as e:                                                                                              # reported, never hidden
+                extras["train_608_bs32_" + dt] = {"error": str(e)[:300]}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    if rank == 0:
+        line = {
+            "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS + host delivery)" % (args.backbone, S, S, B),
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1]); inputs resident in HBM, "
+                                   "kept detections delivered to pinned host memory inside the timed region" % (args.backbone, S, S, B, args.classes),
+                       "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
+                       "parallelism": "image-sharded x%d, no collective" % world, "rccl_ranks": world, "backend": backend if world > 1 else None,
+                       "hipgraph": bool(use_graph), "launch_mode": mode, "launch_calibration_rank0": calib,
+                       "streams_per_gpu": ns, "ms_per_step_is": "inverse throughput with %d batches in flight per GPU" % ns,
+                       "detections_per_step_rank0": kept},
+            "roofline": roof,
+            "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
+            "pipeline": dict(pipeline or {}, frac_of_floor=round((pipeline["roofline_floor_ms"] / ms_per_step), 4) if pipeline else None),
+            "device_only_images_per_s": round(dev_only, 1),
+            "single_stream": single,
+            "latency_bs1": latency,
+            "extras": extras,
+            "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    finish()
 
 
 if __name__ == "__main__":

@@ -31,6 +31,7 @@ typedef struct yn_handle yn_handle;
 
 enum { YN_BACKBONE_0_5X = 0, YN_BACKBONE_1_0X = 1, YN_BACKBONE_1_5X = 2, YN_BACKBONE_2_0X = 3 };
 enum { YN_ACT_NONE = 0, YN_ACT_RELU = 1, YN_ACT_LEAKY = 2 };
+enum { YN_F32 = 0, YN_F16 = 1 };
 
 /* Mirrors YOLONano.__init__(device, input_size, num_classes, trainable, conf_thresh, nms_thresh,
  * anchor_size, backbone, diou_nms)  — models/yolo_nano.py:13-27. */
@@ -98,6 +99,11 @@ int  yn_get_folded(yn_handle* h, const char* conv_key, float* host_weight, float
 int  yn_forward_raw(yn_handle* h, const float* x_dev, int B,
                     float* head_s8_dev, float* head_s16_dev, float* head_s32_dev);
 
+/* ShuffleNetV2.forward (backbone/shufflenetv2.py:157-167): the same network pass, additionally copying the three backbone
+ * taps the neck consumes — c3 [B,S/8,S/8,C3], c4 [B,S/16,S/16,C4], c5 [B,S/32,S/32,C5], NHWC float32 (C = 116/232/464 for
+ * 1.0x, 48/96/192 for 0.5x) — so that a backbone failure localises (parity tests; never graph-captured). */
+int  yn_forward_taps(yn_handle* h, const float* x_dev, int B, float* c3_dev, float* c4_dev, float* c5_dev);
+
 /* Lines 308-330 + 362-367 for EVERY image of the batch (the reference only finishes image 0):
  * all_bbox [B,N,4] = clamp(decode_boxes/S, 0, 1); all_class [B,N,C] = softmax(cls)*sigmoid(obj). */
 int  yn_score_full(yn_handle* h, const float* head_s8_dev, const float* head_s16_dev,
@@ -148,6 +154,14 @@ int  yn_infer(yn_handle* h, const float* x_dev, int B,
               float* out_boxes_dev, float* out_scores_dev, int32_t* out_cls_dev,
               int32_t* out_index_dev, int32_t* count_dev);
 
+/* The hand-over that ends YOLONano.forward (`.to('cpu').numpy()`, models/yolo_nano.py:370-376) for a whole batch: gathers the
+ * kept rows of the yn_infer / yn_postprocess outputs of all B images into ONE contiguous record list
+ * rec_dev [total][6] float32 = x1, y1, x2, y2, score, class (image order; ascending candidate order inside an image; the class
+ * as a float, exact below 2^24) and offsets_dev[B+1] = exclusive prefix of the counts ([B] = total).  The host then needs two
+ * copies per batch (the offsets, then total*24 bytes) instead of three per image.  rec_dev has capacity B*N records. */
+int  yn_pack_detections(yn_handle* h, const float* out_boxes_dev, const float* out_scores_dev, const int32_t* out_cls_dev,
+                        const int32_t* count_dev, int B, int N, float* rec_dev, int32_t* offsets_dev);
+
 /* ---- training loss (train.py:219-229, forward value + gradient w.r.t. the raw predictions) ---------- */
 /* models/yolo_nano.py:332-358 + tools.iou_score (tools.py:219-233) + tools.loss (tools.py:236-276).
  * Predictions in the reference's split layout: conf [B,N] (= [B,N,1]), cls [B,N,C], txtytwth [B,N,4];
@@ -166,7 +180,10 @@ int  yn_loss_heads(yn_handle* h, const float* head_s8_dev, const float* head_s16
 
 /* torch.optim.SGD(lr, momentum=0.9, weight_decay=5e-4).step() (train.py:167-171, 230) on ONE flat float32 bucket
  * holding every parameter (1.27-1.33 M elements), fused with the 1/world_size averaging of the all-reduced
- * gradient sum:  g = grads*grad_scale + wd*p ; buf = first_step ? g : momentum*buf + g ; p -= lr*buf. */
+ * gradient sum:  g = grads*grad_scale + wd*p ; buf = first_step ? g : momentum*buf + g ; p -= lr*buf.
+ * A bucket that holds a NaN or Inf leaves parameters and momentum untouched — the reference skips an iteration whose loss is
+ * NaN (train.py:225-226); after the data-parallel all-reduce every rank sees the same non-finite bucket, so all ranks skip
+ * together without a host round trip.  yn_train_skipped_steps reads the number of skipped updates (synchronises). */
 int  yn_sgd_step(yn_handle* h, float* params_dev, const float* grads_dev, float* momentum_buf_dev, int64_t n,
                  float lr, float momentum, float weight_decay, float grad_scale, int first_step);
 
@@ -199,6 +216,13 @@ int  yn_train_bind(yn_handle* h, float* params_dev, float* grads_dev, float* mom
 int  yn_train_step(yn_handle* h, const float* x_dev, const float* target_dev, int B, float lr, float momentum,
                    float weight_decay, float grad_scale, int do_update, float* losses_dev);
 int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_t numel);
+int  yn_train_skipped_steps(yn_handle* h, int64_t* count_host);
+/* Arithmetic of yn_train_step (BASELINE configs[2] names fp16; train.py itself runs fp32).  YN_F32 (default): fp32 end to end.
+ * YN_F16: activations and activation gradients are STORED as fp16 (channel-padded NHWC, half the HBM bytes), every GEMM-shaped
+ * conv (forward, input gradient, weight gradient) runs on the f16 MFMA with fp32 accumulation, BatchNorm statistics / parameter
+ * gradients / the optimiser stay fp32 on the fp32 master weights, and the loss gradient is multiplied by a dynamic loss scale
+ * kept on the device (halved when a step's gradients overflow — that step is skipped — doubled after 2000 clean steps). */
+int  yn_train_precision(yn_handle* h, int dtype);
 
 /* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
 /* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],
@@ -207,6 +231,11 @@ int  yn_op_dwconv3x3(yn_handle* h, const float* x, int B, int H, int W, int C, i
                      const float* w, const float* bias, int act, float* y);
 int  yn_op_pwconv(yn_handle* h, const float* x, int B, int H, int W, int Cin, int Cout,
                   const float* w, const float* bias, int act, float* y);
+/* The tail of a ShuffleV2Block (backbone/shufflenetv2.py:72,74 + channel_shuffle :14-28) exactly as the network runs it:
+ * y = channel_shuffle(cat(pass, act(pw(x))), 2), i.e. y[..., 2j] = pass[..., j], y[..., 2j+1] = act(pw(x))[..., j], written by
+ * the GEMM epilogue (the shuffle is never materialised on its own).  pass [B,H,W,Cout], y [B,H,W,2*Cout]. */
+int  yn_op_pwconv_shuffle(yn_handle* h, const float* x, const float* pass, int B, int H, int W, int Cin, int Cout,
+                          const float* w, const float* bias, int act, float* y);
 /* x2/resample: 0 none, 1 add nearest-up2 of x2 [B,H/2,W/2,Cin], 2 add nearest-down of x2 [B,2H,2W,Cin]
  * (models/yolo_nano.py:291-296 fused into the conv's prologue).  Cin must be a multiple of 32. */
 int  yn_op_conv3x3(yn_handle* h, const float* x, const float* x2, int resample, int B, int H, int W,

@@ -30,14 +30,39 @@ def _run(extra):
 
 
 def test_two_rank_inference_bench():
-    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-latency", "--batch", "8"])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    d = _run(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-latency", "--no-extras", "--batch", "8"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["config"]["rccl_ranks"] == 2
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
 
 
+def test_plain_python_gpus_2_launches_two_ranks():
+    """The form the driver may use: `python bench.py --gpus 2` with no launcher.  bench.py must start the two ranks itself (a child
+    torch.distributed.run, never an exec of a GPU-initialised process) and relay ONE JSON line with n_gpus == 2."""
+    env = dict(os.environ, YN_BENCH_ONE_GPU="1", YN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--batch", "4", "--size", "224",
+                        "--no-cpu-baseline", "--no-latency", "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
+
+
+def test_gpus_flag_must_match_world_size():
+    """--gpus 1 under a two-rank launcher is a configuration error, not a silent one-GPU number."""
+    env = dict(os.environ, YN_BENCH_ONE_GPU="1", YN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 1" in (r.stdout + r.stderr)
+
+
 def test_two_rank_training_bench():
-    d = _run(["--train", "--size", "224", "--batch", "4", "--steps", "4", "--warmup", "2"])
-    assert d["n_gpus"] == 2 and d["finite"] and d["config"]["global_batch"] == 8
+    for dt in ("f32", "f16"):
+        d = _run(["--train", "--dtype", dt, "--size", "224", "--batch", "4", "--steps", "4", "--warmup", "2"])
+        assert d["n_gpus"] == 2 and d["finite"] and d["config"]["global_batch"] == 8 and d["dtype"] == dt
 
 
 def _run_single(extra):
@@ -51,14 +76,16 @@ def _run_single(extra):
 def test_single_gpu_contract_line():
     """The driver's contract for the default mode: one JSON line with the required keys, the roofline and cpu_baseline blocks and
     the bs=1 latency block (small workload here to keep the test short)."""
-    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2"])
+    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2", "--no-extras"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
-    assert d["latency_bs1_eager"]["224x224"]["p50_ms"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["latency_bs1"]["224x224"]["eager"]["p50_ms"] > 0 and d["latency_bs1"]["608x608"]["hipgraph"]["p50_ms"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["device_only_images_per_s"] >= 0.9 * d["value"] and d["config"]["detections_per_step_rank0"] > 0
 
 
 def test_preprocess_and_latency_modes():

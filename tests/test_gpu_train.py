@@ -277,3 +277,33 @@ def test_full_size_directional_derivative():
     assert all(0.8 < r < 1.1 for r in ratios), (l0, g2, ratios)     # second-order terms pull the ratio slightly below 1
     assert abs(ratios[0] - 1.0) <= abs(ratios[1] - 1.0) + 0.05       # and it tends to 1 as the step shrinks
     h.close()
+
+
+def test_nan_skip_leaves_parameters_untouched(golden):
+    """train.py:225-226 (`if torch.isnan(total_loss): continue`) on the device: a gradient bucket holding a NaN / Inf — what a NaN
+    loss on ANY data-parallel rank turns the all-reduced bucket into — makes yn_sgd_step skip the update as a whole; the next
+    clean step applies normally."""
+    g = golden("train.npz")
+    h, sd = _handle(128, 20, 2, float(g["init_bias_value"]))
+    x = torch.as_tensor(weights.make_input(2, 128, seed=3)).cuda()
+    t = torch.as_tensor(_targets(128, 20, 2)).cuda()
+    h.train_step(x, t, lr=1e-3, update=False)
+    p0, m0 = h.flat_params.clone(), h.flat_momentum.clone()
+    good = h.flat_grads.clone()
+    for poison in (float("nan"), float("inf")):
+        h.flat_grads.copy_(good)
+        h.flat_grads[12345] = poison
+        h.sgd_step(h.flat_params, h.flat_grads, h.flat_momentum, 1e-3)
+        assert torch.equal(h.flat_params, p0) and torch.equal(h.flat_momentum, m0)
+    assert h.skipped_steps() == 2
+    h.flat_grads.copy_(good)
+    h.sgd_step(h.flat_params, h.flat_grads, h.flat_momentum, 1e-3)
+    assert not torch.equal(h.flat_params, p0) and h.skipped_steps() == 2
+    want = p0.double() - 1e-3 * (good.double() + 5e-4 * p0.double())
+    assert float((h.flat_params.double() - want).abs().max()) < 1e-6
+    # a NaN in the input makes the whole fused step a no-op on the parameters
+    p1 = h.flat_params.clone()
+    xb = x.clone(); xb[0, 0, 5, 5] = float("nan")
+    h.train_step(xb, t, lr=1e-3, update=True)
+    assert torch.equal(h.flat_params, p1) and h.skipped_steps() == 3
+    h.close()

@@ -161,3 +161,50 @@ def test_dp_train_step_two_ranks_equals_single_process_on_the_mean_gradient():
         np.testing.assert_allclose(params, single.flat_params.numpy(), rtol=1e-6, atol=1e-6)
         assert losses == [float(rank)] * 4                     # losses stay local (the reference prints per-rank values)
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def _bn_worker(rank, world, port, q, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from yolo_nano_amd import parallel
+    parallel.init("gloo")
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1), torch.nn.BatchNorm2d(2))
+    m.train()
+    with torch.no_grad():
+        m(torch.randn(2, 3, 8, 8) + rank)                     # every rank sees its own shard: running statistics diverge
+        if rank == 1:
+            m(torch.randn(2, 3, 8, 8))                        # and even the step counters may
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    n = parallel.broadcast_bn_buffers(m, src=0)
+    after = {k: v.clone() for k, v in m.state_dict().items()}
+    path = os.path.join(tmp, "ckpt.pth")
+    parallel.save_state_dict(m, path)
+    q.put((rank, n, {k: v.numpy() for k, v in before.items()}, {k: v.numpy() for k, v in after.items()}, os.path.exists(path)))
+    parallel.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_bn_buffers_rank0_policy_at_save(tmp_path):
+    """BN running statistics stay per-rank during training; at save time every rank adopts rank 0's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, b0, a0, s0), (r1, n1, b1, a1, s1) = res
+    assert n0 == n1 == 6 and s0 and s1
+    assert not np.array_equal(b0["1.running_mean"], b1["1.running_mean"]) and int(b1["1.num_batches_tracked"]) == 2
+    for k in a0:
+        np.testing.assert_array_equal(a0[k], a1[k])          # identical everywhere afterwards ...
+        np.testing.assert_array_equal(a0[k], b0[k])          # ... and equal to what rank 0 had (parameters were identical already)
+    import torch
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt.pth"))
+    for k in a0:
+        np.testing.assert_array_equal(ck[k].numpy(), a0[k])

@@ -15,13 +15,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libyolonano_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_unit.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
           "-Wno-pass-failed"]
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     d.append(os.path.join(os.path.dirname(HERE), "include", "yolonano_hip.h"))
     d.append(os.path.abspath(__file__))
     return d

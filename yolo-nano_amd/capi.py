@@ -8,6 +8,7 @@ soname, so torch tensors' ``data_ptr()`` and torch streams are valid in it.
 import ctypes
 import os
 
+import numpy as np
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 from . import arch
@@ -50,12 +51,14 @@ SIGNATURES = {
     "yn_fold_bn": (_i32, [_vp]),
     "yn_get_folded": (_i32, [_vp, ctypes.c_char_p, _vp, _vp]),
     "yn_forward_raw": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "yn_forward_taps": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_score_full": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "yn_decode_boxes": (_i32, [_vp, _vp, _i32, _vp]),
     "yn_create_grid": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "yn_nms": (_i32, [_vp, _vp, _vp, _i32, _f32, _i32, _vp, _vp]),
     "yn_postprocess": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_infer": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_pack_detections": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "yn_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_loss_heads": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_train_param_count": (ctypes.c_int64, [_vp]),
@@ -63,6 +66,8 @@ SIGNATURES = {
     "yn_train_bind": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64]),
     "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
+    "yn_train_skipped_steps": (_i32, [_vp, _i64p]),
+    "yn_train_precision": (_i32, [_vp, _i32]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "yn_preprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "yn_preprocess_batch": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
@@ -71,6 +76,7 @@ SIGNATURES = {
     "yn_sgd_step": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _f32, _f32, _f32, _f32, _i32]),
     "yn_op_dwconv3x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_pwconv": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "yn_op_pwconv_shuffle": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_conv3x3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_stem": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "yn_op_maxpool3x3s2": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -146,6 +152,7 @@ class Handle:
             if self.lib.yn_create(ctypes.byref(cfg), ctypes.byref(h)):
                 raise YnError("yn_create: " + self.lib.yn_last_error(None).decode())
         self.h = h
+        self._stream_ptr = cfg.stream
         self.C, self.S = int(num_classes), int(input_size)
         self.backbone = backbone
         self.head_ch = arch.head_channels(self.C, self.A)
@@ -176,6 +183,15 @@ class Handle:
 
     def set_stream(self, stream):
         self._ck(self.lib.yn_set_stream(self.h, stream.cuda_stream), "yn_set_stream")
+        self._stream_ptr = stream.cuda_stream
+
+    def follow_current_stream(self):
+        """Re-home the handle onto torch's current stream of its device when that differs from the one it launches on
+        (the old stream is drained first: the activation arena is shared).  The host shim calls this before every forward so
+        that `with torch.cuda.stream(s): model(x)` orders the HIP kernels with the torch ops issued on `s`."""
+        st = torch.cuda.current_stream(self.device)
+        if st.cuda_stream != self._stream_ptr:
+            self.set_stream(st)
 
     def set_thresholds(self, conf, nms, diou=False):
         self._ck(self.lib.yn_set_thresholds(self.h, float(conf), float(nms), int(bool(diou))), "yn_set_thresholds")
@@ -252,6 +268,14 @@ class Handle:
         self._ck(self.lib.yn_forward_raw(self.h, x.data_ptr(), B, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()), "yn_forward_raw")
         return out
 
+    def forward_taps(self, x):
+        """The backbone taps (c3, c4, c5) of ShuffleNetV2.forward, NHWC."""
+        B, S = x.shape[0], self.S
+        ch = arch.STAGE_CH[self.backbone]
+        outs = [torch.empty((B, S // st, S // st, c), dtype=torch.float32, device=x.device) for st, c in zip((8, 16, 32), ch)]
+        self._ck(self.lib.yn_forward_taps(self.h, x.contiguous().data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_forward_taps")
+        return outs
+
     def score_full(self, heads):
         B = heads[0].shape[0]
         N = self.N
@@ -309,6 +333,29 @@ class Handle:
         out = self.alloc_outputs(B, device=x.device) if out is None else out
         self._ck(self.lib.yn_infer(self.h, x.data_ptr(), B, *[o.data_ptr() for o in out]), "yn_infer")
         return out
+
+    def pack_detections(self, out, rec=None, offsets=None):
+        """Kept rows of all images of `out` (infer / postprocess outputs) as one record list rec [B*N, 6] = x1,y1,x2,y2,score,class
+        (first offsets[B] rows valid) + offsets [B+1] int32, both on the device (yn_pack_detections)."""
+        boxes, scores, cls, _, count = out
+        B, N = scores.shape
+        rec = torch.empty((B * N, 6), dtype=torch.float32, device=scores.device) if rec is None else rec
+        offsets = torch.empty((B + 1,), dtype=torch.int32, device=scores.device) if offsets is None else offsets
+        self._ck(self.lib.yn_pack_detections(self.h, boxes.data_ptr(), scores.data_ptr(), cls.data_ptr(), count.data_ptr(), B, N,
+                                             rec.data_ptr(), offsets.data_ptr()), "yn_pack_detections")
+        return rec, offsets
+
+    def detections_to_host(self, out):
+        """models/yolo_nano.py:370-376 for a whole batch with two device-to-host copies: -> list of B (bboxes [K,4] f32,
+        scores [K] f32, cls_inds [K] i64) numpy triples, fresh and writable."""
+        rec, offsets = self.pack_detections(out)
+        off = offsets.cpu().numpy()
+        host = rec[: int(off[-1])].cpu().numpy()
+        res = []
+        for b in range(len(off) - 1):
+            r = host[off[b]:off[b + 1]]
+            res.append((r[:, :4].copy(), r[:, 4].copy(), r[:, 5].astype(np.int64)))
+        return res
 
     # ---- training loss
     def loss(self, conf, cls, txtytwth, target, grads=True):
@@ -421,6 +468,15 @@ class Handle:
         self._ck(self.lib.yn_train_bind(self.h, self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.flat_momentum.data_ptr(), n), "yn_train_bind")
         return n
 
+    def train_precision(self, dtype="f32"):
+        """Arithmetic of train_step: "f32" (the reference's own) or "f16" (fp16 storage + f16 MFMA, fp32 master weights, loss scaling)."""
+        self._ck(self.lib.yn_train_precision(self.h, {"f32": 0, "fp32": 0, "f16": 1, "fp16": 1}[dtype]), "yn_train_precision")
+
+    def skipped_steps(self):
+        n = ctypes.c_int64(0)
+        self._ck(self.lib.yn_train_skipped_steps(self.h, ctypes.byref(n)), "yn_train_skipped_steps")
+        return int(n.value)
+
     def param_slice(self, key):
         off, num = ctypes.c_int64(), ctypes.c_int64()
         self._ck(self.lib.yn_train_param_offset(self.h, key.encode(), ctypes.byref(off), ctypes.byref(num)), "yn_train_param_offset")
@@ -471,6 +527,14 @@ class Handle:
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
         self._ck(self.lib.yn_op_pwconv(self.h, _ptr(x.contiguous()), B, H, W, Cin, Cout, _ptr(w.contiguous()),
                                        _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_pwconv")
+        return y
+
+    def op_pwconv_shuffle(self, x, passthrough, w, bias, act=0):
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, H, W, 2 * Cout), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.yn_op_pwconv_shuffle(self.h, x.contiguous().data_ptr(), passthrough.contiguous().data_ptr(), B, H, W, Cin, Cout,
+                                               w.contiguous().data_ptr(), _ptr(bias), act, y.data_ptr()), "yn_op_pwconv_shuffle")
         return y
 
     def op_conv3x3(self, x, w, bias, act=0, x2=None, resample=0):

@@ -342,9 +342,9 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
         const size_t lds = unit_chain_lds(a.bf, BM, BN);                                                               \
         if (lds > 160 * 1024) return false;                                                                            \
         if (dry) return true;                                                                                          \
-        static bool attr = false;                                                                                      \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain_kernel<WMv, WNv, NTv, Vv>),    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        static unsigned long long attr = 0;                                                                                      \
+        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain_kernel<WMv, WNv, NTv, Vv>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
         set_last_kernel_name("unit_chain_kernel<" #WMv "," #WNv "," #NTv "," #Vv ">");                                      \
         hipLaunchKernelGGL((unit_chain_kernel<WMv, WNv, NTv, Vv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
         return true;                                                                                                   \
@@ -536,9 +536,9 @@ bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s)
     {                                                                                                                  \
         constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
         const size_t lds = dwpw_tile_lds(a.K, BM, BN);                                                                 \
-        static bool attr = false;                                                                                      \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        static unsigned long long attr = 0;                                                                                      \
+        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
         set_last_kernel_name("dwpw_tile_kernel<" #WMv "," #WNv "," #NTv "," #Vv "," #Sv ">");                               \
         hipLaunchKernelGGL((dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
         return true;                                                                                                   \

@@ -7,8 +7,8 @@
 //   dwconv3x3_kernel   depthwise 3x3 (stride 1/2), one thread per (pixel, channel pair)
 //   stem_kernel        3->24 3x3 stride-2 conv reading NCHW input, writing NHWC
 //   maxpool_kernel     3x3 stride-2 max pool
-//   (+ gemm_direct_kernel, gemm_persist_kernel, conv3x3_halo*_kernel, dwpw_halo_kernel, stem_pool_kernel: see their headers;
-//    the multi-layer tile kernels live in kernels_chain.hip / kernels_unit.hip, the shared device helpers in yn_device.h)
+//   (+ gemm_direct_kernel, conv3x3_halo*_kernel, stem_pool_kernel: see their headers;
+//    the multi-layer tile kernels live in kernels_chain.hip, the shared device helpers in yn_device.h)
 //
 // Reference semantics: backbone/shufflenetv2.py:31-78,109-116, utils/modules.py:8-18,
 // models/yolo_nano.py:286-301 — with BatchNorm folded into the weights (utils/fuse_conv_bn.py:6-22).
@@ -330,163 +330,6 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs a)
     }
     const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
     gemm_epilogue<NT>(a, acc, mbase, nbase, vecO, lane);
-}
-
-// -------------------------------------------------------------------------------------------------
-// Persistent pointwise GEMM for thin K (K <= 128).  The tiled kernel above re-stages the K x BN weight slice for
-// every 32..128-row tile and runs "load -> barrier -> MFMA -> store" once per block, so a launch of a few hundred
-// blocks is mostly latency.  Here the weight slice of the block column is staged into LDS ONCE and a block walks
-// 64-row M tiles (tile = blockIdx.x + i*gridDim.x): the next tile's A rows are requested from global memory before the
-// MFMAs of the current tile are issued and written to the other A buffer after its epilogue, so the loads, MFMAs and
-// stores of consecutive tiles overlap inside a block.  Same fragment layout and k order as gemm_conv_kernel => results
-// are bit-identical to every tiled configuration.  Block = 4 waves as 2 (M) x 2 (N), 32 x (32*NTW) per wave.
-// -------------------------------------------------------------------------------------------------
-template <int NTW>
-__global__ __launch_bounds__(256) void gemm_persist_kernel(GemmArgs a)
-{
-    constexpr int BM = 64, BN = 64 * NTW, AS = BM * 2 + 2, BS = BN * 2, A_MAX = 8;
-    extern __shared__ __attribute__((aligned(16))) float ps_smem[];
-    const int nq = (a.K + 3) >> 2, kpn = 2 * nq, kp_total = (a.K + 1) >> 1;
-    float* Bs = ps_smem;                                     // [kpn][BS]
-    float* As = Bs + (size_t)kpn * BS;                       // [2][kpn][AS]
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int n0 = blockIdx.y * BN;
-    const int ntiles = (a.M + BM - 1) / BM;
-    const bool vecA = ((a.K | a.in_ld | a.in_off) & 3) == 0;
-    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
-    const int kqn = vecA ? (a.K >> 2) : (a.K >> 1);          // 16- or 8-byte groups per row
-    const int agroups = BM * kqn;
-
-    float4 a_reg[A_MAX];
-    auto prefetch_a = [&](int tile) {
-        const int m0 = tile * BM;
-#pragma unroll
-        for (int i = 0; i < A_MAX; ++i) {
-            const int idx = t + 256 * i;
-            const int row = idx / kqn, kq = idx - row * kqn;
-            const int m = m0 + row;
-            const bool ok = idx < agroups && m < a.M;
-            const unsigned mk = opaque_mask(ok);
-            const float* src = a.in + (size_t)(ok ? m : m0) * a.in_ld + a.in_off + (ok ? kq : 0) * (vecA ? 4 : 2);
-            if (vecA) a_reg[i] = vmask(*reinterpret_cast<const float4*>(src), mk);
-            else { const float2 v = vmask(*reinterpret_cast<const float2*>(src), mk); a_reg[i] = make_float4(v.x, v.y, 0.0f, 0.0f); }
-        }
-    };
-    auto stage_a = [&](int buf) {
-        float* Ab = As + (size_t)buf * kpn * AS;
-#pragma unroll
-        for (int i = 0; i < A_MAX; ++i) {
-            const int idx = t + 256 * i;
-            if (idx >= agroups) continue;
-            const int row = idx / kqn, kq = idx - row * kqn;
-            if (vecA) {
-                *reinterpret_cast<float2*>(Ab + (2 * kq) * AS + row * 2) = make_float2(a_reg[i].x, a_reg[i].y);
-                *reinterpret_cast<float2*>(Ab + (2 * kq + 1) * AS + row * 2) = make_float2(a_reg[i].z, a_reg[i].w);
-            } else {
-                *reinterpret_cast<float2*>(Ab + kq * AS + row * 2) = make_float2(a_reg[i].x, a_reg[i].y);
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch_a(tile);
-    // weights of this block column, once; k-pair rows past K are zero
-    for (int i0 = t; i0 < kpn * (BN / 2); i0 += 256 * 4) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = i0 + 256 * u;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            const int n = n0 + c4 * 2;
-            const bool ok = idx < kpn * (BN / 2) && kp < kp_total && n < a.Npad;
-            v[u] = vmask(*reinterpret_cast<const float4*>(a.Wp + ((size_t)(ok ? kp : 0) * a.Npad + (ok ? n : 0)) * 2), opaque_mask(ok));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = i0 + 256 * u;
-            if (idx < kpn * (BN / 2)) *reinterpret_cast<float4*>(Bs + (size_t)(idx / (BN / 2)) * BS + (idx % (BN / 2)) * 4) = v[u];
-        }
-    }
-    // zero the k-pair rows of both A buffers that no tile ever writes (K % 4 == 2)
-    for (int i = t; i < 2 * (kpn - kp_total) * AS; i += 256) {
-        const int buf = i / ((kpn - kp_total) * AS), r = i - buf * (kpn - kp_total) * AS;
-        As[(size_t)buf * kpn * AS + (size_t)kp_total * AS + r] = 0.0f;
-    }
-    if (tile < ntiles) stage_a(0);
-    __syncthreads();
-
-    for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) prefetch_a(next);                 // in flight during this tile's MFMAs and stores
-        f32x16 acc[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-        const float* Ab = As + (size_t)buf * kpn * AS + (wm * 32 + l31) * 2 + h * AS;
-        const float* Bb = Bs + (wn * NTW * 32 + l31) * 2 + h * BS;
-        float2 av = *reinterpret_cast<const float2*>(Ab);
-        float2 bv[NTW];
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-        for (int q = 0; q < nq; ++q) {
-            const int qn = q + 1 < nq ? q + 1 : q;           // fragments of step q+1 are read before the MFMAs of step q
-            const float2 av_n = *reinterpret_cast<const float2*>(Ab + 2 * qn * AS);
-            float2 bv_n[NTW];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * qn * BS + nt * 64);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            av = av_n;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bv[nt] = bv_n[nt];
-        }
-        gemm_epilogue<NTW>(a, acc, tile * BM + wm * 32, n0 + wn * NTW * 32, vecO, lane);
-        if (next < ntiles) stage_a(buf ^ 1);
-        __syncthreads();
-    }
-}
-
-static size_t gemm_persist_lds(int K, int NTW)
-{
-    const int kpn = 2 * ((K + 3) >> 2);
-    return ((size_t)kpn * (64 * NTW * 2) + 2 * (size_t)kpn * (64 * 2 + 2)) * sizeof(float);
-}
-
-// false when the shape is not covered (K > 128, odd K, or unaligned thin rows wider than 64)
-static bool launch_pw_persist(const GemmArgs& a, int NTW, hipStream_t s)
-{
-    const bool vecA = ((a.K | a.in_ld | a.in_off) & 3) == 0;
-    if ((a.K & 1) || a.K > 128 || (!vecA && a.K > 64) || a.K < 2) return false;
-    const size_t lds = gemm_persist_lds(a.K, NTW);
-    if (lds > 160 * 1024) return false;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_persist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    const int BN = 64 * NTW;
-    const int gy = (a.Npad + BN - 1) / BN;
-    const int ntiles = (a.M + 63) / 64;
-    int bpc = (int)((160 * 1024) / lds);                     // blocks that fit a CU
-    if (bpc > 4) bpc = 4;
-    if (bpc < 1) bpc = 1;
-    int gx = (256 * bpc) / gy;
-    if (gx < 1) gx = 1;
-    if (gx > ntiles) gx = ntiles;
-    g_last_kernel = NTW == 1 ? "gemm_persist_kernel<1>" : "gemm_persist_kernel<2>";
-    if (NTW == 1) hipLaunchKernelGGL(gemm_persist_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(gemm_persist_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a);
-    return true;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -853,233 +696,6 @@ static size_t conv3x3_halo_lds(int W, int Cin, int NT)
     return ((size_t)((npix * (Cin + 2) + 3) & ~3) + 2 * 16 * (32 * NT * 2)) * sizeof(float);
 }
 
-// -------------------------------------------------------------------------------------------------
-// Depthwise 3x3 (stride 1, pad 1) fused into the pointwise conv that consumes it (ShuffleV2 branch2
-// dw -> pw2, head dw -> pw).  The depthwise OUTPUT never exists in memory: a block stages the flat halo
-// [p0 - W - 1, p0 + BM + W + 1) x Cin of the depthwise INPUT once in LDS, and every lane computes its MFMA
-// A fragment (row = output pixel, two consecutive channels) on the fly as the 9-tap weighted sum
-// (+ folded-BN bias, + activation for the heads) right before the MFMAs that consume it.  Per k-step that is
-// 18 ds_read_b64 and ~20 VALU ops hidden behind 2*NT 64-cycle MFMAs.  The pointwise weights stream through a
-// double buffer as in the GEMM kernel; the epilogue is the GEMM's (bias, activation, concat+shuffle).
-// Blocks: WM waves along M (BM = 32*WM), 4/WM waves along N.
-// -------------------------------------------------------------------------------------------------
-template <int WM, int NT>
-__global__ __launch_bounds__(256) void dwpw_halo_kernel(GemmArgs a)
-{
-    constexpr int WN = 4 / WM, BM = 32 * WM, BN = 32 * NT * WN, KP = 16, BS = BN * 2, B_PER = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) float dp_smem[];
-    const int Cin = a.K, CS = Cin + 2;
-    const int W = a.W, H = a.H, HW = H * W;
-    const int npix = BM + 2 * W + 2;
-    float* halo = dp_smem;                                   // [npix][CS]
-    float* Bs = dp_smem + ((npix * CS + 3) & ~3);            // [2][KP][BS]
-    float* wdw = Bs + 2 * KP * BS;                           // [9][CS] taps, then [CS] bias   (CS even => 8-byte aligned rows)
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave % WM, wn = wave / WM;
-    const int p0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;   // XCD-contiguous tile order (gridDim.x is a multiple of 8)
-    if (p0 >= a.M) return;
-    const int n0 = blockIdx.y * BN;
-    const int base = p0 - W - 1;
-    const int nchunks = (Cin + 31) >> 5;
-    const int kp_total = (Cin + 1) >> 1;
-
-    float4 b_reg[B_PER];
-    auto prefetch_b = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            const int kpg = c * KP + kp;
-            const int n = n0 + c4 * 2;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kpg < kp_total && n < a.Npad) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + n) * 2);
-            b_reg[i] = v;
-        }
-    };
-    auto stage_b = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = b_reg[i];
-        }
-    };
-    prefetch_b(0);
-
-    // depthwise taps + bias -> LDS (pad columns zero)
-    for (int i = t; i < 10 * CS; i += 256) {
-        const int row = i / CS, c = i - row * CS;
-        float v = 0.0f;
-        if (c < Cin) v = row < 9 ? a.dw_w[row * Cin + c] : a.dw_b[c];
-        wdw[i] = v;
-    }
-    // halo of the depthwise input; thread = (channel pair incl. the zero pad pair, pixel lane)
-    {
-        constexpr int U = 8;
-        const int cpn = CS >> 1;
-        const int ppl = 256 / cpn;
-        const int cp = t % cpn, pl = t / cpn;
-        if (pl < ppl) {
-            for (int i0 = pl; i0 < npix; i0 += ppl * U) {
-                float2 v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * ppl;
-                    const int q = base + i;
-                    v[u] = make_float2(0.0f, 0.0f);
-                    if (i < npix && q >= 0 && q < a.M && 2 * cp < Cin)
-                        v[u] = *reinterpret_cast<const float2*>(a.in + (size_t)q * a.in_ld + a.in_off + 2 * cp);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * ppl;
-                    if (i < npix) *reinterpret_cast<float2*>(halo + i * CS + 2 * cp) = v[u];
-                }
-            }
-        }
-    }
-    stage_b(0);
-
-    // per-lane tap validity of this lane's output pixel
-    const int r = wm * 32 + l31;
-    const int m = p0 + r;
-    unsigned tapmask = 0;
-    if (m < a.M) {
-        const int rem = m % HW;
-        const int y = rem / W, x = rem - y * W;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) tapmask |= 1u << tap;
-        }
-    }
-    __syncthreads();
-
-    // A fragment (two consecutive channels k, k+1 of this lane's pixel) = depthwise output, computed from LDS
-    const float* hp = halo + (W + 1 + r) * CS + 2 * h;
-    auto dw_frag = [&](int k) {
-        float2 acc = *reinterpret_cast<const float2*>(wdw + 9 * CS + k + 2 * h);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int off = (tap / 3 - 1) * W + (tap % 3 - 1);
-            float2 v = *reinterpret_cast<const float2*>(hp + off * CS + k);
-            const float2 w = *reinterpret_cast<const float2*>(wdw + tap * CS + k + 2 * h);
-            if (!((tapmask >> tap) & 1u)) v = make_float2(0.0f, 0.0f);
-            acc.x += v.x * w.x;
-            acc.y += v.y * w.y;
-        }
-        return make_float2(apply_act(acc.x, a.dw_act), apply_act(acc.y, a.dw_act));
-    };
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
-
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) prefetch_b(c + 1);
-        const int krem = Cin - (c << 5);
-        const int nq = krem >= 32 ? 8 : ((krem + 3) >> 2);
-        const float* Bb = Bs + buf * KP * BS + (wn * NT * 32 + l31) * 2 + h * BS;
-        float2 av = dw_frag(c << 5);
-        float2 bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q < nq) {
-                float2 av_n = av, bv_n[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-                if (q + 1 < nq) {
-                    av_n = dw_frag((c << 5) + 4 * (q + 1));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                av = av_n;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-            }
-        }
-        if (c + 1 < nchunks) stage_b(buf ^ 1);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + l31;
-        if (n >= a.N) continue;
-        const float bias = a.bias[n];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
-            const int mm = p0 + wm * 32 + row;
-            if (mm >= a.M) continue;
-            const float v = apply_act(acc[nt][k] + bias, a.act);
-            if (a.pass) {
-                const float p = a.pass[(size_t)mm * a.pass_ld + a.pass_off + n];
-                *reinterpret_cast<float2*>(a.out + (size_t)mm * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
-            } else {
-                a.out[(size_t)mm * a.out_ld + a.out_off + n] = v;
-            }
-        }
-    }
-}
-
-static size_t dwpw_lds(int W, int Cin, int BM, int BN)
-{
-    const int npix = BM + 2 * W + 2, CS = Cin + 2;
-    return ((size_t)((npix * CS + 3) & ~3) + 2 * 16 * (BN * 2) + 10 * CS) * sizeof(float);
-}
-
-bool launch_dwpw(const GemmArgs& a, hipStream_t s)
-{
-    if ((a.K & 1) || a.K + 2 > 512) return false;
-    const int nt32 = a.Npad / 32;
-    struct Cand { int wm, nt; };
-    // (WM, NT): BM = 32*WM, BN = 32*NT*(4/WM).  Prefer covering N in one block column with the largest BM that fits LDS.
-    static const Cand cands[] = {{4, 4}, {4, 3}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
-    int best = -1;
-    long best_blocks = 0;
-    for (int i = 0; i < (int)(sizeof(cands) / sizeof(cands[0])); ++i) {
-        const int BM = 32 * cands[i].wm, BN = 32 * cands[i].nt * (4 / cands[i].wm);
-        if (BN > a.Npad && !(cands[i].nt == 1 && 4 / cands[i].wm == 1)) { if (BN - a.Npad >= 32) continue; }
-        if (a.Npad % BN != 0 && BN < a.Npad) continue;
-        if (dwpw_lds(a.W, a.K, BM, BN) > 160 * 1024) continue;
-        const long blocks = ((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN);
-        if (best < 0 || (best_blocks < 256 && blocks > best_blocks)) { best = i; best_blocks = blocks; }
-    }
-    if (best < 0) return false;
-    const int wm = cands[best].wm, nt = cands[best].nt;
-    const int BM = 32 * wm, BN = 32 * nt * (4 / wm);
-    const size_t lds = dwpw_lds(a.W, a.K, BM, BN);
-    dim3 grid(xcd_grid((a.M + BM - 1) / BM), (a.Npad + BN - 1) / BN);
-#define YN_DWPW_CASE(WMv, NTv)                                                                                   \
-    if (wm == WMv && nt == NTv) {                                                                                \
-        static bool attr = false;                                                                                \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_halo_kernel<WMv, NTv>),        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-        g_last_kernel = "dwpw_halo_kernel<" #WMv "," #NTv ">";                                                    \
-        hipLaunchKernelGGL((dwpw_halo_kernel<WMv, NTv>), grid, dim3(256), lds, s, a);                            \
-        return true;                                                                                             \
-    }
-    YN_DWPW_CASE(4, 4) YN_DWPW_CASE(4, 3) YN_DWPW_CASE(4, 2) YN_DWPW_CASE(4, 1)
-    YN_DWPW_CASE(2, 4) YN_DWPW_CASE(2, 2) YN_DWPW_CASE(2, 1) YN_DWPW_CASE(1, 2) YN_DWPW_CASE(1, 1)
-#undef YN_DWPW_CASE
-    return false;
-}
-
 struct TileCfg { int WM, WN, NT, KP, NBUF; };
 
 // Every instantiated tile configuration of the pointwise GEMM.  All of them compute bit-identical results,
@@ -1121,9 +737,8 @@ static const char* const g_pwd_names[] = {
 };
 constexpr int N_PWD_CFGS = (int)(sizeof(g_pwd_cfgs) / sizeof(g_pwd_cfgs[0]));
 
-// tile configurations of gemm_conv_kernel, then the two persistent variants (gemm_persist_kernel<1>, <2>), then the
-// register-direct configurations
-int pw_config_count() { return N_PW_CFGS + 2 + N_PWD_CFGS; }
+// tile configurations of gemm_conv_kernel, then the register-direct configurations
+int pw_config_count() { return N_PW_CFGS + N_PWD_CFGS; }
 
 // false when the layer's strides do not allow 16-byte A loads
 static bool launch_pw_direct(const GemmArgs& a, int idx, hipStream_t s)
@@ -1184,8 +799,7 @@ static int choose_pw_cfg(int M, int K, int Npad)
 void launch_pw(const GemmArgs& a, hipStream_t s)
 {
     int idx = a.cfg;
-    if (idx >= N_PW_CFGS && idx < N_PW_CFGS + 2 && launch_pw_persist(a, idx - N_PW_CFGS + 1, s)) return;
-    if (idx >= N_PW_CFGS + 2 && idx < N_PW_CFGS + 2 + N_PWD_CFGS && launch_pw_direct(a, idx - N_PW_CFGS - 2, s)) return;
+    if (idx >= N_PW_CFGS && idx < N_PW_CFGS + N_PWD_CFGS && launch_pw_direct(a, idx - N_PW_CFGS, s)) return;
     if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
     const TileCfg& c = g_pw_cfgs[idx];
     const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
@@ -1222,12 +836,11 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
     // tiles) split N over three block columns instead: the kernel is then latency- not MFMA-bound.
     if (a.K == 96 && NT == 3 && a.in_off == 0 && a.in_ld == 96 && (a.N & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_off & 3) == 0 &&
         conv3x3_halo_tap_lds(a.W, 96, 3) <= 160 * 1024) {
-        static bool attr_t = false;
-        if (!attr_t) {
+        static unsigned long long attr_t = 0;
+        if (attr_pending(attr_t)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<3, 96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_tap_kernel<1, 96, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_t = true;
         }
         const int tiles = (a.M + 127) / 128;
         static const int two_per_cu = getenv("YN_C3_SPLIT") ? atoi(getenv("YN_C3_SPLIT")) : 1;
@@ -1246,12 +859,11 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
     }
     const size_t lds = (a.K % 32 == 0 && a.in_off == 0) ? conv3x3_halo_lds(a.W, a.K, NT) : (size_t)1 << 30;
     if (lds <= 160 * 1024 && a.K / 2 <= 256) {
-        static bool attr = false;
-        if (!attr) {
+        static unsigned long long attr = 0;
+        if (attr_pending(attr)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
         }
         dim3 grid((a.M + 127) / 128, a.Npad / (32 * NT));
         if (NT == 3) { g_last_kernel = "conv3x3_halo_kernel<3>"; hipLaunchKernelGGL(conv3x3_halo_kernel<3>, grid, dim3(256), lds, s, a); }

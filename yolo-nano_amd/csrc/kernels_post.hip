@@ -540,8 +540,10 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
 // resolves the diagonal tile serially (scalar readlanes; the next diagonal is prefetched meanwhile), then
 // all threads OR the kept rows' words of the band into rem[] (independent loads, LDS atomics on the few
 // non-zero words).  Returns the number of kept boxes.
-struct ResolveLds { u64 rem[512]; u64 keepm; int kidx[64]; int nk; };
-#define YN_RESOLVE_MAX_T 512            /* n <= 32768 per segment */
+// rem[] bounds the segment size: n <= 64 * YN_RESOLVE_MAX_T = 131 072 boxes of one class (nms_max_segment(); the C ABI
+// rejects larger work before anything is launched — the suppression matrix of such a segment would be > 1 GB anyway)
+#define YN_RESOLVE_MAX_T 2048
+struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; int kidx[64]; int nk; };
 
 __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
                                int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
@@ -705,6 +707,40 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
     if (threadIdx.x == 0) count[b] = base;
 }
 
+int nms_max_segment() { return 64 * YN_RESOLVE_MAX_T; }
+
+// The `.to('cpu').numpy()` hand-over of models/yolo_nano.py:370-376 for a whole batch: the kept rows of all B images as ONE
+// contiguous record list rec[total][6] = x1, y1, x2, y2, score, class (image order, ascending candidate order inside an
+// image) + offsets[B+1], so the host needs two copies per batch.  Block = one image; its base is the sum of the earlier counts.
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ cls,
+                                                   const int32_t* __restrict__ count, int B, int N, float* __restrict__ rec, int32_t* __restrict__ offsets)
+{
+    __shared__ int base_s, total_s;
+    const int b = blockIdx.x;
+    if (threadIdx.x < 64) {
+        int mine = 0, all = 0;
+        for (int i = threadIdx.x; i < B; i += 64) { const int c = count[i]; all += c; if (i < b) mine += c; }
+        for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o); all += __shfl_xor(all, o); }
+        if (threadIdx.x == 0) { base_s = mine; total_s = all; }
+    }
+    __syncthreads();
+    const int base = base_s, k = count[b];
+    if (threadIdx.x == 0) { offsets[b] = base; if (b == 0) offsets[B] = total_s; }
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const size_t src = (size_t)b * N + i;
+        const float4 bx = *reinterpret_cast<const float4*>(boxes + src * 4);
+        float* r = rec + (size_t)(base + i) * 6;            // 24-byte records: 8-byte aligned
+        *reinterpret_cast<float2*>(r) = make_float2(bx.x, bx.y);
+        *reinterpret_cast<float2*>(r + 2) = make_float2(bx.z, bx.w);
+        *reinterpret_cast<float2*>(r + 4) = make_float2(scores[src], (float)cls[src]);
+    }
+}
+
+void launch_pack(const float* boxes, const float* scores, const int32_t* cls, const int32_t* count, int B, int N, float* rec, int32_t* offsets, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_kernel, dim3(B), dim3(256), 0, s, boxes, scores, cls, count, B, N, rec, offsets);
+}
+
 size_t nms_matrix_words_per_image(int N, int C)
 {
     const size_t Tsum = (size_t)(N + 63) / 64 + C;          // sum_c ceil(n_c/64) <= N/64 + C
@@ -713,11 +749,10 @@ size_t nms_matrix_words_per_image(int N, int C)
 
 static void set_sort_attr()
 {
-    static bool done = false;
-    if (done) return;
+    static unsigned long long done = 0;
+    if (!attr_pending(done)) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(single_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
-    done = true;
 }
 
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,

@@ -257,9 +257,26 @@ void launch_make_targets(const double* labels, const int32_t* offsets, int B, co
 //     g = grad * grad_scale + wd * p ;  buf = first ? g : momentum * buf + g ;  p -= lr * buf
 // (dampening 0, nesterov off — the reference's settings).  16-byte accesses, grid-stride.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                   long n, float lr, float momentum, float wd, float grad_scale, int first)
+// flag[0] = 1 when the gradient bucket holds a NaN / Inf (zeroed by the launcher first): the step is then skipped as a whole —
+// the reference skips an iteration whose loss is NaN (train.py:225-226); with data-parallel ranks the all-reduced bucket is
+// non-finite on EVERY rank as soon as one rank's loss was, so all ranks take the same decision without a host round trip.
+__global__ __launch_bounds__(256) void grad_finite_kernel(const float* __restrict__ g, long n, int* __restrict__ flag)
 {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.0e38f);                      // false for NaN and Inf
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                   long n, float lr, float momentum, float wd, float grad_scale, int first, int* __restrict__ flag)
+{
+    if (flag && flag[0]) {                                  // non-finite gradient: leave parameters and momentum untouched
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&flag[1], 1);
+        return;
+    }
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -298,12 +315,16 @@ void launch_ema(float* v, const float* m, long n, float d, float omd, hipStream_
     hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, s, v, m, n, d, omd);
 }
 
-void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s)
+void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, int* flag, hipStream_t s)
 {
     long blocks = ((n >> 2) + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, grad_scale, first);
+    if (flag) {
+        (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+        hipLaunchKernelGGL(grad_finite_kernel, dim3((unsigned)(blocks > 512 ? 512 : blocks)), dim3(256), 0, s, g, n, flag);
+    }
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, grad_scale, first, flag);
 }
 
 }  // namespace ynk

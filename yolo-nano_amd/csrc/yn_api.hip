@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,8 @@ using namespace ynk;
 namespace {
 
 thread_local std::string g_create_error;
+std::mutex g_tune_mutex;
+std::map<std::vector<int>, int> g_pw_tuned;        // (device, M, K, N, strides...) -> fastest pointwise tile configuration
 
 struct Param {
     void* dev = nullptr;
@@ -86,9 +89,9 @@ struct yn_handle {
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
+    float* tap_out[3] = {nullptr, nullptr, nullptr};      // yn_forward_taps: where run_network copies c3 / c4 / c5
     float* loss_partial = nullptr;
     size_t loss_partial_cap = 0;
-    bool fuse_unit = false;              // stride-1 ShuffleV2 units as one kernel (kernels_unit.hip): parity-tested, measured slower — YN_FUSE_UNIT=1 enables
     // training (yn_train.inc): caller-owned flat buffers + per-layer packs + workspace
     float *tP = nullptr, *tG = nullptr, *tM = nullptr;
     int64_t tN = 0, tN_expected = 0;
@@ -96,14 +99,14 @@ struct yn_handle {
     std::map<std::string, size_t> toff;
     std::vector<TrainPack> tpacks;
     float* zeros = nullptr;
+    int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
+    int train_dtype = 0;                  // 0 fp32, 1 fp16 storage + f16 MFMA (yn_train_precision)
     std::vector<hipEvent_t> train_events;
     char* train_arena = nullptr;
     size_t train_arena_bytes = 0;
     // graphs / profiling
     bool use_graph = false;
     bool autotune = true;
-    bool fuse_dwpw = false;        // measured slower than dw + pw as two kernels (halo staging dominates thin-K layers)
-    std::map<std::vector<int>, int> pw_tuned;      // (M,K,N,...) -> tile configuration index
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
     bool dwpw_tile = false;                        // other depthwise convs fused into their pointwise consumer (dwpw_tile_kernel): parity-tested, measured slower — YN_DWPW_TILE=1
@@ -128,11 +131,26 @@ int fail(yn_handle* h, const char* fmt, ...)
     return 1;
 }
 
+// Every entry point runs with the handle's device current and restores the caller's afterwards (a handle created on
+// cuda:1 may be called while cuda:0 is current: its hipMallocs, launches and hipFuncSetAttributes must not land there).
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(const yn_handle* h);
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define YN_ENTER(h) if (!(h)) return 1; DevGuard dev_guard_(h)
+
 #define HIPCHK(h, expr)                                                                            \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail((h), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+DevGuard::DevGuard(const yn_handle* h)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != h->cfg.device && hipSetDevice(h->cfg.device) == hipSuccess) prev = cur;
+}
 
 const int STAGE_CH[4][3] = {{48, 96, 192}, {116, 232, 464}, {176, 352, 704}, {244, 488, 976}};
 const int STAGE_REP[3] = {4, 8, 4};
@@ -236,6 +254,13 @@ size_t network_arena_bytes(yn_handle* h, int B, int S)
     return fl * sizeof(float) + 64 * 256;
 }
 
+// every cached hipGraphExec_t refers to the buffers it was captured with: destroy them whenever those go away
+void drop_graphs(yn_handle* h)
+{
+    for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
 int ensure_arena(yn_handle* h, int B, int S)
 {
     const size_t need = network_arena_bytes(h, B, S);
@@ -243,7 +268,7 @@ int ensure_arena(yn_handle* h, int B, int S)
     if (h->arena) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
     HIPCHK(h, hipMalloc((void**)&h->arena, need));
     h->arena_bytes = need;
-    h->graphs.clear();
+    drop_graphs(h);
     return 0;
 }
 
@@ -258,6 +283,9 @@ float* arena_take(yn_handle* h, size_t floats)
 
 int ensure_post(yn_handle* h, int B, int N, int C)
 {
+    // worst case every candidate of an image falls into one class: that segment must fit resolve_segment()'s LDS mask
+    if (N > nms_max_segment())
+        return fail(h, "NMS over %d candidates per image exceeds the supported segment size %d", N, nms_max_segment());
     const size_t need = (size_t)B * N, need_seg = (size_t)B * (C + 1);
     const size_t m_stride = nms_matrix_words_per_image(N, C);
     const size_t need_m = m_stride * B;
@@ -273,7 +301,7 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.keep, need * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.sbox, need * 4 * sizeof(float)));
         h->nms_cap = need;
-        h->graphs.clear();
+        drop_graphs(h);
     }
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -284,14 +312,14 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.large_list, need_seg * sizeof(int32_t)));
         h->nms_seg_cap = need_seg;
-        h->graphs.clear();
+        drop_graphs(h);
     }
     if (need_m > h->nms_m_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->nms.matrix) { HIPCHK(h, hipFree(h->nms.matrix)); h->nms.matrix = nullptr; }
         HIPCHK(h, hipMalloc(&h->nms.matrix, need_m * sizeof(unsigned long long)));
         h->nms_m_cap = need_m;
-        h->graphs.clear();
+        drop_graphs(h);
     }
     h->nms.matrix_stride = m_stride;
     h->nms.large_cap = (N / 1024 + 1) < C ? (N / 1024 + 1) : C;       // at most N/1024 segments can exceed 1024 items
@@ -314,7 +342,7 @@ int ensure_heads(yn_handle* h, int B)
     h->heads_cap = need;
     h->heads_int[1] = h->heads_int[0] + (size_t)B * h->grid.hw[0] * hld;
     h->heads_int[2] = h->heads_int[1] + (size_t)B * h->grid.hw[1] * hld;
-    h->graphs.clear();
+    drop_graphs(h);
     return 0;
 }
 
@@ -360,10 +388,15 @@ int tune_pw(yn_handle* h, GemmArgs a)
     static const int forced = getenv("YN_PW_FORCE_CFG") ? atoi(getenv("YN_PW_FORCE_CFG")) : -1;     // debugging / A-B runs
     if (forced >= 0) return forced;
     if (h->force_pw_cfg >= 0) return h->force_pw_cfg;
-    const std::vector<int> key = {a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
-    auto it = h->pw_tuned.find(key);
-    if (it != h->pw_tuned.end()) return it->second;
-    if (!h->autotune || h->profiling) return -1;
+    if (!h->autotune) return -1;
+    // one table per process, shared by every handle (bench.py runs four per GPU: the layer shapes are timed once, not four times)
+    const std::vector<int> key = {h->cfg.device, a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        auto it = g_pw_tuned.find(key);
+        if (it != g_pw_tuned.end()) return it->second;
+    }
+    if (h->profiling) return -1;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->cur, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
     if (!h->tune_e0) { (void)hipEventCreate(&h->tune_e0); (void)hipEventCreate(&h->tune_e1); }
@@ -381,7 +414,10 @@ int tune_pw(yn_handle* h, GemmArgs a)
         if (ms < best_ms) { best_ms = ms; best = c; }
     }
     if (hipGetLastError() != hipSuccess) return -1;
-    h->pw_tuned[key] = best;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        g_pw_tuned[key] = best;
+    }
     return best;
 }
 
@@ -414,10 +450,8 @@ void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     launch_dw(a, h->cur);
 }
 
-// depthwise 3x3 (stride 1) + the pointwise conv that consumes it, fused (launch_dwpw); falls back to the two
-// separate kernels through `tmp` when the shape does not fit the fused kernel's LDS budget
-// stride-1 ShuffleV2 unit (backbone/shufflenetv2.py:70-72): x [B,H,W,C] -> out [B,H,W,C]; one fused kernel when the shape
-// fits (kernels_unit.hip), else pointwise -> depthwise -> pointwise with the concat+shuffle epilogue (t1, t2 scratch)
+// stride-1 ShuffleV2 unit (backbone/shufflenetv2.py:70-72): x [B,H,W,C] -> out [B,H,W,C] as pointwise -> depthwise ->
+// pointwise with the concat+shuffle epilogue (t1, t2 scratch); the one-kernel-per-unit form is run_unit_chain below
 void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, int in_ld, int in_off, int B, int H, int W,
               float* tmp, float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off);
 void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, int W, float* out, float* t1, float* t2)
@@ -427,14 +461,6 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
     const Layer& pw2 = L(h, P + ".b2.pw2");
     const int bf = pw1.cout, C = 2 * bf;
     const long M = (long)B * H * W;
-    if (h->fuse_unit && pw1.cin == bf && pw1.act == YN_ACT_RELU && pw2.act == YN_ACT_RELU && dw.stride == 1 && dw.act != YN_ACT_LEAKY) {
-        UnitArgs a{};
-        a.x = x; a.out = out; a.Wp1 = pw1.w_packed; a.b1 = pw1.b_packed; a.wdw = dw.w_packed; a.bdw = dw.b_packed;
-        a.Wp2 = pw2.w_packed; a.b2 = pw2.b_packed; a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw1.Npad; a.dw_act = dw.act;
-        Bracket br(h, P + ".unit", 2.0 * M * bf * (2.0 * bf + 9.0), 4.0 * (M * 4.0 * bf + 2.0 * bf * bf + 10.0 * bf));
-        if (launch_shuffle_unit(a, h->cur)) return;
-        br.cancel();
-    }
     run_pw(h, pw1, x, C, bf, M, t1, bf, 0, nullptr, 0, 0);
     run_dwpw(h, dw, pw2, t1, bf, 0, B, H, W, t2, out, C, 0, x, C, 0);
 }
@@ -445,7 +471,7 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
 // the stage ran, *result = final [M][C]; -1 on an error (latched in the handle).
 int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
 {
-    if (!h->unit_chain || h->fuse_unit || h->fuse_dwpw) return 0;
+    if (!h->unit_chain) return 0;
     const int bf = C / 2;
     const long M = (long)B * H * W;
     // A chain kernel's block runs its five phases back to back (17 / 27 / 47 us for bf = 58 / 116 / 232) whatever M is, so on
@@ -510,7 +536,7 @@ void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, i
 {
     const int Ho = (H - 1) / dw.stride + 1, Wo = (W - 1) / dw.stride + 1;
     const long M = (long)B * Ho * Wo;                       // output pixels
-    if (h->dwpw_tile && !h->fuse_dwpw) {
+    if (h->dwpw_tile) {
         // dwpw_tile_kernel: the depthwise output lives in an LDS tile only (kernels_conv.hip)
         GemmArgs a{};
         a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
@@ -522,19 +548,6 @@ void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, i
         Bracket br(h, dw.name + "+" + pw.name, 2.0 * M * (9.0 * dw.cout + (double)pw.cin * pw.cout),
                    4.0 * ((double)B * H * W * pw.cin + M * (double)(pw.cout + (pass ? 2 * pw.cout : 0)) + (double)pw.cin * pw.cout));
         if (dw.cout == pw.cin && launch_dwpw_tile(a, h->cur)) return;
-        br.cancel();
-    }
-    if (dw.stride == 1 && h->fuse_dwpw) {
-        GemmArgs a{};
-        a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
-        a.Wp = pw.w_packed; a.bias = pw.b_packed;
-        a.out = out; a.out_ld = out_ld; a.out_off = out_off;
-        a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
-        a.M = (int)M; a.K = pw.cin; a.N = pw.cout; a.Npad = pw.Npad; a.act = pw.act; a.cfg = -1;
-        a.dw_w = dw.w_packed; a.dw_b = dw.b_packed; a.dw_act = dw.act;
-        Bracket br(h, dw.name + "+" + pw.name, 2.0 * M * (9.0 * dw.cout + (double)pw.cin * pw.cout),
-                   4.0 * (M * (double)(pw.cin + pw.cout + (pass ? 2 * pw.cout : 0)) + (double)pw.cin * pw.cout));
-        if (launch_dwpw(a, h->cur)) return;
         br.cancel();
     }
     run_dw(h, dw, in, in_ld, in_off, B, H, W, tmp, dw.cout, 0);
@@ -658,6 +671,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             }
         }
         cfeat[si] = o_cur;
+        if (h->tap_out[si]) HIPCHK(h, hipMemcpyAsync(h->tap_out[si], o_cur, (size_t)Mo * C * sizeof(float), hipMemcpyDeviceToDevice, h->cur));
         cur = o_cur; curC = C; curH = Ho;
     }
     // neck: models/yolo_nano.py:286-296
@@ -767,11 +781,9 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
-    if (const char* e2 = getenv("YN_FUSE_UNIT")) h->fuse_unit = atoi(e2) != 0;      // A/B switch for the fused ShuffleV2 unit kernel
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
-    if (const char* e3 = getenv("YN_FUSE_DWPW")) h->fuse_dwpw = atoi(e3) != 0;      // A/B switch for the fused depthwise -> pointwise kernel
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
     *out = h;
@@ -781,6 +793,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
 void yn_destroy(yn_handle* h)
 {
     if (!h) return;
+    DevGuard dev_guard_(h);
     (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->params) if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (Layer& l : h->layers) {
@@ -799,6 +812,7 @@ void yn_destroy(yn_handle* h)
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->zeros) (void)hipFree(h->zeros);
+    if (h->skip_flag) (void)hipFree(h->skip_flag);
     for (hipEvent_t e : h->train_events) (void)hipEventDestroy(e);
     if (h->train_arena) (void)hipFree(h->train_arena);
     delete h;
@@ -806,7 +820,7 @@ void yn_destroy(yn_handle* h)
 
 int yn_set_grid(yn_handle* h, int input_size)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (set_grid_info(h, input_size)) return 1;
     h->cfg.input_size = input_size;
     return 0;
@@ -814,11 +828,10 @@ int yn_set_grid(yn_handle* h, int input_size)
 
 int yn_set_stream(yn_handle* h, void* stream)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((hipStream_t)stream != h->stream) {
         HIPCHK(h, hipStreamSynchronize(h->stream));        // the arena is shared: drain the old stream first
-        for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        h->graphs.clear();
+        drop_graphs(h);
     }
     h->stream = (hipStream_t)stream;
     h->cur = h->stream;
@@ -827,10 +840,9 @@ int yn_set_stream(yn_handle* h, void* stream)
 
 int yn_set_thresholds(yn_handle* h, float conf_thresh, float nms_thresh, int diou_nms)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (conf_thresh != h->cfg.conf_thresh || nms_thresh != h->cfg.nms_thresh || diou_nms != h->cfg.diou_nms) {
-        for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        h->graphs.clear();
+        drop_graphs(h);
     }
     h->cfg.conf_thresh = conf_thresh; h->cfg.nms_thresh = nms_thresh; h->cfg.diou_nms = diou_nms;
     return 0;
@@ -842,15 +854,14 @@ int yn_use_graph(yn_handle* h, int enable) { if (!h) return 1; h->use_graph = en
 
 int yn_autotune(yn_handle* h, int enable)
 {
-    if (!h) return 1;
-    h->autotune = enable != 0;
-    if (!enable) h->pw_tuned.clear();
+    YN_ENTER(h);
+    h->autotune = enable != 0;                              // off: this handle uses the static heuristic; the shared table stays
     return 0;
 }
 
 int yn_set_pw_config(yn_handle* h, int index)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (index >= pw_config_count()) return fail(h, "yn_set_pw_config: index %d out of range (%d configurations)", index, pw_config_count());
     h->force_pw_cfg = index < 0 ? -1 : index;
     return 0;
@@ -859,7 +870,7 @@ int yn_pw_config_count(void) { return pw_config_count(); }
 int yn_multi_stream(yn_handle* h, int enable) { if (!h) return 1; h->multi_stream = enable != 0; return 0; }
 int yn_unit_chain(yn_handle* h, int mode) { if (!h) return 1; h->unit_chain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 
-int yn_synchronize(yn_handle* h) { if (!h) return 1; HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
+int yn_synchronize(yn_handle* h) { YN_ENTER(h); HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 
 // ---- weights -----------------------------------------------------------------------------------
 static int load_param_impl(yn_handle* h, const char* key, const void* ptr, const int64_t* shape, int ndim, bool from_dev)
@@ -917,7 +928,7 @@ int yn_load_param_dev(yn_handle* h, const char* key, const void* dev_ptr, const 
 
 int yn_fold_bn(yn_handle* h)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (h->tP)                                              // after training: the flat buffer holds the current parameters
         for (const auto& kv : h->toff) {
             const Param* p = find_param(h, kv.first);
@@ -970,7 +981,7 @@ int yn_fold_bn(yn_handle* h)
 
 int yn_get_folded(yn_handle* h, const char* conv_key, float* host_weight, float* host_bias)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (!h->folded) return fail(h, "yn_get_folded before yn_fold_bn");
     auto it = h->by_conv.find(conv_key);
     if (it == h->by_conv.end()) return fail(h, "unknown conv '%s'", conv_key);
@@ -984,7 +995,7 @@ int yn_get_folded(yn_handle* h, const char* conv_key, float* host_weight, float*
 // ---- network -----------------------------------------------------------------------------------
 int yn_forward_raw(yn_handle* h, const float* x_dev, int B, float* head_s8, float* head_s16, float* head_s32)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (check_ready(h, B)) return 1;
     if (ensure_arena(h, B, h->grid.S)) return 1;
     float* const heads[3] = {head_s8, head_s16, head_s32};
@@ -992,9 +1003,22 @@ int yn_forward_raw(yn_handle* h, const float* x_dev, int B, float* head_s8, floa
     return run_maybe_graph(h, key, [&]() { return run_network(h, x_dev, B, heads, h->head_ch); });
 }
 
+int yn_forward_taps(yn_handle* h, const float* x_dev, int B, float* c3_dev, float* c4_dev, float* c5_dev)
+{
+    YN_ENTER(h);
+    if (check_ready(h, B)) return 1;
+    if (!c3_dev || !c4_dev || !c5_dev) return fail(h, "yn_forward_taps: null output");
+    if (ensure_arena(h, B, h->grid.S) || ensure_heads(h, B)) return 1;
+    float* const heads[3] = {h->heads_int[0], h->heads_int[1], h->heads_int[2]};
+    h->tap_out[0] = c3_dev; h->tap_out[1] = c4_dev; h->tap_out[2] = c5_dev;
+    const int rc = run_network(h, x_dev, B, heads, (h->head_ch + 3) & ~3);       // eager: the taps are not part of any captured graph
+    h->tap_out[0] = h->tap_out[1] = h->tap_out[2] = nullptr;
+    return rc;
+}
+
 int yn_score_full(yn_handle* h, const float* h8, const float* h16, const float* h32, int B, float* all_bbox, float* all_class)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     const float* const heads[3] = {h8, h16, h32};
     launch_score_full(heads, h->grid, B, all_bbox, all_class, h->stream);
     HIPCHK(h, hipGetLastError());
@@ -1003,7 +1027,7 @@ int yn_score_full(yn_handle* h, const float* h8, const float* h16, const float* 
 
 int yn_decode_boxes(yn_handle* h, const float* txtytwth, int B, float* xyxy)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     launch_decode_boxes(txtytwth, h->grid, B, xyxy, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1011,7 +1035,7 @@ int yn_decode_boxes(yn_handle* h, const float* txtytwth, int B, float* xyxy)
 
 int yn_create_grid(yn_handle* h, int input_size, float* grid, float* stride, float* anchor)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (input_size <= 0 || input_size % 32) return fail(h, "input_size must be a positive multiple of 32");
     const int A = h->cfg.num_anchors;
     size_t cell = 0;
@@ -1033,7 +1057,7 @@ int yn_create_grid(yn_handle* h, int input_size, float* grid, float* stride, flo
 // ---- post-processing ---------------------------------------------------------------------------
 int yn_nms(yn_handle* h, const float* dets, const float* scores, int n, float nms_thresh, int diou, int32_t* keep, int32_t* count)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (n < 0) return fail(h, "yn_nms: negative n");
     if (ensure_post(h, 1, n > 0 ? n : 1, 1)) return 1;
     launch_nms_single(dets, scores, n, nms_thresh, diou, h->nms.bucket, h->nms.sbox, h->nms.matrix, keep, count, h->stream);
@@ -1044,7 +1068,7 @@ int yn_nms(yn_handle* h, const float* dets, const float* scores, int n, float nm
 int yn_postprocess(yn_handle* h, const float* all_local, const float* all_conf, int B, int N, int C,
                    float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (B <= 0 || N < 0 || C <= 0) return fail(h, "yn_postprocess: bad sizes B=%d N=%d C=%d", B, N, C);
     if (N == 0) { HIPCHK(h, hipMemsetAsync(count, 0, sizeof(int32_t) * B, h->stream)); return 0; }
     if (ensure_post(h, B, N, C)) return 1;
@@ -1058,7 +1082,7 @@ int yn_postprocess(yn_handle* h, const float* all_local, const float* all_conf, 
 int yn_preprocess(yn_handle* h, const uint8_t* img, int h0, int w0, int rw, int rh, int left, int top, int side,
                   const float* mean, const float* stdv, float* x)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (!img || !x || !mean || !stdv) return fail(h, "yn_preprocess: null pointer");
     if (h0 <= 0 || w0 <= 0 || rw <= 0 || rh <= 0 || side <= 0 || left < 0 || top < 0 || left + rw > side || top + rh > side)
         return fail(h, "yn_preprocess: bad geometry (%dx%d -> %dx%d at (%d,%d) in %d)", w0, h0, rw, rh, left, top, side);
@@ -1071,7 +1095,7 @@ int yn_preprocess(yn_handle* h, const uint8_t* img, int h0, int w0, int rw, int 
 
 int yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs, const int32_t* geom, int side, const float* mean, const float* stdv, float* x)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (n == 0) return 0;                                   // an empty batch is not an error
     if (n < 0 || !imgs || !geom || !x || !mean || !stdv || side <= 0) return fail(h, "yn_preprocess_batch: bad arguments");
     for (int c = 0; c < 3; ++c)
@@ -1089,7 +1113,7 @@ int yn_preprocess_batch(yn_handle* h, int n, const uint8_t* const* imgs, const i
 int yn_nms_merge(yn_handle* h, const float* boxes, const float* scores, const int32_t* cls, int n, int num_classes, float nms_thresh, int diou,
                  float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (n < 0 || num_classes <= 0 || !count) return fail(h, "yn_nms_merge: bad arguments");
     if (n == 0) { HIPCHK(h, hipMemsetAsync(count, 0, sizeof(int32_t), h->stream)); return 0; }
     if (ensure_post(h, 1, n, num_classes)) return 1;
@@ -1101,7 +1125,7 @@ int yn_nms_merge(yn_handle* h, const float* boxes, const float* scores, const in
 int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* out_scores, int32_t* out_cls,
              int32_t* out_index, int32_t* count)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (check_ready(h, B)) return 1;
     GridInfo g = h->grid;
     g.head_ld = (h->head_ch + 3) & ~3;
@@ -1135,6 +1159,17 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
     });
 }
 
+int yn_pack_detections(yn_handle* h, const float* out_boxes, const float* out_scores, const int32_t* out_cls, const int32_t* count,
+                       int B, int N, float* rec_dev, int32_t* offsets_dev)
+{
+    YN_ENTER(h);
+    if (B <= 0 || N <= 0 || !out_boxes || !out_scores || !out_cls || !count || !rec_dev || !offsets_dev)
+        return fail(h, "yn_pack_detections: bad arguments");
+    launch_pack(out_boxes, out_scores, out_cls, count, B, N, rec_dev, offsets_dev, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 // ---- training loss ----------------------------------------------------------
 static int ensure_loss(yn_handle* h, int B)
 {
@@ -1150,7 +1185,7 @@ static int ensure_loss(yn_handle* h, int B)
 int yn_loss(yn_handle* h, const float* conf, const float* cls, const float* txtytwth, const float* target, int B,
             float* losses, float* g_conf, float* g_cls, float* g_txtytwth)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (B <= 0) return fail(h, "yn_loss: batch must be positive");
     if ((g_conf != nullptr) != (g_cls != nullptr) || (g_conf != nullptr) != (g_txtytwth != nullptr))
         return fail(h, "yn_loss: pass all three gradient buffers or none");
@@ -1164,7 +1199,7 @@ int yn_loss(yn_handle* h, const float* conf, const float* cls, const float* txty
 int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, const float* head_s32, const float* target, int B,
                   float* losses, float* g_s8, float* g_s16, float* g_s32)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (B <= 0) return fail(h, "yn_loss_heads: batch must be positive");
     if ((g_s8 != nullptr) != (g_s16 != nullptr) || (g_s8 != nullptr) != (g_s32 != nullptr))
         return fail(h, "yn_loss_heads: pass all three gradient buffers or none");
@@ -1180,7 +1215,7 @@ int yn_loss_heads(yn_handle* h, const float* head_s8, const float* head_s16, con
 
 int yn_make_targets(yn_handle* h, const double* labels_dev, const int32_t* offsets_dev, int B, const double* anchors_host, float* target_dev)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (B <= 0 || !offsets_dev || !target_dev || !anchors_host) return fail(h, "yn_make_targets: bad arguments");
     if (h->grid.A != 3) return fail(h, "yn_make_targets: the label assigner is defined for 3 anchors per scale (got %d)", h->grid.A);
     HIPCHK(h, hipMemsetAsync(target_dev, 0, (size_t)B * h->grid.N * 11 * sizeof(float), h->stream));
@@ -1191,7 +1226,7 @@ int yn_make_targets(yn_handle* h, const double* labels_dev, const int32_t* offse
 
 int yn_ema_update(yn_handle* h, float* ema_dev, const float* model_dev, int64_t n, double decay)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (n < 0 || (n > 0 && (!ema_dev || !model_dev))) return fail(h, "yn_ema_update: bad arguments");
     if (n == 0) return 0;
     launch_ema(ema_dev, model_dev, (long)n, (float)decay, (float)(1.0 - decay), h->stream);
@@ -1202,10 +1237,14 @@ int yn_ema_update(yn_handle* h, float* ema_dev, const float* model_dev, int64_t 
 int yn_sgd_step(yn_handle* h, float* params, const float* grads, float* momentum_buf, int64_t n,
                 float lr, float momentum, float weight_decay, float grad_scale, int first_step)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (n < 0 || !params || !grads || !momentum_buf) return fail(h, "yn_sgd_step: bad arguments");
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) return fail(h, "yn_sgd_step: buffers must be 16-byte aligned");
-    launch_sgd(params, grads, momentum_buf, (long)n, lr, momentum, weight_decay, grad_scale, first_step, h->stream);
+    if (!h->skip_flag) {
+        HIPCHK(h, hipMalloc((void**)&h->skip_flag, 2 * sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->skip_flag, 0, 2 * sizeof(int), h->stream));
+    }
+    launch_sgd(params, grads, momentum_buf, (long)n, lr, momentum, weight_decay, grad_scale, first_step, h->skip_flag, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -1245,7 +1284,7 @@ struct TmpLayer {
 
 int yn_op_dwconv3x3(yn_handle* h, const float* x, int B, int H, int W, int C, int stride, const float* w, const float* bias, int act, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (C & 1) return fail(h, "yn_op_dwconv3x3: C must be even");
     TmpLayer t(h, K_DW, C, C, stride, act, w, bias);
     if (t.rc) return fail(h, "yn_op_dwconv3x3: out of memory");
@@ -1256,7 +1295,7 @@ int yn_op_dwconv3x3(yn_handle* h, const float* x, int B, int H, int W, int C, in
 
 int yn_op_pwconv(yn_handle* h, const float* x, int B, int H, int W, int Cin, int Cout, const float* w, const float* bias, int act, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (Cin & 1) return fail(h, "yn_op_pwconv: Cin must be even");
     TmpLayer t(h, K_PW, Cin, Cout, 1, act, w, bias);
     if (t.rc) return fail(h, "yn_op_pwconv: out of memory");
@@ -1265,10 +1304,23 @@ int yn_op_pwconv(yn_handle* h, const float* x, int B, int H, int W, int Cin, int
     return 0;
 }
 
+int yn_op_pwconv_shuffle(yn_handle* h, const float* x, const float* pass, int B, int H, int W, int Cin, int Cout,
+                         const float* w, const float* bias, int act, float* y)
+{
+    YN_ENTER(h);
+    if ((Cin & 1) || (Cout & 1)) return fail(h, "yn_op_pwconv_shuffle: Cin and Cout must be even");
+    if (!pass) return fail(h, "yn_op_pwconv_shuffle: null pass-through tensor");
+    TmpLayer t(h, K_PW, Cin, Cout, 1, act, w, bias);
+    if (t.rc) return fail(h, "yn_op_pwconv_shuffle: out of memory");
+    run_pw(h, t.l, x, Cin, 0, (long)B * H * W, y, 2 * Cout, 0, pass, Cout, 0);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int yn_op_conv3x3(yn_handle* h, const float* x, const float* x2, int resample, int B, int H, int W, int Cin, int Cout,
                   const float* w, const float* bias, int act, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (Cin % 32) return fail(h, "yn_op_conv3x3: Cin must be a multiple of 32");
     if (resample && !x2) return fail(h, "yn_op_conv3x3: resample without x2");
     TmpLayer t(h, K_DENSE3, Cin, Cout, 1, act, w, bias);
@@ -1280,7 +1332,7 @@ int yn_op_conv3x3(yn_handle* h, const float* x, const float* x2, int resample, i
 
 int yn_op_stem(yn_handle* h, const float* x, int B, int H, int W, int Cout, const float* w, const float* bias, int act, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (Cout != 24) return fail(h, "yn_op_stem: Cout must be 24");
     TmpLayer t(h, K_STEM, 3, Cout, 2, act, w, bias);
     if (t.rc) return fail(h, "yn_op_stem: out of memory");
@@ -1291,7 +1343,7 @@ int yn_op_stem(yn_handle* h, const float* x, int B, int H, int W, int Cout, cons
 
 int yn_op_maxpool3x3s2(yn_handle* h, const float* x, int B, int H, int W, int C, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (C % 4) return fail(h, "yn_op_maxpool3x3s2: C must be a multiple of 4");
     launch_maxpool(x, B, H, W, C, y, h->stream);
     HIPCHK(h, hipGetLastError());
@@ -1300,7 +1352,7 @@ int yn_op_maxpool3x3s2(yn_handle* h, const float* x, int B, int H, int W, int C,
 
 int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, int H, int W, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (!h->folded) return fail(h, "yn_op_shuffle_block before yn_fold_bn");
     h->cur = h->stream;
     const std::string P = block;
@@ -1335,7 +1387,7 @@ int yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B, 
 
 int yn_op_nchw_to_nhwc(yn_handle* h, const float* x, int B, int C, int H, int W, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     launch_nchw_to_nhwc(x, B, C, H, W, y, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1343,7 +1395,7 @@ int yn_op_nchw_to_nhwc(yn_handle* h, const float* x, int B, int C, int H, int W,
 
 int yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W, float* y)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     launch_nhwc_to_nchw(x, B, C, H, W, y, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -1352,7 +1404,7 @@ int yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W,
 // ---- profiling ---------------------------------------------------------------------------------
 int yn_profile_enable(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     h->profiling = enable != 0;
     h->prof.clear();
     h->event_next = 0;
@@ -1364,7 +1416,7 @@ int yn_profile_count(yn_handle* h) { return h ? (int)h->prof.size() : -1; }
 int yn_profile_get(yn_handle* h, int i, char* name, int name_cap, char* kernel, int kernel_cap, float* ms,
                    double* alg_flops, double* alg_bytes)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (i < 0 || i >= (int)h->prof.size()) return fail(h, "yn_profile_get: index %d out of range", i);
     const ProfRec& r = h->prof[i];
     HIPCHK(h, hipEventSynchronize(r.e1));

@@ -29,17 +29,6 @@ struct DwArgs {
     int B, H, W, C, stride, act;                // H,W = input extent
 };
 
-// one stride-1 ShuffleV2 unit in a single kernel (kernels_unit.hip)
-struct UnitArgs {
-    const float* x; float* out;                 // [B,H,W,2*bf] NHWC; x1 = channels [0,bf), x2 = [bf,2bf)
-    const float* Wp1; const float* b1;          // pw1: packed [bf/2][Npad][2], bias [Npad] (BN folded, ReLU)
-    const float* wdw; const float* bdw;         // depthwise: [9][bf], [bf]
-    const float* Wp2; const float* b2;          // pw2
-    int B, H, W, bf, Npad, dw_act;
-    int CS, TH, TW, tilesY, tilesX;             // filled by the launcher
-};
-bool launch_shuffle_unit(const UnitArgs& a, hipStream_t s);
-
 // One kernel per stride-1 ShuffleV2 unit, cut at the unit's depthwise conv instead of at its input (kernels_conv.hip,
 // unit_chain_kernel): depthwise 3x3 -> pw2 -> concat+shuffle -> (the NEXT unit's pw1).
 struct ChainArgs {
@@ -60,8 +49,7 @@ void set_last_kernel_name(const char* n);
 int  pw_config_count();
 void launch_pw(const GemmArgs& a, hipStream_t s);
 void launch_conv3x3(const GemmArgs& a, hipStream_t s);
-// depthwise 3x3 (stride 1, pad 1) + pointwise 1x1 in one kernel; returns false when the shape does not fit
-bool launch_dwpw(const GemmArgs& a, hipStream_t s);
+// depthwise 3x3 + the pointwise 1x1 that consumes it in one kernel; returns false when the shape does not fit
 bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s);
 void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
@@ -114,12 +102,14 @@ struct NmsWork {                                // per-handle scratch, sized for
     int      large_cap;
 };
 size_t nms_matrix_words_per_image(int N, int C);
+int nms_max_segment();                      // largest per-class segment resolve_segment() can hold (its removed-mask lives in LDS)
 // optional per-kernel hook of launch_nms_pipeline: called with the kernel's name right before each launch (profiling brackets)
 struct NmsHook { void (*fn)(void* ctx, const char* kernel); void* ctx; };
 void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t* cls, int B, int N, int C,
                          float nms_thresh, int diou, const NmsWork& wk,
                          float* out_boxes, float* out_scores, int32_t* out_cls, int32_t* out_index, int32_t* count,
                          hipStream_t s, const NmsHook* hook = nullptr);
+void launch_pack(const float* boxes, const float* scores, const int32_t* cls, const int32_t* count, int B, int N, float* rec, int32_t* offsets, hipStream_t s);
 void launch_nms_single(const float* dets, const float* scores, int n, float thresh, int diou,
                        int32_t* ids_scratch, float* sbox_scratch, void* matrix_scratch, int32_t* keep, int32_t* count, hipStream_t s);
 
@@ -183,7 +173,8 @@ void launch_preprocess(const unsigned char* img, int h0, int w0, int rw, int rh,
 void launch_preprocess_batch(int n, const unsigned char* const* imgs, const int* geom, int side, const float* mean, const float* stdv,
                              float* out, hipStream_t s);
 void launch_ema(float* v, const float* m, long n, float d, float one_minus_d, hipStream_t s);
-void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, hipStream_t s);
+// flag: int[2] on the device or null — [0] set when g holds a NaN/Inf (the update is then skipped), [1] counts skipped steps
+void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale, int first, int* flag, hipStream_t s);
 
 // XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so with the identity mapping the
 // three input rows of a 3x3 window are fetched by three different L2s (PMC: FETCH_SIZE = 3.3x the input for the stage-3
@@ -191,5 +182,16 @@ void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float mo
 // CONTIGUOUS eighth of the tile range, so only the rows at the seven seams are fetched twice.
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) { return (b & 7u) * (nb >> 3) + (b >> 3); }
 inline unsigned xcd_grid(unsigned blocks) { return (blocks + 7u) & ~7u; }
+
+// hipFuncSetAttribute acts on the CURRENT device: every call site keeps a bit mask of the devices it has configured
+inline bool attr_pending(unsigned long long& mask)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
 
 }  // namespace ynk

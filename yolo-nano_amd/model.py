@@ -249,6 +249,7 @@ class YOLONano(nn.Module):
             self._handle.use_graph(self._graph)
             self._sig = None
         h = self._handle
+        h.follow_current_stream()
         if h.S != self.input_size:
             h.set_grid(self.input_size)
         h.set_thresholds(self.conf_thresh, self.nms_thresh, self.use_diou_nms)
@@ -313,9 +314,7 @@ class YOLONano(nn.Module):
     def forward_batch(self, x):
         """Eval-mode forward for EVERY image: list of (bboxes, scores, cls_inds) numpy triples."""
         h = self.handle(x.shape[0])
-        out = h.infer(x.float())
-        counts = out[4].cpu().tolist()
-        return [self._to_host(out, b, counts[b]) for b in range(x.shape[0])]
+        return h.detections_to_host(h.infer(x.float()))      # two device-to-host copies per batch (yn_pack_detections)
 
     # ---- training (models/yolo_nano.py:332-358, train.py:219-231) -----------------------------------------
     def _train_handle(self, batch):
@@ -338,6 +337,7 @@ class YOLONano(nn.Module):
                 raise YnError("flat parameter buffer holds %d values, the module %d" % (n, off))
             self._bound = h
             self._stats_stale = False
+        h.follow_current_stream()
         if h.S != self.input_size:                           # multi-scale training: train.py:202-208
             h.set_grid(self.input_size)
         if self._stats_stale:                                # load_state_dict after binding: push the BN statistics down

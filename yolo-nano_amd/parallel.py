@@ -96,13 +96,49 @@ class FlatBucket:
         return 1.0
 
 
+def broadcast_bn_buffers(module, src=0):
+    """BatchNorm running statistics are the one piece of model state the data-parallel step does NOT keep identical across ranks
+    (the reference has no SyncBN: each replica tracks the statistics of its own shard; parameters stay identical because every
+    rank applies the same all-reduced gradient).  Policy: at save time every rank adopts rank `src`'s buffers, so the
+    checkpoint rank 0 writes and the weights every rank evaluates with afterwards are the same.  Call before state_dict()."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 0
+    sd = module.state_dict()                                # the shim pulls the device-side statistics into the buffers here
+    bufs = [v for k, v in sd.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.reshape(-1).to(torch.float64) for b in bufs])      # one broadcast; float64 holds the int64 counters exactly
+    dist.broadcast(flat, src=src)
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+        off += n
+    if hasattr(module, "_stats_stale"):
+        module._stats_stale = True                          # the shim pushes the adopted statistics back down before the next step
+        module._sig = None
+    return len(bufs)
+
+
+def save_state_dict(module, path, src=0):
+    """train.py:277 under data parallelism: BN buffers unified (broadcast_bn_buffers), then rank `src` alone writes the file."""
+    broadcast_bn_buffers(module, src)
+    if not dist.is_initialized() or dist.get_rank() == src:
+        torch.save(module.state_dict(), path)
+    barrier()
+
+
 def dp_train_step(handle, x, target, lr, momentum=0.9, weight_decay=5e-4):
     """One data-parallel training step on this rank's shard of the global batch (BASELINE config 3):
     yn_train_step(do_update=0) -> ONE all-reduce(sum) of the flat gradient buffer -> yn_sgd_step(grad_scale=1/world).
-    `handle` is a capi.Handle after train_bind(); call on the stream the handle was created on.  -> losses [4] (local)."""
+    `handle` is a capi.Handle after train_bind(); call on the stream the handle was created on.  -> losses [4] (local).
+    NaN-skip (train.py:225-226): yn_sgd_step leaves parameters and momentum untouched when the (all-reduced) gradient bucket
+    holds a NaN/Inf — one rank's NaN loss makes the bucket non-finite on every rank, so all replicas skip together."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
-        return handle.train_step(x, target, lr, momentum, weight_decay, update=True)
+        losses = handle.train_step(x, target, lr, momentum, weight_decay, update=False)
+        handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0)
+        return losses
     losses = handle.train_step(x, target, lr, momentum, weight_decay, update=False)
     dist.all_reduce(handle.flat_grads, op=dist.ReduceOp.SUM)
     handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0 / world)
