@@ -94,14 +94,46 @@ class TorchNet:
         return torch.cat(boxes, 0).numpy(), torch.cat(clss, 0).numpy()
 
 
+class _Q16(torch.autograd.Function):
+    """Storage rounding of the fp16 training step (kernels_h16.hip), emulated: the forward value is rounded to IEEE fp16, and the
+    gradient flowing back through the same point is rounded to fp16 while it carries the loss scale (a power of two: the rounding
+    is that of the scaled value, the result is returned unscaled).  Identity otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.to(torch.float16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        s = ctx.scale
+        return ((g * s).to(torch.float16).to(g.dtype) / s), None
+
+
+class _W16(torch.autograd.Function):
+    """fp16 copy of an fp32 master weight as the f16 MFMA sees it; the gradient goes straight through to the master weight."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.to(torch.float16).to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class TrainNet:
     """Train-mode restatement (torch autograd on the CPU): BatchNorm with batch statistics (momentum 0.1, eps 1e-5,
     running-stat update), the loss of tools.py:219-276 / models/yolo_nano.py:332-358, SGD(momentum, weight_decay) as
     train.py:167-171,222-231.  Pinned against tests/golden/train.npz (two reference training steps)."""
 
-    def __init__(self, state_dict, backbone="1.0x", num_classes=20, num_anchors=3, anchors=None, dtype=torch.float32):
-        """dtype=torch.float64 gives the round-off-free gradient the fp32 paths (reference, this port, HIP) are judged against."""
+    def __init__(self, state_dict, backbone="1.0x", num_classes=20, num_anchors=3, anchors=None, dtype=torch.float32, fp16_storage=False, loss_scale=1024.0):
+        """dtype=torch.float64 gives the round-off-free gradient the fp32 paths (reference, this port, HIP) are judged against.
+        fp16_storage=True emulates the fp16 training step's storage points (conv outputs, BN+activation outputs, their gradients,
+        the GEMM weights) in otherwise exact arithmetic (use with dtype=float64): what fp16 STORAGE alone does to the gradients —
+        the yardstick the HIP fp16 step is judged by, as the fp32 oracle run is for the fp32 step."""
         self.C, self.A, self.backbone, self.dt = num_classes, num_anchors, backbone, dtype
+        self.q16, self.loss_scale = bool(fp16_storage), float(loss_scale)
         self.anchors = torch.tensor(anchors, dtype=dtype).view(3, num_anchors, 2)
         self.specs = [s for s in arch.conv_specs(backbone, num_classes, num_anchors)]
         self.by = {s.name: s for s in self.specs}
@@ -120,16 +152,22 @@ class TrainNet:
 
     def conv(self, name, x):
         s, p = self.by[name], self.p
-        y = F.conv2d(x, p[s.conv + ".weight"], p.get(s.conv + ".bias"), stride=s.stride,
+        w = p[s.conv + ".weight"]
+        if self.q16 and s.kind != "dw3" and name != "stem":      # the GEMM-shaped convs read fp16 packs; depthwise / stem taps stay fp32
+            w = _W16.apply(w)
+        y = F.conv2d(x, w, p.get(s.conv + ".bias"), stride=s.stride,
                      padding=0 if s.kind == "pw" else 1, groups=s.cout if s.kind == "dw3" else 1)
-        if s.bn is not None:
-            y = F.batch_norm(y, p[s.bn + ".running_mean"], p[s.bn + ".running_var"], p[s.bn + ".weight"], p[s.bn + ".bias"],
-                             training=True, momentum=0.1, eps=arch.BN_EPS)
+        if self.q16:
+            y = _Q16.apply(y, self.loss_scale)
+        if s.bn is None:
+            return y
+        y = F.batch_norm(y, p[s.bn + ".running_mean"], p[s.bn + ".running_var"], p[s.bn + ".weight"], p[s.bn + ".bias"],
+                         training=True, momentum=0.1, eps=arch.BN_EPS)
         if s.act == arch.ACT_RELU:
-            return F.relu(y)
-        if s.act == arch.ACT_LEAKY:
-            return F.leaky_relu(y, 0.1)
-        return y
+            y = F.relu(y)
+        elif s.act == arch.ACT_LEAKY:
+            y = F.leaky_relu(y, 0.1)
+        return _Q16.apply(y, self.loss_scale) if self.q16 else y
 
     def block(self, pfx, x, stride):
         if stride == 1:
@@ -149,11 +187,12 @@ class TrainNet:
             for bi in range(rep):
                 x = self.block("backbone.stage%d.%d" % (si + 2, bi), x, 2 if bi == 0 else 1)
             feats.append(x)
+        q = (lambda t: _Q16.apply(t, self.loss_scale)) if self.q16 else (lambda t: t)       # the FPN / PAN sums are stored tensors too
         p3, p4, p5 = (self.conv("conv1x1_%d" % i, f) for i, f in enumerate(feats))
-        p4 = self.conv("smooth_0", p4 + F.interpolate(p5, scale_factor=2.0))
-        p3 = self.conv("smooth_1", p3 + F.interpolate(p4, scale_factor=2.0))
-        p4 = self.conv("smooth_2", p4 + F.interpolate(p3, scale_factor=0.5))
-        p5 = self.conv("smooth_3", p5 + F.interpolate(p4, scale_factor=0.5))
+        p4 = self.conv("smooth_0", q(p4 + F.interpolate(p5, scale_factor=2.0)))
+        p3 = self.conv("smooth_1", q(p3 + F.interpolate(p4, scale_factor=2.0)))
+        p4 = self.conv("smooth_2", q(p4 + F.interpolate(p3, scale_factor=0.5)))
+        p5 = self.conv("smooth_3", q(p5 + F.interpolate(p4, scale_factor=0.5)))
         outs = []
         for h, pp in ((1, p3), (2, p4), (3, p5)):
             for j in range(5):

@@ -467,12 +467,19 @@ def test_config5_608_bs1(capi):
     eager, counts = _infer_vs_oracle(h, x, 0.001, 0.5)
     eager = [t.clone() for t in eager]
     # the hipGraph-captured form config 5 names: first call = eager warm-up (autotune) + capture + launch, then two replays
-    h.use_graph(True)
-    bufs = h.alloc_outputs(1)
-    for _ in range(3):
-        h.infer(x, bufs)
-    torch.cuda.synchronize()
-    h.use_graph(False)
+    with pytest.raises(capi.YnError):                          # the default stream cannot be captured: refused, not attempted
+        h.use_graph(True)
+        h.infer(x)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        h.set_stream(st)
+        bufs = h.alloc_outputs(1)
+        for _ in range(3):
+            h.infer(x, bufs)
+        st.synchronize()
+        h.use_graph(False)
+    h.set_stream(torch.cuda.current_stream())
     k = counts[0]
     assert int(bufs[4][0].item()) == k
     for i in range(4):

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libyolonano_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_h16.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
           "-Wno-pass-failed"]
 

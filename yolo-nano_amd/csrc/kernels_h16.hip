@@ -1,0 +1,1161 @@
+// kernels_h16.hip — the mixed-precision (BASELINE configs[2]: "fp16") training step's kernels for gfx950.
+//
+// train.py:219-231 runs in fp32; configs[2] names fp16.  This file is the fp16 form of the train-mode network:
+//   * activations, pre-BatchNorm conv outputs and every activation gradient are STORED as IEEE fp16 (half the HBM bytes of
+//     the fp32 step, which is bandwidth-bound nearly everywhere);
+//   * every GEMM-shaped convolution — pointwise 1x1 and dense 3x3, forward, input gradient and weight gradient — runs on
+//     v_mfma_f32_32x32x16_f16 with fp32 accumulation;
+//   * BatchNorm statistics, parameter gradients, the loss and the optimiser stay fp32 / double on the fp32 master weights;
+//   * the loss gradient carries a dynamic loss scale kept on the device (yn_train_h16.inc).
+//
+// Layout: NHWC with the channel axis PADDED to a multiple of 8 halves, so every row and every channel-half offset is
+// 16-byte aligned and one lane moves 8 channels per access.  A ShuffleV2 unit output (2*bf channels, consumed half by half:
+// backbone/shufflenetv2.py:70-72) is stored as two planes [x1 | pad][x2 | pad] of bfp = roundup8(bf) channels each
+// ("gapped": logical channel c lives at c + (c >= half ? gap : 0)), which keeps the x2 view of bf = 58 / 116 aligned.
+// Pad channels hold exact zeros everywhere (every kernel writes whole physical rows), and the packed weights carry zero
+// rows / columns at the pad positions, so GEMMs run over physical channel counts with no masking.
+#include "yn_internal.h"
+#include "yn_h16.h"
+#include <stdlib.h>
+
+namespace ynk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h16x8 ldh8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
+__device__ __forceinline__ void sth8(h16* p, h16x8 v) { *reinterpret_cast<h16x8*>(p) = v; }
+__device__ __forceinline__ h16x8 zero8() { h16x8 z; for (int i = 0; i < 8; ++i) z[i] = (h16)0.0f; return z; }
+// value if ok else 0 through an opaque mask: keeps clamped-address loads unconditional (see yn_device.h)
+__device__ __forceinline__ h16x8 keep8(h16x8 v, bool ok)
+{
+    unsigned mk = ok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(mk));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+    u.x &= mk; u.y &= mk; u.z &= mk; u.w &= mk;
+    return __builtin_bit_cast(h16x8, u);
+}
+__device__ __forceinline__ float hact(float v, int act) { return act == 1 ? (v > 0.0f ? v : 0.0f) : (act == 2 ? (v > 0.0f ? v : 0.1f * v) : v); }
+__device__ __forceinline__ float hact_grad(float g, float zz, int act) { return zz > 0.0f ? g : (act == 2 ? 0.1f * g : 0.0f); }
+__device__ __forceinline__ float hbn_value(float y, float mu, float is, float ga, float be) { return __fmaf_rn(__fmul_rn(__fsub_rn(y, mu), is), ga, be); }
+// physical channel p of a gapped row -> logical channel, or -1 for a pad
+__device__ __forceinline__ int logical_of(int p, int C, int half, int gap)
+{
+    if (p < half) return p;
+    if (p < half + gap) return -1;
+    const int c = p - gap;
+    return c < C ? c : -1;
+}
+
+// =================================================================================================
+// GEMM-shaped convolutions on the f16 MFMA: pointwise 1x1 (TAPS = 1) and dense 3x3 stride 1 pad 1 (TAPS = 9), used for the
+// forward pass and — on transposed (/ flipped) packs — for the input gradients.
+//   out[m][n] (+)= sum_tap sum_k A[pix(m, tap)][k] * Wp[tap][k][n] + bias[n]
+// A: h16, row m has Kp physical channels at a.in + m*in_ld + in_off (16-byte aligned);  Wp: h16 packed [TAPS][Kp/8][Npad][8]
+// (k-octet major: a lane's B fragment = 16 contiguous bytes), Npad a multiple of 32, zero beyond the real rows / columns.
+// Block = 4 waves, each owning 32 rows x (32*NT) columns in NT 32x32 f32 accumulators; the block walks K in chunks of 32
+// (one A chunk = 128 rows x 4 octets, one B chunk = 4 octets x BN columns, staged through LDS with the next chunk's global
+// loads in flight during the MFMAs).  Epilogue through LDS: whole 16-byte row segments leave the block, optionally added to
+// what is already there (dX accumulation).  MFMA operand convention: lane l supplies row/column l%32 and the k-octet l/32 of
+// a 16-deep step for both A and B, so the k-sum is consistent whatever order the hardware walks the octet in.
+// =================================================================================================
+template <int NT, int TAPS>
+__global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a)
+{
+    constexpr int BM = 128, BN = 32 * NT, KC = 32, AST = KC + 8;      // A row stride in LDS (halves): 80 bytes, conflict-free b128 reads
+    constexpr int OST = BN + 8;                                        // epilogue tile row stride (halves)
+    constexpr int LDS_MAIN = BM * AST + (KC / 8) * BN * 8;
+    constexpr int LDS_EPI = BM * OST;
+    __shared__ __attribute__((aligned(16))) h16 smem[LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI];
+    h16* As = smem;
+    h16* Bs = smem + BM * AST;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const unsigned gy = (unsigned)(a.Npad / BN), gx8 = gridDim.x / gy;          // XCD-aware decode (see gemm_conv_kernel)
+    const unsigned slot = blockIdx.x >> 3;
+    const int m0 = (int)((blockIdx.x & 7u) * (gx8 >> 3) + slot / gy) * BM;
+    const int n0 = (int)(slot % gy) * BN;
+    if (m0 >= a.M) return;
+    const int KQ = a.Kp >> 3;                                          // octets per tap
+    const int cpt = (a.Kp + KC - 1) / KC;                              // chunks per tap
+    const int nchunks = TAPS * cpt;
+
+    // A: thread -> (row = t/4 + 64*i, octet = t%4) of the chunk, i = 0..1
+    const int a_oct = t & 3;
+    int a_row[2], a_m[2], a_y[2], a_x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_row[i] = (t >> 2) + 64 * i;
+        const int m = m0 + a_row[i];
+        a_m[i] = m < a.M ? m : -1;
+        a_y[i] = a_x[i] = 0;
+        if (TAPS == 9 && m < a.M) { const int rem = m % (a.H * a.W); a_y[i] = rem / a.W; a_x[i] = rem - a_y[i] * a.W; }
+    }
+    constexpr int B_PER = (4 * BN + 255) / 256;                       // B chunk = 4 octets x BN columns = 4*BN 16-byte granules / 256 threads
+    h16x8 a_reg[2];
+    h16x8 b_reg[B_PER];
+    auto prefetch = [&](int c) {
+        const int tap = TAPS == 9 ? c / cpt : 0;
+        const int kq = (c - tap * cpt) * (KC / 8) + a_oct;             // octet inside the tap
+        const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bool ok = a_m[i] >= 0 && kq < KQ;
+            int src = a_m[i] >= 0 ? a_m[i] : 0;
+            if (TAPS == 9) {
+                const int y = a_y[i] + dy, x = a_x[i] + dx;
+                const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+                ok = ok && in;
+                src = in ? src + dy * a.W + dx : src;                  // clamped to the centre pixel when the tap is outside
+            }
+            a_reg[i] = keep8(ldh8(a.in + (size_t)src * a.in_ld + a.in_off + (kq < KQ ? kq : 0) * 8), ok);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;                                  // granule = (octet o, column n)
+            const int o = g / BN, n = g - o * BN;
+            const int kqb = (c - tap * cpt) * (KC / 8) + o;
+            const bool ok = g < 4 * BN && kqb < KQ;
+            b_reg[i] = keep8(ldh8(a.Wp + (((size_t)tap * KQ + (ok ? kqb : 0)) * a.Npad + n0 + (g < 4 * BN ? n : 0)) * 8), ok);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sth8(As + a_row[i] * AST + a_oct * 8, a_reg[i]);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < 4 * BN) sth8(Bs + (size_t)g * 8, b_reg[i]);
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    prefetch(0);
+    stage();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) prefetch(c + 1);
+        const h16* Ab = As + (wave * 32 + l31) * AST + hh * 8;
+        const h16* Bb = Bs + (hh * BN + l31) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const h16x8 av = ldh8(Ab + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const h16x8 bv = ldh8(Bb + (ks * 2 * BN + nt * 32) * 8);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[nt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+            __syncthreads();                                            // every wave is done reading the chunk
+            stage();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: bias, h16, through LDS so that whole 16-byte row segments are written (and read, when accumulating)
+    __syncthreads();
+    h16* Os = smem;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ncol = n0 + nt * 32 + l31;
+        const float bias = a.bias ? a.bias[ncol] : 0.0f;              // bias has Npad entries (zero padded)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            Os[row * OST + nt * 32 + l31] = (h16)(acc[nt][r] + bias);
+        }
+    }
+    __syncthreads();
+    const int segs = BN / 8;                                            // 16-byte segments per tile row
+    for (int g = t; g < BM * segs; g += 256) {
+        const int row = g / segs, sg = g - row * segs;
+        const int m = m0 + row, n = n0 + sg * 8;
+        if (m >= a.M || n >= a.Np) continue;
+        h16x8 v = ldh8(Os + row * OST + sg * 8);
+        h16* o = a.out + (size_t)m * a.out_ld + a.out_off + n;
+        if (a.accumulate) {
+            const h16x8 old = ldh8(o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (h16)((float)v[i] + (float)old[i]);
+        }
+        sth8(o, v);
+    }
+}
+
+template <int NT>
+static void launch_hgemm_nt(const HGemmArgs& a, hipStream_t s)
+{
+    const int BN = 32 * NT;
+    const dim3 grid(xcd_grid((unsigned)((a.M + 127) / 128)) * (unsigned)(a.Npad / BN));
+    if (a.taps == 9) hipLaunchKernelGGL((hgemm_kernel<NT, 9>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((hgemm_kernel<NT, 1>), grid, dim3(256), 0, s, a);
+}
+
+// Npad must be a multiple of 32; the widest column tile that divides it is used (<= 128 columns: 64 accumulator registers)
+void launch_hgemm(const HGemmArgs& a, hipStream_t s)
+{
+    const int n32 = a.Npad / 32;
+    if (n32 % 4 == 0) launch_hgemm_nt<4>(a, s);
+    else if (n32 % 3 == 0) launch_hgemm_nt<3>(a, s);
+    else if (n32 % 2 == 0) launch_hgemm_nt<2>(a, s);
+    else launch_hgemm_nt<1>(a, s);
+}
+
+// =================================================================================================
+// Weight gradient of a GEMM-shaped conv on the f16 MFMA:  dW[n][k] = sum_m dY[m][n] * X[pix(m, tap)][k]
+// The reduction index m is the MFMA's k, so BOTH operands are needed "m-contiguous per lane", i.e. transposed w.r.t. their
+// row-major [m][channel] storage: a block stages MT = 64 rows of dY (<= NB columns) and of X (<= KB columns) row-major in
+// LDS with coalesced 16-byte loads and every lane gathers its fragment (8 consecutive m of one channel) with 8 ds_read_u16.
+// grid = (column blocks of dY, column blocks of X * taps, M slices); per-slice fp32 copies of dW, reduced — and scattered into
+// the reference's weight layout with the channel map of X undone — by hwgrad_reduce_kernel (deterministic, no atomics).
+// =================================================================================================
+template <int TAPS>
+__global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a)
+{
+    constexpr int MT = 64, NB = 64, KB = 64, ST = 64 + 2;              // LDS row stride (halves): odd dword stride => column gathers spread over banks
+    __shared__ __attribute__((aligned(16))) h16 Ds[MT * ST];
+    __shared__ __attribute__((aligned(16))) h16 Xs[MT * ST];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave & 1, wk = wave >> 1;                           // wave tile: 32 dY columns x 32 X columns
+    const int n0 = blockIdx.x * NB;
+    const int kblocks = (a.Kp + KB - 1) / KB;
+    const int tap = TAPS == 9 ? blockIdx.y / kblocks : 0;
+    const int k0 = (blockIdx.y - tap * kblocks) * KB;
+    const int dyy = TAPS == 9 ? tap / 3 - 1 : 0, dxx = TAPS == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int slices = gridDim.z;
+    const int rows = (((a.M + slices - 1) / slices) + MT - 1) / MT * MT;
+    const int m_begin = blockIdx.z * rows, m_end = min(a.M, m_begin + rows);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // staging: thread -> (row = t/8 + 32*i, octet = t%8), i = 0..1, for both tiles
+    const int s_oct = t & 7;
+    h16x8 dreg[2], xreg[2];
+    auto prefetch = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mt + (t >> 3) + 32 * i;
+            const bool mok = m < m_end;
+            const int mc = mok ? m : m_begin;
+            const int nn = n0 + s_oct * 8, kk = k0 + s_oct * 8;
+            dreg[i] = keep8(ldh8(a.dy + (size_t)mc * a.dy_ld + (nn < a.Np ? nn : 0)), mok && nn < a.Np);
+            bool ok = mok && kk < a.Kp;
+            int src = mc;
+            if (TAPS == 9) {
+                const int rem = mc % (a.H * a.W);
+                const int y = rem / a.W + dyy, x = rem - (rem / a.W) * a.W + dxx;
+                const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+                ok = ok && in;
+                src = in ? mc + dyy * a.W + dxx : mc;
+            }
+            xreg[i] = keep8(ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0)), ok);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (t >> 3) + 32 * i;
+            // ST is not a multiple of 8 halves: store as four 4-byte pieces
+            h16x2* d = reinterpret_cast<h16x2*>(Ds + row * ST + s_oct * 8);
+            h16x2* x = reinterpret_cast<h16x2*>(Xs + row * ST + s_oct * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h16x2 dv, xv;
+                dv[0] = dreg[i][2 * j]; dv[1] = dreg[i][2 * j + 1];
+                xv[0] = xreg[i][2 * j]; xv[1] = xreg[i][2 * j + 1];
+                d[j] = dv; x[j] = xv;
+            }
+        }
+    };
+    if (m_begin < m_end) {
+        prefetch(m_begin);
+        for (int mt = m_begin; mt < m_end; mt += MT) {
+            __syncthreads();                                            // previous tile fully consumed
+            stage();
+            __syncthreads();
+            if (mt + MT < m_end) prefetch(mt + MT);
+#pragma unroll
+            for (int ks = 0; ks < MT / 16; ++ks) {
+                h16x8 av, bv;
+                const int mrow = ks * 16 + hh * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    av[j] = Ds[(mrow + j) * ST + wn * 32 + l31];
+                    bv[j] = Xs[(mrow + j) * ST + wk * 32 + l31];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    // acc[r]: dY column n = n0 + wn*32 + (r&3) + 8*(r>>2) + 4*hh, X column k = k0 + wk*32 + l31
+    float* out = a.partial + (size_t)blockIdx.z * ((size_t)a.Np * a.Kp * TAPS);
+    const int k = k0 + wk * 32 + l31;
+    if (k < a.Kp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (n < a.Np) out[((size_t)n * TAPS + tap) * a.Kp + k] = acc[r];
+        }
+    }
+}
+
+// dW (reference layout, logical channels) = sum over slices of partial[s][n][tap][k_phys], in slice order; * inv_scale
+__global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restrict__ partial, int slices, int Np, int Kp, int taps,
+                                                             int N, int Cin, int half, int gap, float* __restrict__ dw)
+{
+    const long total = (long)N * Cin * taps;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i / ((long)Cin * taps));
+    const int rem = (int)(i - (long)n * Cin * taps);
+    const int ci = rem / taps, tap = rem - ci * taps;                 // reference layouts: [Cout][Cin] and [Cout][Cin][3][3]
+    const int kp = ci + (ci >= half ? gap : 0);
+    const size_t src = ((size_t)n * taps + tap) * Kp + kp, stride = (size_t)Np * Kp * taps;
+    float s0 = 0.0f, s1 = 0.0f;
+    int s = 0;
+    for (; s + 1 < slices; s += 2) { s0 += partial[(size_t)s * stride + src]; s1 += partial[(size_t)(s + 1) * stride + src]; }
+    if (s < slices) s0 += partial[(size_t)s * stride + src];
+    dw[i] = s0 + s1;
+}
+
+void launch_hwgrad(const HWgradArgs& a, hipStream_t s)
+{
+    const int gn = (a.Np + 63) / 64, gk = (a.Kp + 63) / 64 * a.taps;
+    int slices = 1024 / (gn * gk);
+    const int max_slices = (a.M + 255) / 256;
+    if (slices > max_slices) slices = max_slices;
+    const long nk = (long)a.Np * a.Kp * a.taps;
+    if ((long)slices * nk > (long)a.partial_cap) slices = (int)((long)a.partial_cap / nk);
+    if (slices < 1) slices = 1;
+    if (a.taps == 9) hipLaunchKernelGGL(hwgrad_kernel<9>, dim3(gn, gk, slices), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hwgrad_kernel<1>, dim3(gn, gk, slices), dim3(256), 0, s, a);
+    const long total = (long)a.N * a.Cin * a.taps;
+    hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.partial, slices, a.Np, a.Kp, a.taps,
+                       a.N, a.Cin, a.half, a.gap, a.dw);
+}
+
+// =================================================================================================
+// Depthwise 3x3 (stride 1 / 2, pad 1), h16 in / out, fp32 taps [9][Cp] (+ bias [Cp] or null), fp32 math.
+// thread = one channel octet of one output pixel; XCD-contiguous pixel order (the 3 input rows of a window share an L2).
+// Serves the forward convs and — with flipped taps — the stride-1 input gradient (accumulate: dX += ).
+// =================================================================================================
+template <int STRIDE>
+__global__ __launch_bounds__(256) void hdw_kernel(HDwArgs a)
+{
+    const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
+    const int OC = a.Cp >> 3;
+    const long total = (long)a.B * Ho * Wo * OC;
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    long p = i / OC;
+    const int ox = (int)(p % Wo); const long q = p / Wo;
+    const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    const int c = oc * 8;
+    h16x8 v[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * STRIDE - 1 + ky;
+        const bool yok = iy >= 0 && iy < a.H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * STRIDE - 1 + kx;
+            const bool ok = yok && ix >= 0 && ix < a.W;
+            const size_t src = ((size_t)(b * a.H + (yok ? iy : 0)) * a.W + (ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix)));
+            v[ky * 3 + kx] = keep8(ldh8(a.in + src * a.in_ld + a.in_off + c), ok);
+        }
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = a.bias ? a.bias[c + j] : 0.0f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const float4 w0 = *reinterpret_cast<const float4*>(a.w + (size_t)tp * a.Cp + c);
+        const float4 w1 = *reinterpret_cast<const float4*>(a.w + (size_t)tp * a.Cp + c + 4);
+        acc[0] = __builtin_fmaf((float)v[tp][0], w0.x, acc[0]); acc[1] = __builtin_fmaf((float)v[tp][1], w0.y, acc[1]);
+        acc[2] = __builtin_fmaf((float)v[tp][2], w0.z, acc[2]); acc[3] = __builtin_fmaf((float)v[tp][3], w0.w, acc[3]);
+        acc[4] = __builtin_fmaf((float)v[tp][4], w1.x, acc[4]); acc[5] = __builtin_fmaf((float)v[tp][5], w1.y, acc[5]);
+        acc[6] = __builtin_fmaf((float)v[tp][6], w1.z, acc[6]); acc[7] = __builtin_fmaf((float)v[tp][7], w1.w, acc[7]);
+    }
+    h16* o = a.out + (size_t)p * a.out_ld + a.out_off + c;
+    h16x8 r;
+    if (a.accumulate) {
+        const h16x8 old = ldh8(o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)(acc[j] + (float)old[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
+    }
+    sth8(o, r);
+}
+
+void launch_hdw(const HDwArgs& a, hipStream_t s)
+{
+    const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
+    const long total = (long)a.B * Ho * Wo * (a.Cp >> 3);
+    const dim3 grid(xcd_grid((unsigned)((total + 255) / 256)));
+    if (a.stride == 1) hipLaunchKernelGGL(hdw_kernel<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hdw_kernel<2>, grid, dim3(256), 0, s, a);
+}
+
+// depthwise 3x3 stride-2 input gradient (gather form, see dw_dgrad_s2_kernel): thread = (input pixel, channel octet); w = forward taps [9][Cp]
+__global__ __launch_bounds__(256) void hdw_dgrad_s2_kernel(const h16* __restrict__ dy, int dy_ld, const float* __restrict__ w, int B, int H, int W, int Cp,
+                                                            h16* __restrict__ dx, int dx_ld, int dx_off, int accumulate)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int OC = Cp >> 3;
+    const long total = (long)B * H * W * OC;
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    long p = i / OC;
+    const int ix = (int)(p % W); const long q = p / W;
+    const int iy = (int)(q % H), b = (int)(q / H);
+    const int c = oc * 8;
+    int oy[2], ky[2], ox[2], kx[2];
+    bool vy[2], vx[2];
+    oy[0] = (iy + 1) >> 1; ky[0] = iy + 1 - 2 * oy[0]; vy[0] = oy[0] < Ho;
+    oy[1] = oy[0] - 1;     ky[1] = 2;                  vy[1] = ky[0] == 0 && oy[1] >= 0;
+    ox[0] = (ix + 1) >> 1; kx[0] = ix + 1 - 2 * ox[0]; vx[0] = ox[0] < Wo;
+    ox[1] = ox[0] - 1;     kx[1] = 2;                  vx[1] = kx[0] == 0 && ox[1] >= 0;
+    h16x8 g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = u >> 1, f = u & 1;
+        const bool ok = vy[e] && vx[f];
+        g[u] = keep8(ldh8(dy + ((size_t)(b * Ho + (vy[e] ? oy[e] : 0)) * Wo + (vx[f] ? ox[f] : 0)) * dy_ld + c), ok);
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float* wp = w + (size_t)(ky[u >> 1] * 3 + kx[u & 1]) * Cp + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)g[u][j] * wp[j];
+    }
+    h16* o = dx + (size_t)p * dx_ld + dx_off + c;
+    h16x8 r;
+    if (accumulate) { const h16x8 old = ldh8(o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)(acc[j] + (float)old[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
+    }
+    sth8(o, r);
+}
+
+void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s)
+{
+    const long total = (long)B * H * W * (Cp >> 3);
+    hipLaunchKernelGGL(hdw_dgrad_s2_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, dy_ld, w, B, H, W, Cp, dx, dx_ld, dx_off, accumulate);
+}
+
+// =================================================================================================
+// Column reductions over an [M][Cp] h16 matrix.  Block = OL octet-lanes x (256/OL) row-lanes; a thread owns 8 channels and
+// walks down the rows with four independent 16-byte loads in flight, accumulating in double; row-lanes are combined through
+// LDS and ONE double atomic per channel per block goes into the block's accumulator slot (ACC_SLOTS copies, kernels_bwd.hip).
+//   MODE 0  stats:     acc[0][c] += sum y,   acc[1][c] += sum y*y
+//   MODE 2  BN bwd:    acc[0][c] += sum dyh, acc[1][c] += sum dyh * xhat      (dyh = dz * act'(BN(y)), xhat = (y - mean) * invstd)
+//   MODE 3  column sum of y into the fp32 gradient slots (bias gradient)
+// Channel index in acc / mean / gamma is the LOGICAL channel (logical_of); pad channels are skipped.
+// dz: dense with y's own map (dz_odd = 0), or the odd logical channels of a gapped 2C-channel tensor (dz_odd = 1: channel c
+// of this layer is logical channel 2c+1 there — the concat+shuffle of backbone/shufflenetv2.py:72-74).
+// =================================================================================================
+__device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, float (&g)[8])
+{
+    if (!a.dz_odd) {
+        const h16x8 v = ldh8(a.dz + row * a.dz_ld + a.dz_off + p0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (float)v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = p0 + j;                                       // y is dense here (half == C): physical == logical
+            const int l = 2 * c + 1;
+            const int pp = l + (l >= a.dz_half ? a.dz_gap : 0);
+            g[j] = c < a.C ? (float)a.dz[row * a.dz_ld + pp] : 0.0f;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
+{
+    __shared__ double red[256][17];
+    const int OL = a.lanes, rowsPer = 256 / OL;
+    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
+    const int OC = a.Cp >> 3;
+    const bool live = ol < OC;
+    const int p0 = ol * 8;
+    double s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    int lc[8];
+    float mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lc[j] = live ? logical_of(p0 + j, a.C, a.half, a.gap) : -1;
+        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
+        if (MODE == 2 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
+    }
+    if (live) {
+        const long step = (long)gridDim.x * rowsPer;
+        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += 2 * step) {
+            const bool has2 = r + step < a.M;
+            const long r2 = has2 ? r + step : r;
+            const h16x8 v0 = ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0);
+            const h16x8 v1 = ldh8(a.y + (size_t)r2 * a.y_ld + a.y_off + p0);
+            float g0[8], g1[8];
+            if (MODE == 2) { load_dz8(a, (size_t)r, p0, g0); load_dz8(a, (size_t)r2, p0, g1); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y0 = (float)v0[j], y1 = has2 ? (float)v1[j] : 0.0f;
+                if (MODE == 0) {
+                    s0[j] += (double)y0 + (double)y1;
+                    s1[j] += (double)y0 * (double)y0 + (double)y1 * (double)y1;
+                } else if (MODE == 3) {
+                    s0[j] += (double)y0 + (double)y1;
+                } else {
+                    float d0 = g0[j], d1 = has2 ? g1[j] : 0.0f;
+                    if (a.act) {
+                        d0 = hact_grad(d0, hbn_value(y0, mu[j], is[j], ga[j], be[j]), a.act);
+                        d1 = hact_grad(d1, hbn_value((float)v1[j], mu[j], is[j], ga[j], be[j]), a.act);
+                    }
+                    const float x0 = (y0 - mu[j]) * is[j], x1 = ((float)v1[j] - mu[j]) * is[j];
+                    s0[j] += (double)d0 + (double)d1;
+                    s1[j] += (double)d0 * (double)x0 + (double)d1 * (double)x1;
+                }
+            }
+        }
+    }
+    // combine the row-lanes (two rounds of 8 doubles each keep the LDS footprint at 34 KB)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = pass == 0 ? s0[j] : s1[j];
+        __syncthreads();
+        if (rl == 0 && live) {
+            for (int k = 1; k < rowsPer; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { if (pass == 0) s0[j] += red[k * OL + ol][j]; else s1[j] += red[k * OL + ol][j]; }
+        }
+    }
+    if (rl == 0 && live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (lc[j] < 0) continue;
+            if (MODE == 3) {
+                atomicAdd(a.facc + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * a.slot_stride + lc[j], (float)s0[j]);
+            } else {
+                double* acc = a.acc + (size_t)(blockIdx.x & (ACC_SLOTS - 1)) * 2 * a.C;
+                atomicAdd(acc + lc[j], s0[j]);
+                atomicAdd(acc + a.C + lc[j], s1[j]);
+            }
+        }
+    }
+}
+
+static int hlanes_for(int Cp) { int l = 1; while (l < (Cp >> 3) && l < 256) l <<= 1; return l; }
+static int hreduce_blocks(long M, int rowsPer, int cap)
+{
+    long b = (M + (long)rowsPer * 4 - 1) / ((long)rowsPer * 4);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
+{
+    HRedArgs a = a0;
+    a.lanes = hlanes_for(a.Cp);
+    static const int gmax = getenv("YN_RED_G") ? atoi(getenv("YN_RED_G")) : 512;
+    const dim3 grid(hreduce_blocks(a.M, 256 / a.lanes, gmax));
+    if (mode == 0) hipLaunchKernelGGL(hcol_reduce_kernel<0>, grid, dim3(256), 0, s, a);
+    else if (mode == 2) hipLaunchKernelGGL(hcol_reduce_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hcol_reduce_kernel<3>, grid, dim3(256), 0, s, a);
+}
+
+// ---- BatchNorm forward apply (batch statistics): z = act((y - mean) * invstd * gamma + beta), h16 in / out.
+//      Dense mode: out has y's channel map (pads written as zero).  Shuffle mode (pass != null): y dense [M][*] with C = bf
+//      channels, out = the gapped 2*bf-channel unit output: out[2c] = pass[c], out[2c+1] = z[c]  (concat + channel_shuffle,
+//      backbone/shufflenetv2.py:14-28,72-74), pads zeroed.  Block 0 saves mean / invstd and updates the running statistics.
+__global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
+{
+    const int OC = a.Cp >> 3;
+    const long total = (long)a.M * OC;
+    const double invM = 1.0 / (double)a.M;
+    // per-thread channel constants: the octet a thread owns is fixed over its grid-stride loop when the stride is a multiple of OC
+    const long stride = ((long)gridDim.x * 256 + OC - 1) / OC * OC;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= stride) return;
+    const int oc = (int)(i % OC), p0 = oc * 8;
+    int lc[8];
+    float mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
+        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
+        if (lc[j] >= 0) {
+            const int c = lc[j];
+            double m = 0.0, q = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < ACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * a.C + c]; q += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+            m *= invM;
+            double var = q * invM - m * m;
+            if (var < 0.0) var = 0.0;
+            mu[j] = (float)m; is[j] = (float)(1.0 / sqrt(var + (double)a.eps)); ga[j] = a.gamma[c]; be[j] = a.beta[c];
+            if (i < OC) {                                               // first pass over the channels: exactly one thread per channel
+                a.mean[c] = mu[j]; a.invstd[c] = is[j];
+                if (a.rmean) {
+                    const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
+                    a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu[j];
+                    a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+                }
+            }
+        }
+    }
+    for (; i < total; i += stride) {
+        const long m = i / OC;
+        const h16x8 v = ldh8(a.y + (size_t)m * a.y_ld + p0);
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = lc[j] >= 0 ? hact(hbn_value((float)v[j], mu[j], is[j], ga[j], be[j]), a.act) : 0.0f;
+        if (!a.pass) {
+            h16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (h16)z[j];
+            sth8(a.out + (size_t)m * a.out_ld + a.out_off + p0, r);
+        } else {
+            const h16x8 pv = ldh8(a.pass + (size_t)m * a.pass_ld + a.pass_off + p0);
+            h16* o = a.out + (size_t)m * a.out_ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = p0 + j;                                   // y dense: physical == logical
+                if (c >= a.C) continue;
+                const int l = 2 * c;
+                const int pp = l + (l >= a.out_half ? a.out_gap : 0);
+                h16x2 w2; w2[0] = pv[j]; w2[1] = (h16)z[j];
+                *reinterpret_cast<h16x2*>(o + pp) = w2;
+            }
+            if (oc == 0 && a.out_gap > 0) {                             // the two pad runs of the gapped row
+                for (int q = 0; q < a.out_gap; ++q) { o[a.out_half + q] = (h16)0.0f; o[2 * a.out_half + a.out_gap + q] = (h16)0.0f; }
+            }
+        }
+    }
+}
+
+void launch_hbn_apply(const HBnApplyArgs& a, hipStream_t s)
+{
+    const long total = (long)a.M * (a.Cp >> 3);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hbn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+// ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)); dy dense h16 [M][Cp] with y's map,
+//      pads zero; one thread per channel writes dgamma / dbeta (fp32, still carrying the loss scale).
+__global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int OC = a.Cp >> 3;
+    const long total = (long)a.M * OC;
+    const double invM = 1.0 / (double)a.M;
+    const long stride = ((long)gridDim.x * 256 + OC - 1) / OC * OC;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= stride) return;
+    const int oc = (int)(i % OC), p0 = oc * 8;
+    int lc[8];
+    float mu[8], is[8], ga[8], be[8], kk[8], m0[8], m1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
+        mu[j] = is[j] = ga[j] = be[j] = kk[j] = m0[j] = m1[j] = 0.0f;
+        if (lc[j] >= 0) {
+            const int c = lc[j];
+            mu[j] = a.mean[c]; is[j] = a.invstd[c]; ga[j] = a.gamma[c]; be[j] = a.beta[c]; kk[j] = ga[j] * is[j];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < ACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+            m0[j] = (float)(s0 * invM); m1[j] = (float)(s1 * invM);
+            if (i < OC) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+        }
+    }
+    for (; i < total; i += stride) {
+        const long m = i / OC;
+        const h16x8 v = ldh8(a.y + (size_t)m * a.y_ld + a.y_off + p0);
+        float g[8];
+        load_dz8(a, (size_t)m, p0, g);
+        h16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = g[j];
+            const float yv = (float)v[j];
+            if (a.act) d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+            const float xh = (yv - mu[j]) * is[j];
+            r[j] = lc[j] >= 0 ? (h16)(kk[j] * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
+        }
+        sth8(dy + (size_t)m * a.Cp + p0, r);
+    }
+}
+
+void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hipStream_t s)
+{
+    launch_hcol_reduce(a0, 2, s);
+    HRedArgs a = a0;
+    a.lanes = hlanes_for(a.Cp);
+    const long total = (long)a.M * (a.Cp >> 3);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, dy, dgamma, dbeta);
+}
+
+// =================================================================================================
+// Depthwise weight gradient: dW[c][tap] += sum_p dY[p][c] * X[p*stride + tap - 1][c]  -> fp32 atomics into the gradient slots
+// (reference layout [C][1][3][3], logical channels).  Block = OL octet-lanes x row-lanes; a row-lane takes a contiguous range
+// of output pixels; LDS combine, one atomic per (c, tap) per block.
+// =================================================================================================
+template <int STRIDE>
+__global__ __launch_bounds__(256) void hdw_wgrad_kernel(const h16* __restrict__ dy, int dy_ld, const h16* __restrict__ x, int x_ld, int x_off,
+                                                         int B, int H, int W, int C, int Cp, int half, int gap, float* __restrict__ dw, size_t slot_stride, int OL)
+{
+    __shared__ float red[256][9];
+    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+    const int rowsPer = 256 / OL;
+    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
+    const int OC = Cp >> 3;
+    const bool live = ol < OC;
+    const int c0 = ol * 8;
+    float acc[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
+    if (live) {
+        const long npix = (long)B * Ho * Wo;
+        const long lanes_total = (long)gridDim.x * rowsPer;
+        const long per = (npix + lanes_total - 1) / lanes_total;
+        const long begin = ((long)xcd_block(blockIdx.x, gridDim.x) * rowsPer + rl) * per;
+        const long end = begin + per < npix ? begin + per : npix;
+        for (long p = begin; p < end; ++p) {
+            const int ox = (int)(p % Wo); const long q = p / Wo;
+            const int oy = (int)(q % Ho), b = (int)(q / Ho);
+            const h16x8 g = ldh8(dy + (size_t)p * dy_ld + c0);
+            h16x8 v[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * STRIDE - 1 + ky;
+                const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * STRIDE - 1 + kx;
+                    const bool ok = yok && ix >= 0 && ix < W;
+                    const size_t src = ((size_t)(b * H + (yok ? iy : 0)) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)));
+                    v[ky * 3 + kx] = keep8(ldh8(x + src * x_ld + x_off + c0), ok);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] += (float)g[j] * (float)v[k][j];
+        }
+    }
+    // combine the row-lanes, one channel of the octet at a time (9 floats per thread per round)
+    for (int j = 0; j < 8; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[threadIdx.x][k] = acc[k][j];
+        __syncthreads();
+        if (rl == 0 && live) {
+            const int lc = logical_of(c0 + j, C, half, gap);
+            if (lc >= 0) {
+                float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride + (size_t)lc * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float sum = 0.0f;
+                    for (int r = 0; r < rowsPer; ++r) sum += red[r * OL + ol][k];
+                    atomicAdd(out + k, sum);
+                }
+            }
+        }
+    }
+}
+
+void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_off, int B, int H, int W, int C, int Cp, int half, int gap, int stride,
+                      float* dw, size_t slot_stride, hipStream_t s)
+{
+    const int OL = hlanes_for(Cp);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long npix = (long)B * Ho * Wo;
+    long G = (npix + (256 / OL) * 16 - 1) / ((256 / OL) * 16);
+    static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 512;
+    if (G > gmax) G = gmax;
+    if (G < 1) G = 1;
+    G = (long)xcd_grid((unsigned)G);
+    if (stride == 1) hipLaunchKernelGGL(hdw_wgrad_kernel<1>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, dw, slot_stride, OL);
+    else hipLaunchKernelGGL(hdw_wgrad_kernel<2>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, dw, slot_stride, OL);
+}
+
+// =================================================================================================
+// Stem (backbone/shufflenetv2.py:109): 3x3 stride-2 conv 3 -> 24 reading the fp32 NCHW input, h16 NHWC output [M][24];
+// thread = one output pixel x 8 output channels.  Its weight gradient: thread = (patch element r < 27, 8 output channels),
+// a block walks a range of output pixels, LDS combine, fp32 atomics into the gradient slots.
+// =================================================================================================
+__global__ __launch_bounds__(256) void hstem_kernel(const float* __restrict__ x, int B, int H, int W, const float* __restrict__ w /*[27][24]*/,
+                                                     const float* __restrict__ bias, h16* __restrict__ y)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)B * Ho * Wo * 3;
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % 3);
+    const long p = i / 3;
+    const int ox = (int)(p % Wo); const long q = p / Wo;
+    const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[oc * 8 + j] : 0.0f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                const bool ok = yok && ix >= 0 && ix < W;
+                const float v = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+                const float* wp = w + (size_t)(ci * 9 + ky * 3 + kx) * 24 + oc * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(v, wp[j], acc[j]);
+            }
+        }
+    h16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
+    sth8(y + (size_t)p * 24 + oc * 8, r);
+}
+
+void launch_hstem(const float* x, int B, int H, int W, const float* w, const float* bias, h16* y, hipStream_t s)
+{
+    const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 3;
+    hipLaunchKernelGGL(hstem_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, x, B, H, W, w, bias, y);
+}
+
+__global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict__ dy, const float* __restrict__ x, int B, int H, int W,
+                                                           float* __restrict__ dw /* slots, reference layout [24][3][3][3] */, size_t slot_stride)
+{
+    // thread -> (row-lane rl = t/96 < 2, patch element r = (t%96)/3 < 27.., channel octet oc = t%3); 192 threads busy of 256 (162 do work)
+    __shared__ float red[256][8];
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int t = threadIdx.x;
+    const int rl = t / 96, u = t - rl * 96, r = u / 3, oc = u - r * 3;
+    const bool live = rl < 2 && r < 27;
+    const int ci = r / 9, ky = (r % 9) / 3, kx = r % 3;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    if (live) {
+        const long npix = (long)B * Ho * Wo;
+        const long lanes_total = (long)gridDim.x * 2;
+        const long per = (npix + lanes_total - 1) / lanes_total;
+        const long begin = ((long)blockIdx.x * 2 + rl) * per;
+        const long end = begin + per < npix ? begin + per : npix;
+        for (long p = begin; p < end; ++p) {
+            const int ox = (int)(p % Wo); const long q = p / Wo;
+            const int oy = (int)(q % Ho), b = (int)(q / Ho);
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float xv = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
+            const h16x8 g = ldh8(dy + (size_t)p * 24 + oc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv, (float)g[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[t][j] = acc[j];
+    __syncthreads();
+    if (rl == 0 && r < 27) {
+        float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(out + (size_t)(oc * 8 + j) * 27 + r, red[t][j] + red[t + 96][j]);
+    }
+}
+
+void launch_hstem_wgrad(const h16* dy, const float* x, int B, int H, int W, float* dw_slots, size_t slot_stride, hipStream_t s)
+{
+    const long npix = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    long G = (npix + 255) / 256;
+    static const int gmax = getenv("YN_STEM_G") ? atoi(getenv("YN_STEM_G")) : 1024;
+    if (G > gmax) G = gmax;
+    if (G < 1) G = 1;
+    hipLaunchKernelGGL(hstem_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, s, dy, x, B, H, W, dw_slots, slot_stride);
+}
+
+// ---- 3x3 stride-2 max pool with recorded arg-max (first maximum in scan order, as ATen) and its gather-form backward; C = 24
+__global__ __launch_bounds__(256) void hmaxpool_idx_kernel(const h16* __restrict__ x, int B, int H, int W, int Cp, h16* __restrict__ y, int32_t* __restrict__ idx)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, OC = Cp >> 3;
+    const long total = (long)B * Ho * Wo * OC;
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    const long p = i / OC;
+    const int ox = (int)(p % Wo); const long q = p / Wo;
+    const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    float m[8]; int best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; best[j] = -1; }
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const h16x8 v = ldh8(x + ((size_t)(b * H + iy) * W + ix) * Cp + oc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if ((float)v[j] > m[j] || best[j] < 0) { m[j] = (float)v[j]; best[j] = iy * W + ix; }
+        }
+    }
+    h16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r[j] = (h16)m[j]; idx[(size_t)p * Cp + oc * 8 + j] = best[j]; }
+    sth8(y + (size_t)p * Cp + oc * 8, r);
+}
+
+__global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const h16* __restrict__ dy, const int32_t* __restrict__ idx, int B, int H, int W, int Cp, h16* __restrict__ dx)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, OC = Cp >> 3;
+    const long total = (long)B * H * W * OC;
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    const long p = i / OC;
+    const int ix = (int)(p % W); const long q = p / W;
+    const int iy = (int)(q % H), b = (int)(q / H);
+    const int me = iy * W + ix;
+    int oy[2], ox[2]; bool vy[2], vx[2];
+    oy[0] = (iy + 1) >> 1; vy[0] = oy[0] < Ho; oy[1] = oy[0] - 1; vy[1] = (iy & 1) && oy[1] >= 0;
+    ox[0] = (ix + 1) >> 1; vx[0] = ox[0] < Wo; ox[1] = ox[0] - 1; vx[1] = (ix & 1) && ox[1] >= 0;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = vy[u >> 1] && vx[u & 1];
+        const size_t o = ((size_t)(b * Ho + (vy[u >> 1] ? oy[u >> 1] : 0)) * Wo + (vx[u & 1] ? ox[u & 1] : 0)) * Cp + oc * 8;
+        const h16x8 g = ldh8(dy + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (ok && idx[o + j] == me) ? (float)g[j] : 0.0f;
+    }
+    h16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
+    sth8(dx + (size_t)p * Cp + oc * 8, r);
+}
+
+void launch_hmaxpool_idx(const h16* x, int B, int H, int W, int Cp, h16* y, int32_t* idx, hipStream_t s)
+{
+    const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (Cp >> 3);
+    hipLaunchKernelGGL(hmaxpool_idx_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, x, B, H, W, Cp, y, idx);
+}
+void launch_hmaxpool_bwd(const h16* dy, const int32_t* idx, int B, int H, int W, int Cp, h16* dx, hipStream_t s)
+{
+    const long total = (long)B * H * W * (Cp >> 3);
+    hipLaunchKernelGGL(hmaxpool_bwd_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, idx, B, H, W, Cp, dx);
+}
+
+// ---- element-wise glue of the FPN / PAN adds (models/yolo_nano.py:291-296), dense Cp-channel h16 tensors; modes as resample_kernel
+__global__ __launch_bounds__(256) void hresample_kernel(const h16* __restrict__ a, const h16* __restrict__ b, h16* __restrict__ out, int B, int H, int W, int Cp, int mode)
+{
+    const int OC = Cp >> 3;
+    if (mode <= 1 || mode == 3) {
+        const long total = (long)B * H * W * OC;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int oc = (int)(i % OC);
+            const long p = i / OC;
+            const int x = (int)(p % W); const long q = p / W;
+            const int y = (int)(q % H), bb = (int)(q / H);
+            size_t j;
+            if (mode == 0) j = (((size_t)bb * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1));
+            else           j = (((size_t)bb * (H << 1) + (y << 1)) * (W << 1) + (x << 1));
+            const h16x8 va = ldh8(a + (size_t)p * Cp + oc * 8);
+            h16x8 r;
+            if (mode == 3) {                                            // out = grad of the high-res tensor, a = g: out[even pixel] += g
+                const h16x8 vo = ldh8(out + j * Cp + oc * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = (h16)((float)vo[k] + (float)va[k]);
+                sth8(out + j * Cp + oc * 8, r);
+            } else {
+                const h16x8 vb = ldh8(b + j * Cp + oc * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = (h16)((float)va[k] + (float)vb[k]);
+                sth8(out + (size_t)p * Cp + oc * 8, r);
+            }
+        }
+    } else {                                                            // mode 2: out [B,H/2,W/2] += the 4 children of a [B,H,W]
+        const int h2 = H >> 1, w2 = W >> 1;
+        const long total = (long)B * h2 * w2 * OC;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int oc = (int)(i % OC);
+            const long p = i / OC;
+            const int x = (int)(p % w2); const long q = p / w2;
+            const int y = (int)(q % h2), bb = (int)(q / h2);
+            const size_t base = (((size_t)bb * H + 2 * y) * W + 2 * x) * Cp + oc * 8;
+            const h16x8 c0 = ldh8(a + base), c1 = ldh8(a + base + Cp), c2 = ldh8(a + base + (size_t)W * Cp), c3 = ldh8(a + base + (size_t)W * Cp + Cp);
+            const h16x8 vo = ldh8(out + (size_t)p * Cp + oc * 8);
+            h16x8 r;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = (h16)((float)vo[k] + (((float)c0[k] + (float)c1[k]) + ((float)c2[k] + (float)c3[k])));
+            sth8(out + (size_t)p * Cp + oc * 8, r);
+        }
+    }
+}
+
+void launch_hresample(const h16* a, const h16* b, h16* out, int B, int H, int W, int Cp, int mode, hipStream_t s)
+{
+    long n = (long)B * H * W * (Cp >> 3);
+    if (mode == 2) n /= 4;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hresample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, out, B, H, W, Cp, mode);
+}
+
+// dst[m][dp(j)] = src[m][sp(j)] for j < n, where sp(j) = phys_src(src_off + j*src_cs), dp(j) = phys_dst(dst_off + j*dst_cs) (gapped maps);
+// dst pads [n, npad) of a dense destination are zeroed.  Used for: the pass-through half of the unit gradient (even logical
+// channels of the gapped output gradient -> first plane of the input gradient), branch1's gradient, plain copies.
+__global__ __launch_bounds__(256) void hgather_kernel(const h16* __restrict__ src, int src_ld, int src_off, int src_cs, int src_half, int src_gap,
+                                                       h16* __restrict__ dst, int dst_ld, int dst_off, int dst_cs, int dst_half, int dst_gap, long M, int n, int npad)
+{
+    const long total = M * npad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % npad);
+        const long m = i / npad;
+        const int dl = dst_off + j * dst_cs;
+        const int dp = dl + (dl >= dst_half ? dst_gap : 0);
+        h16 v = (h16)0.0f;
+        if (j < n) {
+            const int sl = src_off + j * src_cs;
+            v = src[(size_t)m * src_ld + sl + (sl >= src_half ? src_gap : 0)];
+        }
+        dst[(size_t)m * dst_ld + dp] = v;
+    }
+}
+
+void launch_hgather(const h16* src, int src_ld, int src_off, int src_cs, int src_half, int src_gap,
+                    h16* dst, int dst_ld, int dst_off, int dst_cs, int dst_half, int dst_gap, long M, int n, int npad, hipStream_t s)
+{
+    long blocks = (M * npad + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hgather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, src_ld, src_off, src_cs, src_half, src_gap,
+                       dst, dst_ld, dst_off, dst_cs, dst_half, dst_gap, M, n, npad);
+}
+
+// =================================================================================================
+// Weight packing from the fp32 master weights (reference layouts), every step.
+//   GEMM forward  : Wp[tap][kp/8][n][kp%8] = W[n][ci][tap], kp = phys_in(ci)        (rows at pad positions stay zero)
+//   GEMM backward : Wp[tap'][np/8][kp_out][np%8] with the roles swapped: contraction over the OUTPUT channels n (physical, dense
+//                   map of dY), result columns = physical INPUT channels; dense 3x3 taps flipped (tap' = 8 - tap)
+//   depthwise     : Wd[tap][cp] = W[c][tap] (forward) / Wd[8 - tap][cp] (stride-1 input gradient), cp = phys(c)
+// =================================================================================================
+__global__ __launch_bounds__(256) void hpack_gemm_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int in_half, int in_gap,
+                                                          int Kp, int Npad, int backward, h16* __restrict__ out)
+{
+    const long total = (long)Cout * Cin * taps;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i / ((long)Cin * taps));
+    const int rem = (int)(i - (long)n * Cin * taps);
+    const int ci = rem / taps, tap = rem - ci * taps;
+    const int cp = ci + (ci >= in_half ? in_gap : 0);
+    if (!backward) out[(((size_t)tap * (Kp >> 3) + (cp >> 3)) * Npad + n) * 8 + (cp & 7)] = (h16)w[i];
+    else out[(((size_t)(taps - 1 - tap) * (Kp >> 3) + (n >> 3)) * Npad + cp) * 8 + (n & 7)] = (h16)w[i];     // Kp = physical Cout, Npad covers physical Cin
+}
+
+__global__ __launch_bounds__(256) void hpack_dw_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C, int half, int gap, int Cp, int flip,
+                                                        float* __restrict__ out, float* __restrict__ bias_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < C * 9) {
+        const int c = i / 9, tap = i - c * 9;
+        out[(size_t)(flip ? 8 - tap : tap) * Cp + c + (c >= half ? gap : 0)] = w[i];
+    }
+    if (bias_out && i < C) bias_out[i + (i >= half ? gap : 0)] = bias ? bias[i] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void hpack_stem_kernel(const float* __restrict__ w /*[24][3][3][3]*/, float* __restrict__ out /*[27][24]*/)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 24 * 27) return;
+    const int co = i / 27, r = i - co * 27;
+    out[(size_t)r * 24 + co] = w[i];
+}
+
+void launch_hpack_gemm(const float* w, int Cout, int Cin, int taps, int in_half, int in_gap, int Kp, int Npad, int backward, h16* out, hipStream_t s)
+{
+    const long total = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(hpack_gemm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, Cout, Cin, taps, in_half, in_gap, Kp, Npad, backward, out);
+}
+void launch_hpack_dw(const float* w, const float* bias, int C, int half, int gap, int Cp, int flip, float* out, float* bias_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(hpack_dw_kernel, dim3((unsigned)((C * 9 + 255) / 256)), dim3(256), 0, s, w, bias, C, half, gap, Cp, flip, out, bias_out);
+}
+void launch_hpack_stem(const float* w, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(hpack_stem_kernel, dim3(3), dim3(256), 0, s, w, out);
+}
+
+// =================================================================================================
+// Loss-scale bookkeeping, all on the device (no host round trip, capture-friendly).
+//   state[0] = current scale S, state[1] = 1/S, state[2] = clean steps since the last change (as float), state[3] = overflow flag
+// hgrad_finish_kernel: g = (g + sum of the atomics slots) / S, and raises the overflow flag when a value is not finite;
+// hscale_update_kernel (one thread, after it): overflow -> S /= 2 (>= 1), counter = 0; else counter++, and S *= 2 (<= 65536)
+// after 2000 clean steps.  The overflowed step's gradients stay non-finite in the bucket, so yn_sgd_step skips it.
+// =================================================================================================
+__global__ __launch_bounds__(256) void hgrad_finish_kernel(float* __restrict__ g, const float* __restrict__ slots, long n, size_t stride, float* __restrict__ state)
+{
+    const float inv = state[1];
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = g[i];
+#pragma unroll
+        for (int s = 0; s < GRAD_SLOTS; ++s) v += slots[(size_t)s * stride + i];
+        v *= inv;
+        bad |= !(fabsf(v) <= 3.0e38f);
+        g[i] = v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned*>(state + 3), 1u);
+}
+
+__global__ void hscale_update_kernel(float* __restrict__ state)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float S = state[0], clean = state[2];
+    const unsigned over = *reinterpret_cast<unsigned*>(state + 3);
+    if (over) { S = S > 1.0f ? S * 0.5f : 1.0f; clean = 0.0f; }
+    else { clean += 1.0f; if (clean >= 2000.0f) { S = S < 65536.0f ? S * 2.0f : S; clean = 0.0f; } }
+    state[0] = S; state[1] = 1.0f / S; state[2] = clean;
+    *reinterpret_cast<unsigned*>(state + 3) = 0u;
+}
+
+void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, float* state, hipStream_t s)
+{
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(hgrad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, slots, n, stride, state);
+    hipLaunchKernelGGL(hscale_update_kernel, dim3(1), dim3(64), 0, s, state);
+}
+
+}  // namespace ynk

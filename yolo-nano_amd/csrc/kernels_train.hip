@@ -9,6 +9,7 @@
 //                       from / write gradients to the three raw NHWC head tensors directly (no re-layout pass).
 //   loss_reduce_kernel  deterministic final sum of the per-block partials.
 #include "yn_internal.h"
+#include "yn_h16.h"
 
 namespace ynk {
 
@@ -16,7 +17,8 @@ __device__ __forceinline__ float sigmoid_t(float v) { return 1.0f / (1.0f + expf
 
 struct LossArgs {
     const float* conf; const float* cls; const float* t;          // split layout (HEADS = false)
-    const float* head[3]; float* ghead[3];                        // head layout  (HEADS = true)
+    const void* head[3]; void* ghead[3];                          // head layout  (HEADS = true): HT = float or _Float16
+    const float* gscale;                                          // device pointer to the loss scale the gradients are multiplied by, or null
     const float* target;                                          // [B,N,11] = obj, cls, tx,ty,tw,th, weight, x1,y1,x2,y2
     float* g_conf; float* g_cls; float* g_t;                      // may be null (forward only)
     float* partial;                                               // [gridDim.x][4]
@@ -24,7 +26,7 @@ struct LossArgs {
     int B;
 };
 
-template <bool HEADS>
+template <bool HEADS, typename HT = float>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
 {
     __shared__ float red[4][4];
@@ -39,22 +41,25 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
         const int gy = cell / g.w[s], gx = cell - gy * g.w[s];
         const float stride = (float)(8 << s), S = (float)g.S, invB = 1.0f / (float)a.B;
         const int HC = g.head_ld;
-        const float* pconf; const float* pcls; const float* pt;
-        float *qconf = nullptr, *qcls = nullptr, *qt = nullptr;
+        const HT* pconf; const HT* pcls; const HT* pt;
+        HT *qconf = nullptr, *qcls = nullptr, *qt = nullptr;
+        const float gs = a.gscale ? a.gscale[0] : 1.0f;           // loss scale (fp16 step): every gradient written below carries it
         if (HEADS) {
             const size_t row = ((size_t)b * g.hw[s] + cell) * HC;
-            pconf = a.head[s] + row + an; pcls = a.head[s] + row + g.A + an * g.C; pt = a.head[s] + row + g.A * (1 + g.C) + an * 4;
-            if (a.ghead[s]) { qconf = a.ghead[s] + row + an; qcls = a.ghead[s] + row + g.A + an * g.C; qt = a.ghead[s] + row + g.A * (1 + g.C) + an * 4; }
+            const HT* hp = reinterpret_cast<const HT*>(a.head[s]);
+            HT* gp = reinterpret_cast<HT*>(a.ghead[s]);
+            pconf = hp + row + an; pcls = hp + row + g.A + an * g.C; pt = hp + row + g.A * (1 + g.C) + an * 4;
+            if (gp) { qconf = gp + row + an; qcls = gp + row + g.A + an * g.C; qt = gp + row + g.A * (1 + g.C) + an * 4; }
         } else {
-            pconf = a.conf + i; pcls = a.cls + (size_t)i * g.C; pt = a.t + (size_t)i * 4;
-            if (a.g_conf) { qconf = a.g_conf + i; qcls = a.g_cls + (size_t)i * g.C; qt = a.g_t + (size_t)i * 4; }
+            pconf = reinterpret_cast<const HT*>(a.conf) + i; pcls = reinterpret_cast<const HT*>(a.cls) + (size_t)i * g.C; pt = reinterpret_cast<const HT*>(a.t) + (size_t)i * 4;
+            if (a.g_conf) { qconf = reinterpret_cast<HT*>(a.g_conf) + i; qcls = reinterpret_cast<HT*>(a.g_cls) + (size_t)i * g.C; qt = reinterpret_cast<HT*>(a.g_t) + (size_t)i * 4; }
         }
         const float* tg = a.target + (size_t)i * 11;
         const float obj = tg[0], wgt = tg[6];
         const int gcls = (int)tg[1];
         const float pos = obj == 1.0f ? 1.0f : 0.0f, neg = obj == 0.0f ? 1.0f : 0.0f, mask = obj > 0.0f ? 1.0f : 0.0f;
         // decode (models/yolo_nano.py:120-156) / S, unclamped
-        const float tx = pt[0], ty = pt[1], tw = pt[2], th = pt[3];
+        const float tx = (float)pt[0], ty = (float)pt[1], tw = (float)pt[2], th = (float)pt[3];
         const float sx = sigmoid_t(tx), sy = sigmoid_t(ty), ew = expf(tw), eh = expf(th);
         const float aw = g.anchors[(s * g.A + an) * 2], ah = g.anchors[(s * g.A + an) * 2 + 1];
         const float cx = (sx + (float)gx) * stride, cy = (sy + (float)gy) * stride, bw = ew * aw, bh = eh * ah;
@@ -70,24 +75,24 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
         const float U = Aa + Ab - I;
         const float iou = I / U;
         // objectness (tools.py:12-34); gt_conf = iou.detach()
-        const float sg = sigmoid_t(pconf[0]);
+        const float sg = sigmoid_t((float)pconf[0]);
         l_conf = (5.0f * pos * (sg - iou) * (sg - iou) + neg * sg * sg) * invB;
-        if (qconf) qconf[0] = (5.0f * pos * 2.0f * (sg - iou) + neg * 2.0f * sg) * sg * (1.0f - sg) * invB;
+        if (qconf) qconf[0] = (HT)((5.0f * pos * 2.0f * (sg - iou) + neg * 2.0f * sg) * sg * (1.0f - sg) * invB * gs);
         // class cross-entropy * mask
         // candidates that are not positives contribute nothing to the class term: their (pre-zeroed, see the callers)
         // gradient slots are left untouched, so only the handful of positives walk the class vector
         if (mask > 0.0f) {
             float mx = -INFINITY;
-            for (int c = 0; c < g.C; ++c) mx = fmaxf(mx, pcls[c]);
+            for (int c = 0; c < g.C; ++c) mx = fmaxf(mx, (float)pcls[c]);
             float sum = 0.0f;
-            for (int c = 0; c < g.C; ++c) sum += expf(pcls[c] - mx);
-            if (mask > 0.0f) l_cls = (mx + logf(sum) - pcls[gcls]) * invB;
+            for (int c = 0; c < g.C; ++c) sum += expf((float)pcls[c] - mx);
+            if (mask > 0.0f) l_cls = (mx + logf(sum) - (float)pcls[gcls]) * invB;
             if (qcls) {
                 const float k = mask * invB / sum;
                 for (int c = 0; c < g.C; ++c) {
-                    float gr = expf(pcls[c] - mx) * k;
+                    float gr = expf((float)pcls[c] - mx) * k;
                     if (c == gcls) gr -= mask * invB;
-                    qcls[c] = gr;
+                    qcls[c] = (HT)(gr * gs);
                 }
             }
         }
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a)
                 gt1 += (gb[1] + gb[3]) * dcy;
                 gt2 += 0.5f * (gb[2] - gb[0]) * (bw / S);
                 gt3 += 0.5f * (gb[3] - gb[1]) * (bh / S);
-                qt[0] = gt0; qt[1] = gt1; qt[2] = gt2; qt[3] = gt3;
+                qt[0] = (HT)(gt0 * gs); qt[1] = (HT)(gt1 * gs); qt[2] = (HT)(gt2 * gs); qt[3] = (HT)(gt3 * gs);
             }
         }
     }
@@ -166,10 +171,22 @@ void launch_loss(const float* conf, const float* cls, const float* t, const floa
     const int nb = loss_num_blocks(g, B);
     if (head) {
         for (int k = 0; k < 3; ++k) { a.head[k] = head[k]; a.ghead[k] = ghead ? ghead[k] : nullptr; }
-        hipLaunchKernelGGL(loss_kernel<true>, dim3(nb), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((loss_kernel<true, float>), dim3(nb), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(loss_kernel<false>, dim3(nb), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((loss_kernel<false, float>), dim3(nb), dim3(256), 0, s, a);
     }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nb, losses);
+}
+
+// the same pass over fp16 head tensors (the fp16 training step): losses in fp32, gradients * loss scale stored as fp16
+void launch_loss_h16(const h16* const head[3], h16* const ghead[3], const float* target, const GridInfo& g, int B, float* partial, float* losses,
+                     const float* scale_state, hipStream_t s)
+{
+    LossArgs a{};
+    a.target = target; a.partial = partial; a.g = g; a.B = B; a.gscale = scale_state;
+    for (int k = 0; k < 3; ++k) { a.head[k] = head[k]; a.ghead[k] = ghead ? ghead[k] : nullptr; }
+    const int nb = loss_num_blocks(g, B);
+    hipLaunchKernelGGL((loss_kernel<true, h16>), dim3(nb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nb, losses);
 }
 

@@ -15,6 +15,7 @@
 
 #include "../../include/yolonano_hip.h"
 #include "yn_internal.h"
+#include "yn_h16.h"
 #include <stdlib.h>
 
 using namespace ynk;
@@ -46,6 +47,9 @@ struct Layer {
 };
 
 struct TrainPack { float* wp = nullptr; float* bias = nullptr; float* wp_bwd = nullptr; int Kb = 0, Npad_b = 0; };   // per-layer training weight packs
+
+// per-layer weight packs of the fp16 training step (yn_train_h16.inc): f16 GEMM packs (forward / input gradient), fp32 depthwise taps
+struct HPack { ynk::h16* wf = nullptr; ynk::h16* wb = nullptr; float* bias = nullptr; float* dwf = nullptr; float* dwb = nullptr; int Kp = 0, Npad = 0, Kpb = 0, Npadb = 0; };
 
 struct ProfRec {
     std::string name, kernel;
@@ -101,6 +105,8 @@ struct yn_handle {
     float* zeros = nullptr;
     int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
     int train_dtype = 0;                  // 0 fp32, 1 fp16 storage + f16 MFMA (yn_train_precision)
+    std::vector<HPack> hpacks;
+    float* scale_state = nullptr;         // device float[4]: loss scale, its inverse, clean-step counter, overflow flag (kernels_h16.hip)
     std::vector<hipEvent_t> train_events;
     char* train_arena = nullptr;
     size_t train_arena_bytes = 0;
@@ -733,6 +739,8 @@ template <class F>
 int run_maybe_graph(yn_handle* h, const std::vector<uintptr_t>& key, F body)
 {
     if (!h->use_graph || h->profiling) return body();
+    if (h->stream == nullptr)                               // the legacy default stream cannot be captured; trying leaves the runtime in capture-error state
+        return fail(h, "hipGraph capture needs a non-default stream: create the handle on (or yn_set_stream to) a stream of its own");
     for (GraphEntry& g : h->graphs)
         if (g.key == key) { HIPCHK(h, hipGraphLaunch(g.exec, h->stream)); return 0; }
     if (h->autotune) { const int rc0 = body(); if (rc0) return rc0; }      // eager pass: tunes tile configurations, warms up
@@ -813,6 +821,8 @@ void yn_destroy(yn_handle* h)
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
+    if (h->scale_state) (void)hipFree(h->scale_state);
+    for (HPack& pk : h->hpacks) { void* q[] = {pk.wf, pk.wb, pk.bias, pk.dwf, pk.dwb}; for (void* v : q) if (v) (void)hipFree(v); }
     for (hipEvent_t e : h->train_events) (void)hipEventDestroy(e);
     if (h->train_arena) (void)hipFree(h->train_arena);
     delete h;

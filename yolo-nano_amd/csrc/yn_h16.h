@@ -1,0 +1,78 @@
+// yn_h16.h — declarations of the fp16 training kernels (kernels_h16.hip) shared with the executor (yn_train_h16.inc).
+#pragma once
+#include "yn_internal.h"
+
+namespace ynk {
+
+typedef _Float16 h16;
+
+// C[M][Np] (+)= A[M][Kp] (x taps) * Wp + bias — see hgemm_kernel
+struct HGemmArgs {
+    const h16* in; int in_ld, in_off;           // A rows: Kp physical channels at in + m*in_ld + in_off (16-byte aligned)
+    int H, W, taps;                             // taps = 9: dense 3x3 stride 1 pad 1 over [B,H,W]; 1: pointwise
+    const h16* Wp; const float* bias;           // packed [taps][Kp/8][Npad][8]; bias [Npad] or null
+    h16* out; int out_ld, out_off;
+    int M, Kp, Np, Npad;                        // Np = physical output channels written (multiple of 8), Npad = packed width (multiple of 32)
+    int accumulate;                             // out += result (input-gradient accumulation)
+};
+void launch_hgemm(const HGemmArgs& a, hipStream_t s);
+
+struct HWgradArgs {
+    const h16* dy; int dy_ld;                   // [M][Np] dense
+    const h16* x; int x_ld, x_off;              // [M][Kp] view
+    int H, W, taps;
+    int M, Np, Kp;                              // physical widths
+    int N, Cin, half, gap;                      // logical Cout / Cin and the channel map of x (reference-layout scatter)
+    float* dw;                                  // [N][Cin][taps] fp32 (written)
+    float* partial; size_t partial_cap;
+};
+void launch_hwgrad(const HWgradArgs& a, hipStream_t s);
+
+struct HDwArgs {
+    const h16* in; int in_ld, in_off;
+    const float* w; const float* bias;          // [9][Cp], [Cp] or null
+    h16* out; int out_ld, out_off;
+    int B, H, W, Cp, stride, accumulate;
+};
+void launch_hdw(const HDwArgs& a, hipStream_t s);
+void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
+void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_off, int B, int H, int W, int C, int Cp, int half, int gap, int stride,
+                      float* dw_slots, size_t slot_stride, hipStream_t s);
+
+struct HRedArgs {
+    const h16* y; int y_ld, y_off;              // the matrix (stats / column sum) or the pre-BN conv output (BN backward)
+    int M, C, Cp, half, gap;                    // logical channels, physical width, channel map
+    const h16* dz; int dz_ld, dz_off, dz_odd, dz_half, dz_gap;
+    const float* mean; const float* invstd; const float* gamma; const float* beta; int act;
+    double* acc; float* facc; size_t slot_stride;
+    int lanes;                                  // filled by the launcher
+};
+void launch_hcol_reduce(const HRedArgs& a, int mode, hipStream_t s);      // mode 0 stats, 2 BN-backward sums, 3 column sum -> facc slots
+void launch_hbn_bwd(const HRedArgs& a, h16* dy, float* dgamma, float* dbeta, hipStream_t s);
+
+struct HBnApplyArgs {
+    const h16* y; int y_ld; const double* acc; float eps;
+    int M, C, Cp, half, gap, act;
+    float* mean; float* invstd; const float* gamma; const float* beta;
+    float* rmean; float* rvar; float momentum;
+    h16* out; int out_ld, out_off;
+    const h16* pass; int pass_ld, pass_off; int out_half, out_gap;      // shuffle mode
+};
+void launch_hbn_apply(const HBnApplyArgs& a, hipStream_t s);
+
+void launch_hstem(const float* x_nchw, int B, int H, int W, const float* w, const float* bias, h16* y, hipStream_t s);
+void launch_hstem_wgrad(const h16* dy, const float* x_nchw, int B, int H, int W, float* dw_slots, size_t slot_stride, hipStream_t s);
+void launch_hmaxpool_idx(const h16* x, int B, int H, int W, int Cp, h16* y, int32_t* idx, hipStream_t s);
+void launch_hmaxpool_bwd(const h16* dy, const int32_t* idx, int B, int H, int W, int Cp, h16* dx, hipStream_t s);
+void launch_hresample(const h16* a, const h16* b, h16* out, int B, int H, int W, int Cp, int mode, hipStream_t s);
+void launch_hgather(const h16* src, int src_ld, int src_off, int src_cs, int src_half, int src_gap,
+                    h16* dst, int dst_ld, int dst_off, int dst_cs, int dst_half, int dst_gap, long M, int n, int npad, hipStream_t s);
+void launch_hpack_gemm(const float* w, int Cout, int Cin, int taps, int in_half, int in_gap, int Kp, int Npad, int backward, h16* out, hipStream_t s);
+void launch_hpack_dw(const float* w, const float* bias, int C, int half, int gap, int Cp, int flip, float* out, float* bias_out, hipStream_t s);
+void launch_hpack_stem(const float* w, float* out, hipStream_t s);
+void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, float* state, hipStream_t s);
+// the loss on fp16 head tensors (kernels_train.hip): gradients are multiplied by the loss scale state[0] read on the device
+void launch_loss_h16(const h16* const head[3], h16* const ghead[3], const float* target, const GridInfo& g, int B, float* partial, float* losses,
+                     const float* scale_state, hipStream_t s);
+
+}  // namespace ynk
