@@ -216,6 +216,10 @@ int  yn_train_bind(yn_handle* h, float* params_dev, float* grads_dev, float* mom
 int  yn_train_step(yn_handle* h, const float* x_dev, const float* target_dev, int B, float lr, float momentum,
                    float weight_decay, float grad_scale, int do_update, float* losses_dev);
 int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_t numel);
+/* The forward half of yn_train_step on its own — `model.train(); model.backbone/neck/heads(x)` (models/yolo_nano.py:284-301 with
+ * BatchNorm batch statistics; the running statistics ARE updated) in the precision selected by yn_train_precision: the three
+ * raw NHWC head tensors as dense float32 [B,S/8,S/8,A(5+C)], [B,S/16,..], [B,S/32,..].  Parity hook for the train-mode network. */
+int  yn_train_forward(yn_handle* h, const float* x_dev, int B, float* head_s8_dev, float* head_s16_dev, float* head_s32_dev);
 int  yn_train_skipped_steps(yn_handle* h, int64_t* count_host);
 /* Arithmetic of yn_train_step (BASELINE configs[2] names fp16; train.py itself runs fp32).  YN_F32 (default): fp32 end to end.
  * YN_F16: activations and activation gradients are STORED as fp16 (channel-padded NHWC, half the HBM bytes), every GEMM-shaped
@@ -250,6 +254,16 @@ int  yn_op_shuffle_block(yn_handle* h, const char* block, const float* x, int B,
 /* NCHW <-> NHWC helpers for the tests and the host shim */
 int  yn_op_nchw_to_nhwc(yn_handle* h, const float* x, int B, int C, int H, int W, float* y);
 int  yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W, float* y);
+
+/* Single kernels of the fp16 training step (yn_train_precision YN_F16) behind fp32 NHWC device tensors, for op-level parity: the
+ * inputs are rounded to fp16 into the step's channel-padded layout (gapped != 0: the two-plane layout of a ShuffleV2 unit output,
+ * Cin = 2*bf), ONE kernel per requested result runs, the fp16 results return as fp32.  kind 0 pointwise, 1 depthwise 3x3
+ * (stride 1|2), 2 dense 3x3; w / dw in the reference layouts; y = conv(x) + bias, dx / dw = the gradients for dy (null = skip). */
+int  yn_op_h16_conv(yn_handle* h, int kind, const float* x, int B, int H, int W, int Cin, int gapped, const float* w, const float* bias,
+                    int Cout, int stride, const float* dy, float* y, float* dx, float* dw);
+/* Train-mode BatchNorm (+ activation) forward over y [M][C] and, when dz is given, its backward: z, dy [M][C], dgamma, dbeta [C]. */
+int  yn_op_h16_bn(yn_handle* h, const float* y, const float* dz, int64_t M, int C, const float* gamma, const float* beta, int act,
+                  float* z, float* dy, float* dgamma, float* dbeta);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch of yn_forward_raw / yn_infer is bracketed by a pair of HIP

@@ -1,0 +1,234 @@
+"""GPU parity of the fp16 training step (BASELINE configs[2]: "SGD training step fp16"; yn_train_precision(YN_F16)).
+
+Three layers of evidence, sharpest first:
+
+1. every KERNEL of the step on its own (yn_op_h16_conv / yn_op_h16_bn): the f16-MFMA forward conv, input gradient and weight
+   gradient (pointwise incl. the gapped two-plane layout, dense 3x3, depthwise stride 1 / 2) and the train-mode BatchNorm
+   forward / backward, against float64 torch on the SAME fp16-rounded inputs.  The only differences left are fp32 accumulation
+   and the fp16 rounding of the result: 2e-3 of the output scale.
+
+2. the whole train-mode FORWARD (yn_train_forward) and the whole STEP against the float64 oracle AND against the float64
+   oracle with fp16 STORAGE emulated at the step's storage points (oracle/torch_port.TrainNet(fp16_storage=True)).  SURVEY
+   §8(c) hoped for 1e-2 relative against the exact gradient; measured on this network that is not available to ANY fp16-storage
+   implementation: the random-weight ShuffleNetV2 amplifies a perturbation by ~1.2x per unit (tools in DESIGN §9b), so rounding
+   the stored tensors to fp16 in otherwise EXACT arithmetic already moves the raw heads by ~5 % and the backbone gradients by
+   ~0.5 relative (the fp32 step sits at 1e-2 for the same reason).  The emulation is therefore the yardstick — exactly as the
+   fp32 oracle run is the yardstick for the fp32 step: the HIP step has to be as close to exact as fp16 storage allows, per head
+   and per parameter, and closer to the emulation than the emulation is to exact (same rounding points => correlated).
+
+3. at the full configs[2] shape (608x608, bs=32, COCO head) the size-independent property: -eps * g lowers the loss by
+   eps * |g|^2 to first order.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from yolo_nano_amd import arch, weights
+from tests.test_gpu_train import _handle, _targets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hop():
+    from yolo_nano_amd import capi
+    h = capi.Handle(64, 20, arch.MULTI_ANCHOR_SIZE)
+    yield h
+    h.close()
+
+
+def _q(a):
+    """fp16 rounding as the device stages it, back in float64"""
+    return torch.as_tensor(a).to(torch.float16).to(torch.float64)
+
+
+def _close(got, ref, tol=2e-3):
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else ref
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol * scale + 1e-6)
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,stride,gapped,B,H,W", [
+    (0, 24, 58, 1, 0, 2, 9, 7),        # stage-2 pw1 of the stride-2 block: K = 24 (3 octets: partial chunk)
+    (0, 58, 58, 1, 0, 3, 11, 5),       # bf = 58 plane (padded to 64)
+    (0, 116, 58, 1, 1, 2, 7, 9),       # gapped two-plane input, 2 x 58 -> 2 x 64
+    (0, 232, 116, 1, 1, 1, 13, 6),     # gapped, bf = 116 -> 120
+    (0, 464, 96, 1, 1, 2, 5, 5),       # lateral on the stage-4 output (no gap: 232 is a multiple of 8)
+    (0, 96, 255, 1, 0, 2, 6, 7),       # head output conv: N = 255 -> 256, bias
+    (0, 116, 116, 1, 0, 1, 40, 37),    # several row tiles, ragged M
+    (2, 96, 96, 1, 0, 2, 9, 11),       # dense 3x3 (smooth_*), image borders inside a tile, two images
+    (2, 96, 96, 1, 0, 1, 21, 19),      # several row tiles
+    (1, 58, 58, 1, 0, 2, 9, 7), (1, 116, 116, 2, 1, 2, 10, 12), (1, 24, 24, 2, 0, 2, 11, 9), (1, 96, 96, 1, 0, 1, 13, 13), (1, 232, 232, 2, 1, 1, 8, 6),
+])
+def test_h16_conv_kernels_vs_float64(hop, kind, Cin, Cout, stride, gapped, B, H, W):
+    rs = np.random.RandomState(kind * 1000 + Cin + Cout + H)
+    x = rs.standard_normal((B, Cin, H, W)).astype(np.float32)
+    if kind == 1:
+        w = (rs.standard_normal((Cout, 1, 3, 3)) / 3).astype(np.float32)
+    else:
+        k = 3 if kind == 2 else 1
+        w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = (rs.standard_normal((Cout,)) * 0.3).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    nhwc = lambda a: torch.as_tensor(np.ascontiguousarray(np.transpose(a, (0, 2, 3, 1)))).cuda()
+    y, dx, dw = hop.op_h16_conv(kind, nhwc(x), torch.as_tensor(w).cuda(), torch.as_tensor(b).cuda(), stride, nhwc(dy), gapped)
+    # float64 reference on the fp16-rounded operands (weights of the GEMM-shaped convs are fp16 packs; depthwise taps stay fp32)
+    xq = _q(x).requires_grad_(True)
+    wq = (_q(w) if kind != 1 else torch.as_tensor(w).double()).requires_grad_(True)
+    ref = F.conv2d(xq, wq, torch.as_tensor(b).double(), stride=stride, padding=0 if kind == 0 else 1, groups=Cout if kind == 1 else 1)
+    ref.backward(_q(dy))
+    to_nchw = lambda t: t.permute(0, 3, 1, 2).cpu().numpy()
+    _close(to_nchw(y), ref.detach())
+    _close(to_nchw(dx), xq.grad)
+    _close(dw.cpu().numpy(), wq.grad, 2e-3 if kind != 1 else 1e-4)         # fp32 accumulation over M; the depthwise path keeps fp32 products
+
+
+@pytest.mark.parametrize("M,C,act", [(500, 58, 1), (4097, 96, 2), (333, 24, 1), (129, 232, 0), (64, 116, 1)])
+def test_h16_batchnorm_kernels_vs_float64(hop, M, C, act):
+    rs = np.random.RandomState(M + C)
+    y = (rs.standard_normal((M, C)) * rs.uniform(0.5, 2.0, C) + rs.uniform(-1, 1, C)).astype(np.float32)
+    dz = rs.standard_normal((M, C)).astype(np.float32)
+    ga, be = rs.uniform(0.7, 1.3, C).astype(np.float32), rs.uniform(-0.2, 0.2, C).astype(np.float32)
+    z, dy, dg, db = hop.op_h16_bn(torch.as_tensor(y).cuda(), torch.as_tensor(ga).cuda(), torch.as_tensor(be).cuda(), act, torch.as_tensor(dz).cuda())
+    yq = _q(y).requires_grad_(True)
+    g64, b64 = torch.as_tensor(ga).double().requires_grad_(True), torch.as_tensor(be).double().requires_grad_(True)
+    r = F.batch_norm(yq, None, None, g64, b64, training=True, eps=arch.BN_EPS)
+    r = F.relu(r) if act == 1 else (F.leaky_relu(r, 0.1) if act == 2 else r)
+    r.backward(_q(dz))
+    _close(z.cpu().numpy(), r.detach(), 1e-3)
+    # an activation sign can flip where the fp32 BN value rounds across zero: compare in L2, not max
+    rel = lambda a, e: float(np.linalg.norm(a - e.numpy()) / np.linalg.norm(e.numpy()))
+    assert rel(dy.cpu().numpy(), yq.grad) < 5e-3
+    assert rel(dg.cpu().numpy(), g64.grad) < 2e-3 and rel(db.cpu().numpy(), b64.grad) < 2e-3
+
+
+def _oracles(sd, backbone, C, x, target, S):
+    from oracle.torch_port import TrainNet
+    mk = lambda **kw: TrainNet(sd, backbone, C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=torch.float64, **kw)
+    exact, emul = mk(), mk(fp16_storage=True)
+    with torch.no_grad():
+        h64 = [t.numpy() for t in exact.forward_raw(x)]
+        hq = [t.numpy() for t in emul.forward_raw(x)]
+    l64, g64 = mk().train_step(x, target, S)
+    lq, gq = mk(fp16_storage=True).train_step(x, target, S)
+    return h64, hq, l64, {k: v.numpy() for k, v in g64.items()}, lq, {k: v.numpy() for k, v in gq.items()}
+
+
+@pytest.mark.parametrize("backbone,S,C,B", [("1.0x", 128, 20, 8), ("0.5x", 160, 80, 4)])
+def test_h16_step_is_as_exact_as_fp16_storage_allows(golden, backbone, S, C, B):
+    g = golden("train.npz")
+    h, sd = _handle(S, C, B, float(g["init_bias_value"]), backbone)
+    h.train_precision("f16")
+    target = _targets(S, C, B)
+    x = weights.make_input(B, S, seed=21)
+    h64, hq, l64, g64, lq, gq = _oracles(sd, backbone, C, x, target, S)
+    rms = lambda a: float(np.sqrt((np.asarray(a, np.float64) ** 2).mean()))
+    # ---- forward: raw heads of the train-mode network
+    got = [t.permute(0, 3, 1, 2).cpu().numpy() for t in h.train_forward(torch.as_tensor(x).cuda())]
+    for k in range(3):
+        e_hip, e_emul, d = rms(got[k] - h64[k]), rms(hq[k] - h64[k]), rms(got[k] - hq[k])
+        assert e_hip <= 1.3 * e_emul + 1e-3 * rms(h64[k]), (k, e_hip, e_emul)          # as exact as fp16 storage allows
+        assert d <= 1.0 * e_emul + 1e-3 * rms(h64[k]), (k, d, e_emul)                  # and on the emulation's side of exact (same rounding points)
+    # ---- the step (the forward above moved the running statistics only; parameters are untouched)
+    losses = h.train_step(torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda(), lr=1e-3, update=False).cpu().numpy()
+    assert np.isfinite(losses).all()
+    for a, e, q in zip(losses, l64, lq):
+        assert abs(a - e) <= 2.0 * abs(q - e) + 5e-3 * abs(e), (losses, l64, lq)
+    gmax = max(float(np.abs(v).max()) for v in g64.values())
+    rel = lambda a, e: float(np.linalg.norm((a - e).ravel()) / np.linalg.norm(e.ravel()))
+    bad, ratios = [], []
+    for name, exact in g64.items():
+        got_g = h.flat_grads[h.param_slice(name)].cpu().numpy().reshape(exact.shape).astype(np.float64)
+        assert np.isfinite(got_g).all(), name
+        if float(np.abs(exact).max()) < 1e-9 * gmax:                                      # mathematically zero (bias in front of BN)
+            assert float(np.abs(got_g).max()) <= 1e-6 * gmax, name
+            continue
+        e_hip, e_emul = rel(got_g, exact), rel(gq[name], exact)
+        ratios.append(e_hip / max(e_emul, 1e-6))
+        if e_hip > 1.5 * e_emul + 2e-2:
+            bad.append((name, e_hip, e_emul))
+    assert not bad, "fp16 gradients further from exact than fp16 storage explains (name, hip, emulation): %s" % bad[:10]
+    assert np.median(ratios) < 1.25, np.median(ratios)
+    # the loss scale is removed again, and a clean step leaves it in place
+    assert h.skipped_steps() == 0
+    h.close()
+
+
+def test_h16_step_matches_fp32_step_on_a_shallow_path(golden):
+    """Where fp16 rounding is NOT amplified by depth the two precisions must agree closely: the head output convolutions' own
+    parameters see the loss gradient directly (one conv away), so their fp16 gradients are within a few 1e-3 of what the
+    fp16-rounded inputs give — checked against the fp32 step run on the same parameters: cosine > 0.98 for the head biases."""
+    g = golden("train.npz")
+    S, C, B = 128, 20, 8
+    x = torch.as_tensor(weights.make_input(B, S, seed=21)).cuda()
+    t = torch.as_tensor(_targets(S, C, B)).cuda()
+    grads = {}
+    for dt in ("f32", "f16"):
+        h, _ = _handle(S, C, B, float(g["init_bias_value"]))
+        h.train_precision(dt)
+        h.train_step(x, t, update=False)
+        grads[dt] = {k: h.flat_grads[h.param_slice(k)].double().cpu() for k in ("head_det_1.4.bias", "head_det_2.4.bias", "head_det_3.4.bias")}
+        h.close()
+    for k in grads["f32"]:
+        a, b = grads["f32"][k], grads["f16"][k]
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.98, (k, cos)
+
+
+def test_h16_loss_scale_overflow_is_skipped_and_backed_off(golden, monkeypatch):
+    """An absurd initial loss scale overflows the fp16 gradients: the step's bucket is non-finite, yn_sgd_step skips it, the scale
+    is halved on the device each time, and training proceeds once it fits — no host round trip decides any of this."""
+    g = golden("train.npz")
+    monkeypatch.setenv("YN_LOSS_SCALE", str(2.0 ** 26))
+    h, _ = _handle(128, 20, 4, float(g["init_bias_value"]))
+    monkeypatch.delenv("YN_LOSS_SCALE")
+    h.train_precision("f16")
+    x = torch.as_tensor(weights.make_input(4, 128, seed=3)).cuda()
+    t = torch.as_tensor(_targets(128, 20, 4)).cuda()
+    p0 = h.flat_params.clone()
+    h.train_step(x, t, lr=1e-3, update=True)
+    assert torch.equal(h.flat_params, p0) and h.skipped_steps() == 1 and not torch.isfinite(h.flat_grads).all()
+    for _ in range(40):
+        h.train_step(x, t, lr=1e-4, update=True)
+        if torch.isfinite(h.flat_grads).all():
+            break
+    assert torch.isfinite(h.flat_grads).all() and not torch.equal(h.flat_params, p0)
+    assert 2 <= h.skipped_steps() <= 30
+    h.close()
+
+
+def test_h16_full_size_directional_derivative():
+    """BASELINE configs[2] as named (1.0x, 608x608, bs=32, COCO head, fp16): -eps * g lowers the summed loss by eps * |g|^2 to first
+    order.  The fp16 forward carries ~1e-3 relative noise, so the probe steps are larger than in the fp32 twin of this test."""
+    from yolo_nano_amd import capi
+    S, C, B = 608, 80, 32
+    sd = weights.make_state_dict("1.0x", C)
+    h = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", max_batch=B)
+    h.load_state_dict(sd)
+    h.train_bind()
+    h.train_precision("f16")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    x = torch.randn((B, 3, S, S), generator=gen, device="cuda")
+    rs = np.random.RandomState(3)
+    labels = []
+    for _ in range(B):
+        c = rs.uniform(0.25, 0.75, (8, 2)); wh = rs.uniform(0.05, 0.5, (8, 2))
+        box = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32).astype(np.float64)
+        labels.append(np.concatenate([box, rs.randint(0, C, (8, 1)).astype(np.float64)], 1).tolist())
+    t = h.make_targets(labels, arch.MULTI_ANCHOR_SIZE_COCO)
+    l0 = float(h.train_step(x, t, update=False).double().sum())
+    g = h.flat_grads.clone()
+    assert torch.isfinite(g).all() and h.skipped_steps() == 0
+    g2 = float((g.double() ** 2).sum())
+    p0 = h.flat_params.clone()
+    ratios = []
+    for frac in (0.03, 0.06):
+        eps = frac * l0 / g2
+        h.flat_params.copy_(p0 - eps * g)
+        l1 = float(h.train_step(x, t, update=False).double().sum())
+        ratios.append((l0 - l1) / (eps * g2))
+    h.flat_params.copy_(p0)
+    assert all(0.6 < r < 1.2 for r in ratios), (l0, g2, ratios)
+    h.close()

@@ -66,6 +66,7 @@ SIGNATURES = {
     "yn_train_bind": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64]),
     "yn_train_step": (_i32, [_vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
+    "yn_train_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_train_skipped_steps": (_i32, [_vp, _i64p]),
     "yn_train_precision": (_i32, [_vp, _i32]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
@@ -83,6 +84,8 @@ SIGNATURES = {
     "yn_op_shuffle_block": (_i32, [_vp, ctypes.c_char_p, _vp, _i32, _i32, _i32, _vp]),
     "yn_op_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "yn_op_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "yn_op_h16_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "yn_op_h16_bn": (_i32, [_vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_profile_enable": (_i32, [_vp, _i32]),
     "yn_profile_count": (_i32, [_vp]),
     "yn_profile_get": (_i32, [_vp, _i32, ctypes.c_char_p, _i32, ctypes.c_char_p, _i32, ctypes.POINTER(_f32),
@@ -491,6 +494,13 @@ class Handle:
                                         float(grad_scale), int(bool(update)), losses.data_ptr()), "yn_train_step")
         return losses
 
+    def train_forward(self, x):
+        """Train-mode forward only (batch statistics; running statistics updated) -> three NHWC float32 raw heads."""
+        B = x.shape[0]
+        outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.head_shapes(B)]
+        self._ck(self.lib.yn_train_forward(self.h, x.contiguous().float().data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_train_forward")
+        return outs
+
     def read_param(self, key, shape):
         import numpy as np
         a = np.empty(shape, dtype=np.float32)
@@ -565,6 +575,29 @@ class Handle:
         y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.float32, device=x.device)
         self._ck(self.lib.yn_op_shuffle_block(self.h, block.encode(), _ptr(x.contiguous()), B, H, W, y.data_ptr()), "yn_op_shuffle_block")
         return y
+
+    def op_h16_conv(self, kind, x, w, bias=None, stride=1, dy=None, gapped=False):
+        """One conv kernel of the fp16 training step (+ its two gradient kernels when dy is given): x [B,H,W,Cin] fp32 NHWC,
+        kind 0 pw / 1 dw / 2 dense3x3 -> (y, dx, dw) fp32 (dx, dw None without dy)."""
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if dy is not None else None
+        dw = torch.empty_like(w) if dy is not None else None
+        self._ck(self.lib.yn_op_h16_conv(self.h, int(kind), x.contiguous().data_ptr(), B, H, W, Cin, int(bool(gapped)), w.contiguous().data_ptr(), _ptr(bias),
+                                         Cout, int(stride), _ptr(dy.contiguous() if dy is not None else None), y.data_ptr(), _ptr(dx), _ptr(dw)), "yn_op_h16_conv")
+        return y, dx, dw
+
+    def op_h16_bn(self, y, gamma, beta, act=0, dz=None):
+        M, C = y.shape
+        z = torch.empty_like(y)
+        dy = torch.empty_like(y) if dz is not None else None
+        dg = torch.empty((C,), dtype=torch.float32, device=y.device) if dz is not None else None
+        db = torch.empty((C,), dtype=torch.float32, device=y.device) if dz is not None else None
+        self._ck(self.lib.yn_op_h16_bn(self.h, y.contiguous().data_ptr(), _ptr(dz.contiguous() if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
+                                       int(act), z.data_ptr(), _ptr(dy), _ptr(dg), _ptr(db)), "yn_op_h16_bn")
+        return z, dy, dg, db
 
     def to_nhwc(self, x):
         B, C, H, W = x.shape

@@ -1117,6 +1117,55 @@ void launch_hpack_stem(const float* w, float* out, hipStream_t s)
     hipLaunchKernelGGL(hpack_stem_kernel, dim3(3), dim3(256), 0, s, w, out);
 }
 
+// fp32 dense rows [M][C] <-> h16 rows in the padded / gapped layout (op-level parity entry points; dst pads pre-zeroed by the caller)
+__global__ __launch_bounds__(256) void hstage_kernel(const float* __restrict__ src, int C, h16* __restrict__ dst, int ld, int half, int gap, long M)
+{
+    const long total = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        dst[(size_t)m * ld + c + (c >= half ? gap : 0)] = (h16)src[i];
+    }
+}
+__global__ __launch_bounds__(256) void hunstage_kernel(const h16* __restrict__ src, int ld, int half, int gap, float* __restrict__ dst, int C, long M)
+{
+    const long total = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        dst[i] = (float)src[(size_t)m * ld + c + (c >= half ? gap : 0)];
+    }
+}
+void launch_hstage(const float* src, int C, h16* dst, int ld, int half, int gap, long M, hipStream_t s)
+{
+    long blocks = (M * C + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hstage_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, C, dst, ld, half, gap, M);
+}
+void launch_hunstage(const h16* src, int ld, int half, int gap, float* dst, int C, long M, hipStream_t s)
+{
+    long blocks = (M * C + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hunstage_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, ld, half, gap, dst, C, M);
+}
+
+// dst[m][j] = (float)src[m*src_ld + j], j < n: the raw heads of a train-mode forward as dense fp32 rows (yn_train_forward)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_f32_kernel(const T* __restrict__ src, int src_ld, float* __restrict__ dst, int n, long M)
+{
+    const long total = M * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / n;
+        dst[i] = (float)src[(size_t)m * src_ld + (int)(i - m * n)];
+    }
+}
+void launch_rows_to_f32(const void* src, int is_h16, int src_ld, float* dst, int n, long M, hipStream_t s)
+{
+    long blocks = (M * n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    if (is_h16) hipLaunchKernelGGL(rows_to_f32_kernel<h16>, dim3((unsigned)blocks), dim3(256), 0, s, (const h16*)src, src_ld, dst, n, M);
+    else hipLaunchKernelGGL(rows_to_f32_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, src_ld, dst, n, M);
+}
+
 // =================================================================================================
 // Loss-scale bookkeeping, all on the device (no host round trip, capture-friendly).
 //   state[0] = current scale S, state[1] = 1/S, state[2] = clean steps since the last change (as float), state[3] = overflow flag

@@ -93,6 +93,7 @@ struct yn_handle {
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
+    float* fwd_only[3] = {nullptr, nullptr, nullptr};     // yn_train_forward: the training executors stop after the forward pass and copy the raw heads here
     float* tap_out[3] = {nullptr, nullptr, nullptr};      // yn_forward_taps: where run_network copies c3 / c4 / c5
     float* loss_partial = nullptr;
     size_t loss_partial_cap = 0;

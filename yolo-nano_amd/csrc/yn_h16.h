@@ -70,6 +70,9 @@ void launch_hgather(const h16* src, int src_ld, int src_off, int src_cs, int src
 void launch_hpack_gemm(const float* w, int Cout, int Cin, int taps, int in_half, int in_gap, int Kp, int Npad, int backward, h16* out, hipStream_t s);
 void launch_hpack_dw(const float* w, const float* bias, int C, int half, int gap, int Cp, int flip, float* out, float* bias_out, hipStream_t s);
 void launch_hpack_stem(const float* w, float* out, hipStream_t s);
+void launch_hstage(const float* src, int C, h16* dst, int ld, int half, int gap, long M, hipStream_t s);
+void launch_hunstage(const h16* src, int ld, int half, int gap, float* dst, int C, long M, hipStream_t s);
+void launch_rows_to_f32(const void* src, int is_h16, int src_ld, float* dst, int n, long M, hipStream_t s);
 void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, float* state, hipStream_t s);
 // the loss on fp16 head tensors (kernels_train.hip): gradients are multiplied by the loss scale state[0] read on the device
 void launch_loss_h16(const h16* const head[3], h16* const ghead[3], const float* target, const GridInfo& g, int B, float* partial, float* losses,
