@@ -142,8 +142,8 @@ def test_h16_step_is_as_exact_as_fp16_storage_allows(golden, backbone, S, C, B):
     for name, exact in g64.items():
         got_g = h.flat_grads[h.param_slice(name)].cpu().numpy().reshape(exact.shape).astype(np.float64)
         assert np.isfinite(got_g).all(), name
-        if float(np.abs(exact).max()) < 1e-9 * gmax:                                      # mathematically zero (bias in front of BN)
-            assert float(np.abs(got_g).max()) <= 1e-6 * gmax, name
+        if float(np.abs(exact).max()) < 1e-9 * gmax:      # mathematically zero (a per-channel shift in front of conv + BN): fp16 rounding of the
+            assert float(np.abs(got_g).max()) <= 3.0 * float(np.abs(gq[name]).max()) + 1e-5 * gmax, name     # stored tensors breaks the exact cancellation, in the emulation too
             continue
         e_hip, e_emul = rel(got_g, exact), rel(gq[name], exact)
         ratios.append(e_hip / max(e_emul, 1e-6))
@@ -181,14 +181,14 @@ def test_h16_loss_scale_overflow_is_skipped_and_backed_off(golden, monkeypatch):
     """An absurd initial loss scale overflows the fp16 gradients: the step's bucket is non-finite, yn_sgd_step skips it, the scale
     is halved on the device each time, and training proceeds once it fits — no host round trip decides any of this."""
     g = golden("train.npz")
-    monkeypatch.setenv("YN_LOSS_SCALE", str(2.0 ** 26))
     h, _ = _handle(128, 20, 4, float(g["init_bias_value"]))
-    monkeypatch.delenv("YN_LOSS_SCALE")
     h.train_precision("f16")
     x = torch.as_tensor(weights.make_input(4, 128, seed=3)).cuda()
     t = torch.as_tensor(_targets(128, 20, 4)).cuda()
     p0 = h.flat_params.clone()
+    monkeypatch.setenv("YN_LOSS_SCALE", str(2.0 ** 26))         # read when the first fp16 step creates the scale state
     h.train_step(x, t, lr=1e-3, update=True)
+    monkeypatch.delenv("YN_LOSS_SCALE")
     assert torch.equal(h.flat_params, p0) and h.skipped_steps() == 1 and not torch.isfinite(h.flat_grads).all()
     for _ in range(40):
         h.train_step(x, t, lr=1e-4, update=True)

@@ -304,38 +304,55 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a)
     }
 }
 
-// dW (reference layout, logical channels) = sum over slices of partial[s][n][tap][k_phys], in slice order; * inv_scale
-__global__ __launch_bounds__(256) void hwgrad_reduce_kernel(const float* __restrict__ partial, int slices, int Np, int Kp, int taps,
-                                                             int N, int Cin, int half, int gap, float* __restrict__ dw)
+// dW (reference layout, logical channels) = sum over slices of partial[s][n][tap][k_phys].  Block = 64 consecutive PACKED entries
+// (n, tap, k_phys: coalesced 256-byte reads) x 16 slice lanes — a thread adds every 16th slice with four loads in flight — then an
+// LDS tree over the slice lanes; pad entries (k_phys in a gap, n >= N) are dropped, the rest scatter to [n][ci][tap].  Fixed order.
+__global__ __launch_bounds__(1024) void hwgrad_reduce_kernel(const float* __restrict__ partial, int slices, int Np, int Kp, int taps,
+                                                              int N, int Cin, int half, int gap, float* __restrict__ dw)
 {
-    const long total = (long)N * Cin * taps;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int n = (int)(i / ((long)Cin * taps));
-    const int rem = (int)(i - (long)n * Cin * taps);
-    const int ci = rem / taps, tap = rem - ci * taps;                 // reference layouts: [Cout][Cin] and [Cout][Cin][3][3]
-    const int kp = ci + (ci >= half ? gap : 0);
-    const size_t src = ((size_t)n * taps + tap) * Kp + kp, stride = (size_t)Np * Kp * taps;
-    float s0 = 0.0f, s1 = 0.0f;
-    int s = 0;
-    for (; s + 1 < slices; s += 2) { s0 += partial[(size_t)s * stride + src]; s1 += partial[(size_t)(s + 1) * stride + src]; }
-    if (s < slices) s0 += partial[(size_t)s * stride + src];
-    dw[i] = s0 + s1;
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long total = (long)N * taps * Kp;                             // packed entries of the real output channels
+    const long i = (long)blockIdx.x * 64 + e;
+    const size_t stride = (size_t)Np * Kp * taps;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < total) {
+        int s = sl;
+        for (; s + 48 < slices; s += 64) {
+            s0 += partial[(size_t)s * stride + i]; s1 += partial[(size_t)(s + 16) * stride + i];
+            s2 += partial[(size_t)(s + 32) * stride + i]; s3 += partial[(size_t)(s + 48) * stride + i];
+        }
+        for (; s < slices; s += 16) s0 += partial[(size_t)s * stride + i];
+    }
+    red[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][e];
+        const int kp = (int)(i % Kp);
+        const long nt = i / Kp;
+        const int tap = (int)(nt % taps), n = (int)(nt / taps);
+        int ci = -1;
+        if (kp < half) ci = kp; else if (kp >= half + gap) ci = kp - gap;
+        if (ci >= 0 && ci < Cin) dw[((size_t)n * Cin + ci) * taps + tap] = v;
+    }
 }
 
 void launch_hwgrad(const HWgradArgs& a, hipStream_t s)
 {
     const int gn = (a.Np + 63) / 64, gk = (a.Kp + 63) / 64 * a.taps;
     int slices = 1024 / (gn * gk);
-    const int max_slices = (a.M + 255) / 256;
+    if (slices > 512) slices = 512;
+    const int max_slices = (a.M + 511) / 512;
     if (slices > max_slices) slices = max_slices;
     const long nk = (long)a.Np * a.Kp * a.taps;
     if ((long)slices * nk > (long)a.partial_cap) slices = (int)((long)a.partial_cap / nk);
     if (slices < 1) slices = 1;
     if (a.taps == 9) hipLaunchKernelGGL(hwgrad_kernel<9>, dim3(gn, gk, slices), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(hwgrad_kernel<1>, dim3(gn, gk, slices), dim3(256), 0, s, a);
-    const long total = (long)a.N * a.Cin * a.taps;
-    hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.partial, slices, a.Np, a.Kp, a.taps,
+    const long total = (long)a.N * a.taps * a.Kp;
+    hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, a.partial, slices, a.Np, a.Kp, a.taps,
                        a.N, a.Cin, a.half, a.gap, a.dw);
 }
 
@@ -476,12 +493,20 @@ __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = (float)v[j];
     } else {
+        const int l0 = 2 * p0;                                          // y is dense here (half == C): physical == logical
+        if (p0 + 8 <= a.C && (l0 + 16 <= a.dz_half || l0 >= a.dz_half)) {             // the 16 interleaved values sit in one plane: two 16-byte loads
+            const h16* q = a.dz + row * a.dz_ld + l0 + (l0 >= a.dz_half ? a.dz_gap : 0);
+            const h16x8 v0 = ldh8(q), v1 = ldh8(q + 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = p0 + j;                                       // y is dense here (half == C): physical == logical
-            const int l = 2 * c + 1;
-            const int pp = l + (l >= a.dz_half ? a.dz_gap : 0);
-            g[j] = c < a.C ? (float)a.dz[row * a.dz_ld + pp] : 0.0f;
+            for (int j = 0; j < 4; ++j) { g[j] = (float)v0[2 * j + 1]; g[4 + j] = (float)v1[2 * j + 1]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = p0 + j;
+                const int l = 2 * c + 1;
+                const int pp = l + (l >= a.dz_half ? a.dz_gap : 0);
+                g[j] = c < a.C ? (float)a.dz[row * a.dz_ld + pp] : 0.0f;
+            }
         }
     }
 }
@@ -507,31 +532,36 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
         if (MODE == 2 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
     }
     if (live) {
+        constexpr int U = 4;
         const long step = (long)gridDim.x * rowsPer;
-        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += 2 * step) {
-            const bool has2 = r + step < a.M;
-            const long r2 = has2 ? r + step : r;
-            const h16x8 v0 = ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0);
-            const h16x8 v1 = ldh8(a.y + (size_t)r2 * a.y_ld + a.y_off + p0);
-            float g0[8], g1[8];
-            if (MODE == 2) { load_dz8(a, (size_t)r, p0, g0); load_dz8(a, (size_t)r2, p0, g1); }
+        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += U * step) {
+            h16x8 v[U];
+            float g[U][8];
+            bool ok[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y0 = (float)v0[j], y1 = has2 ? (float)v1[j] : 0.0f;
-                if (MODE == 0) {
-                    s0[j] += (double)y0 + (double)y1;
-                    s1[j] += (double)y0 * (double)y0 + (double)y1 * (double)y1;
-                } else if (MODE == 3) {
-                    s0[j] += (double)y0 + (double)y1;
-                } else {
-                    float d0 = g0[j], d1 = has2 ? g1[j] : 0.0f;
-                    if (a.act) {
-                        d0 = hact_grad(d0, hbn_value(y0, mu[j], is[j], ga[j], be[j]), a.act);
-                        d1 = hact_grad(d1, hbn_value((float)v1[j], mu[j], is[j], ga[j], be[j]), a.act);
+            for (int u = 0; u < U; ++u) { ok[u] = r + u * step < a.M; v[u] = ldh8(a.y + (size_t)(ok[u] ? r + u * step : r) * a.y_ld + a.y_off + p0); }
+            if (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) load_dz8(a, (size_t)(ok[u] ? r + u * step : r), p0, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float yv = (float)v[u][j];
+                    if (MODE == 0) {
+                        const float y0 = ok[u] ? yv : 0.0f;
+                        s0[j] += (double)y0;
+                        s1[j] += (double)y0 * (double)y0;
+                    } else if (MODE == 3) {
+                        s0[j] += ok[u] ? (double)yv : 0.0;
+                    } else {
+                        float d = ok[u] ? g[u][j] : 0.0f;
+                        if (a.act) d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+                        const float xh = (yv - mu[j]) * is[j];
+                        s0[j] += (double)d;
+                        s1[j] += (double)d * (double)xh;
                     }
-                    const float x0 = (y0 - mu[j]) * is[j], x1 = ((float)v1[j] - mu[j]) * is[j];
-                    s0[j] += (double)d0 + (double)d1;
-                    s1[j] += (double)d0 * (double)x0 + (double)d1 * (double)x1;
                 }
             }
         }
@@ -590,42 +620,43 @@ void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
 //      backbone/shufflenetv2.py:14-28,72-74), pads zeroed.  Block 0 saves mean / invstd and updates the running statistics.
 __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
 {
-    const int OC = a.Cp >> 3;
-    const long total = (long)a.M * OC;
+    // per-channel constants once per BLOCK (thread c <-> logical channel c; C <= 256), not per thread: mean / invstd from the
+    // double sums (16 loads + a double sqrt per channel), gamma, beta; block 0 also saves them and updates the running statistics
+    __shared__ float cst[4][256];
     const double invM = 1.0 / (double)a.M;
-    // per-thread channel constants: the octet a thread owns is fixed over its grid-stride loop when the stride is a multiple of OC
-    const long stride = ((long)gridDim.x * 256 + OC - 1) / OC * OC;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= stride) return;
-    const int oc = (int)(i % OC), p0 = oc * 8;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double m = 0.0, q = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < ACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * a.C + c]; q += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+        m *= invM;
+        double var = q * invM - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)a.eps));
+        cst[0][c] = mu; cst[1][c] = is; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+        if (blockIdx.x == 0) {
+            a.mean[c] = mu; a.invstd[c] = is;
+            if (a.rmean) {
+                const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
+                a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu;
+                a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const int OL = a.lanes, rowsPer = 256 / OL;
+    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
+    const int OC = a.Cp >> 3;
+    if (ol >= OC) return;
+    const int p0 = ol * 8;
     int lc[8];
     float mu[8], is[8], ga[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
-        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
-        if (lc[j] >= 0) {
-            const int c = lc[j];
-            double m = 0.0, q = 0.0;
-#pragma unroll
-            for (int sl = 0; sl < ACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * a.C + c]; q += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
-            m *= invM;
-            double var = q * invM - m * m;
-            if (var < 0.0) var = 0.0;
-            mu[j] = (float)m; is[j] = (float)(1.0 / sqrt(var + (double)a.eps)); ga[j] = a.gamma[c]; be[j] = a.beta[c];
-            if (i < OC) {                                               // first pass over the channels: exactly one thread per channel
-                a.mean[c] = mu[j]; a.invstd[c] = is[j];
-                if (a.rmean) {
-                    const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
-                    a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu[j];
-                    a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
-                }
-            }
-        }
+        const int c = lc[j] >= 0 ? lc[j] : 0;
+        mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c];
     }
-    for (; i < total; i += stride) {
-        const long m = i / OC;
-        const h16x8 v = ldh8(a.y + (size_t)m * a.y_ld + p0);
+    auto emit = [&](long m, h16x8 v, h16x8 pv) {
         float z[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = lc[j] >= 0 ? hact(hbn_value((float)v[j], mu[j], is[j], ga[j], be[j]), a.act) : 0.0f;
@@ -635,65 +666,89 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
             for (int j = 0; j < 8; ++j) r[j] = (h16)z[j];
             sth8(a.out + (size_t)m * a.out_ld + a.out_off + p0, r);
         } else {
-            const h16x8 pv = ldh8(a.pass + (size_t)m * a.pass_ld + a.pass_off + p0);
             h16* o = a.out + (size_t)m * a.out_ld;
+            const int l0 = 2 * p0;                                      // logical position of the octet's first output pair (y dense: physical == logical)
+            if (p0 + 8 <= a.C && (l0 + 16 <= a.out_half || l0 >= a.out_half)) {      // the 16 interleaved values do not straddle the plane boundary: two 16-byte stores
+                const int pp = l0 + (l0 >= a.out_half ? a.out_gap : 0);
+                h16x8 r0, r1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = p0 + j;                                   // y dense: physical == logical
-                if (c >= a.C) continue;
-                const int l = 2 * c;
-                const int pp = l + (l >= a.out_half ? a.out_gap : 0);
-                h16x2 w2; w2[0] = pv[j]; w2[1] = (h16)z[j];
-                *reinterpret_cast<h16x2*>(o + pp) = w2;
+                for (int j = 0; j < 4; ++j) { r0[2 * j] = pv[j]; r0[2 * j + 1] = (h16)z[j]; r1[2 * j] = pv[4 + j]; r1[2 * j + 1] = (h16)z[4 + j]; }
+                sth8(o + pp, r0); sth8(o + pp + 8, r1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = p0 + j;
+                    if (c >= a.C) continue;
+                    const int l = 2 * c;
+                    const int pp = l + (l >= a.out_half ? a.out_gap : 0);
+                    h16x2 w2; w2[0] = pv[j]; w2[1] = (h16)z[j];
+                    *reinterpret_cast<h16x2*>(o + pp) = w2;
+                }
             }
-            if (oc == 0 && a.out_gap > 0) {                             // the two pad runs of the gapped row
+            if (ol == 0 && a.out_gap > 0) {                             // the two pad runs of the gapped row
                 for (int q = 0; q < a.out_gap; ++q) { o[a.out_half + q] = (h16)0.0f; o[2 * a.out_half + a.out_gap + q] = (h16)0.0f; }
             }
         }
+    };
+    constexpr int U = 4;
+    const long step = (long)gridDim.x * rowsPer;
+    long r = (long)blockIdx.x * rowsPer + rl;
+    for (; r + (U - 1) * step < a.M; r += U * step) {
+        h16x8 v[U], pv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ldh8(a.y + (size_t)(r + u * step) * a.y_ld + p0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) pv[u] = a.pass ? ldh8(a.pass + (size_t)(r + u * step) * a.pass_ld + a.pass_off + p0) : zero8();
+#pragma unroll
+        for (int u = 0; u < U; ++u) emit(r + u * step, v[u], pv[u]);
     }
+    for (; r < a.M; r += step) emit(r, ldh8(a.y + (size_t)r * a.y_ld + p0), a.pass ? ldh8(a.pass + (size_t)r * a.pass_ld + a.pass_off + p0) : zero8());
 }
 
-void launch_hbn_apply(const HBnApplyArgs& a, hipStream_t s)
+static int hstream_blocks(long M, int rowsPer)
 {
-    const long total = (long)a.M * (a.Cp >> 3);
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(hbn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    long b = (M + (long)rowsPer * 4 - 1) / ((long)rowsPer * 4);
+    if (b > 256 * 6) b = 256 * 6;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_hbn_apply(const HBnApplyArgs& a0, hipStream_t s)
+{
+    HBnApplyArgs a = a0;
+    a.lanes = hlanes_for(a.Cp);
+    hipLaunchKernelGGL(hbn_apply_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a);
 }
 
 // ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)); dy dense h16 [M][Cp] with y's map,
 //      pads zero; one thread per channel writes dgamma / dbeta (fp32, still carrying the loss scale).
 __global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    const int OC = a.Cp >> 3;
-    const long total = (long)a.M * OC;
+    __shared__ float cst[6][256];                             // mean, invstd, gamma, beta, mean(dyh), mean(dyh * xhat) per logical channel
     const double invM = 1.0 / (double)a.M;
-    const long stride = ((long)gridDim.x * 256 + OC - 1) / OC * OC;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= stride) return;
-    const int oc = (int)(i % OC), p0 = oc * 8;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < ACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+        cst[0][c] = a.mean[c]; cst[1][c] = a.invstd[c]; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+        cst[4][c] = (float)(s0 * invM); cst[5][c] = (float)(s1 * invM);
+        if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+    }
+    __syncthreads();
+    const int OL = a.lanes, rowsPer = 256 / OL;
+    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
+    const int OC = a.Cp >> 3;
+    if (ol >= OC) return;
+    const int p0 = ol * 8;
     int lc[8];
     float mu[8], is[8], ga[8], be[8], kk[8], m0[8], m1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
-        mu[j] = is[j] = ga[j] = be[j] = kk[j] = m0[j] = m1[j] = 0.0f;
-        if (lc[j] >= 0) {
-            const int c = lc[j];
-            mu[j] = a.mean[c]; is[j] = a.invstd[c]; ga[j] = a.gamma[c]; be[j] = a.beta[c]; kk[j] = ga[j] * is[j];
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int sl = 0; sl < ACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
-            m0[j] = (float)(s0 * invM); m1[j] = (float)(s1 * invM);
-            if (i < OC) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
-        }
+        const int c = lc[j] >= 0 ? lc[j] : 0;
+        mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c]; kk[j] = ga[j] * is[j]; m0[j] = cst[4][c]; m1[j] = cst[5][c];
     }
-    for (; i < total; i += stride) {
-        const long m = i / OC;
-        const h16x8 v = ldh8(a.y + (size_t)m * a.y_ld + a.y_off + p0);
-        float g[8];
-        load_dz8(a, (size_t)m, p0, g);
+    auto emit = [&](long m, h16x8 v, const float (&g)[8]) {
         h16x8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -704,6 +759,24 @@ __global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restric
             r[j] = lc[j] >= 0 ? (h16)(kk[j] * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
         }
         sth8(dy + (size_t)m * a.Cp + p0, r);
+    };
+    constexpr int U = 4;
+    const long step = (long)gridDim.x * rowsPer;
+    long r = (long)blockIdx.x * rowsPer + rl;
+    for (; r + (U - 1) * step < a.M; r += U * step) {
+        h16x8 v[U];
+        float g[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ldh8(a.y + (size_t)(r + u * step) * a.y_ld + a.y_off + p0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_dz8(a, (size_t)(r + u * step), p0, g[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) emit(r + u * step, v[u], g[u]);
+    }
+    for (; r < a.M; r += step) {
+        float g[8];
+        load_dz8(a, (size_t)r, p0, g);
+        emit(r, ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0), g);
     }
 }
 
@@ -712,11 +785,7 @@ void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hi
     launch_hcol_reduce(a0, 2, s);
     HRedArgs a = a0;
     a.lanes = hlanes_for(a.Cp);
-    const long total = (long)a.M * (a.Cp >> 3);
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, dy, dgamma, dbeta);
+    hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a, dy, dgamma, dbeta);
 }
 
 // =================================================================================================
@@ -741,32 +810,44 @@ __global__ __launch_bounds__(256) void hdw_wgrad_kernel(const h16* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.0f;
     if (live) {
-        const long npix = (long)B * Ho * Wo;
+        // a row-lane walks RUNS of R output pixels along an image row: the 3 x NCOL input window of a run is loaded once (18 / 27
+        // 16-byte loads for stride 1 / 2 instead of 9 per pixel), all loads of a run are issued before any FMA
+        constexpr int R = 4, NCOL = STRIDE == 1 ? R + 2 : 2 * R + 1;
+        const int runsPerRow = (Wo + R - 1) / R;
+        const long nruns = (long)B * Ho * runsPerRow;
         const long lanes_total = (long)gridDim.x * rowsPer;
-        const long per = (npix + lanes_total - 1) / lanes_total;
+        const long per = (nruns + lanes_total - 1) / lanes_total;
         const long begin = ((long)xcd_block(blockIdx.x, gridDim.x) * rowsPer + rl) * per;
-        const long end = begin + per < npix ? begin + per : npix;
-        for (long p = begin; p < end; ++p) {
-            const int ox = (int)(p % Wo); const long q = p / Wo;
-            const int oy = (int)(q % Ho), b = (int)(q / Ho);
-            const h16x8 g = ldh8(dy + (size_t)p * dy_ld + c0);
-            h16x8 v[9];
+        const long end = begin + per < nruns ? begin + per : nruns;
+        for (long u = begin; u < end; ++u) {
+            const int seg = (int)(u % runsPerRow); const long row = u / runsPerRow;
+            const int oy = (int)(row % Ho), b = (int)(row / Ho);
+            const int ox0 = seg * R;
+            h16x8 col[3][NCOL], g[R];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * STRIDE - 1 + ky;
                 const bool yok = iy >= 0 && iy < H;
+                const h16* xr = x + ((size_t)(b * H + (yok ? iy : 0)) * W) * x_ld + x_off + c0;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * STRIDE - 1 + kx;
-                    const bool ok = yok && ix >= 0 && ix < W;
-                    const size_t src = ((size_t)(b * H + (yok ? iy : 0)) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)));
-                    v[ky * 3 + kx] = keep8(ldh8(x + src * x_ld + x_off + c0), ok);
+                for (int j = 0; j < NCOL; ++j) {
+                    const int ix = ox0 * STRIDE - 1 + j;
+                    col[ky][j] = keep8(ldh8(xr + (size_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * x_ld), yok && ix >= 0 && ix < W);
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
+            for (int o = 0; o < R; ++o) {
+                const int ox = ox0 + o;
+                g[o] = keep8(ldh8(dy + ((size_t)row * Wo + (ox < Wo ? ox : Wo - 1)) * dy_ld + c0), ox < Wo);
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[k][j] += (float)g[j] * (float)v[k][j];
+            for (int o = 0; o < R; ++o)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += (float)g[o][j] * (float)col[ky][o * STRIDE + kx][j];
         }
     }
     // combine the row-lanes, one channel of the octet at a time (9 floats per thread per round)
@@ -795,8 +876,8 @@ void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_of
 {
     const int OL = hlanes_for(Cp);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const long npix = (long)B * Ho * Wo;
-    long G = (npix + (256 / OL) * 16 - 1) / ((256 / OL) * 16);
+    const long npix = (long)B * Ho * ((Wo + 3) / 4);                    // runs of 4 output pixels
+    long G = (npix + (256 / OL) * 8 - 1) / ((256 / OL) * 8);
     static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 512;
     if (G > gmax) G = gmax;
     if (G < 1) G = 1;
@@ -871,15 +952,25 @@ __global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict_
         const long per = (npix + lanes_total - 1) / lanes_total;
         const long begin = ((long)blockIdx.x * 2 + rl) * per;
         const long end = begin + per < npix ? begin + per : npix;
-        for (long p = begin; p < end; ++p) {
-            const int ox = (int)(p % Wo); const long q = p / Wo;
-            const int oy = (int)(q % Ho), b = (int)(q / Ho);
-            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float xv = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
-            const h16x8 g = ldh8(dy + (size_t)p * 24 + oc * 8);
+        for (long p = begin; p < end; p += 4) {
+            float xv[4]; h16x8 g[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv, (float)g[j], acc[j]);
+            for (int u = 0; u < 4; ++u) {                                // four output pixels' operands requested before any FMA
+                const long pp = p + u < end ? p + u : p;
+                const int ox = (int)(pp % Wo); const long q = pp / Wo;
+                const int oy = (int)(q % Ho), b = (int)(q / Ho);
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                const bool ok = p + u < end && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float v = x[(((size_t)b * 3 + ci) * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix))];
+                unsigned mk = ok ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(mk));
+                xv[u] = __uint_as_float(__float_as_uint(v) & mk);
+                g[u] = ldh8(dy + (size_t)pp * 24 + oc * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv[u], (float)g[u][j], acc[j]);
         }
     }
 #pragma unroll
@@ -896,7 +987,7 @@ void launch_hstem_wgrad(const h16* dy, const float* x, int B, int H, int W, floa
 {
     const long npix = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
     long G = (npix + 255) / 256;
-    static const int gmax = getenv("YN_STEM_G") ? atoi(getenv("YN_STEM_G")) : 1024;
+    static const int gmax = getenv("YN_STEM_G") ? atoi(getenv("YN_STEM_G")) : 2048;
     if (G > gmax) G = gmax;
     if (G < 1) G = 1;
     hipLaunchKernelGGL(hstem_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, s, dy, x, B, H, W, dw_slots, slot_stride);
@@ -1101,6 +1192,40 @@ __global__ __launch_bounds__(256) void hpack_stem_kernel(const float* __restrict
     if (i >= 24 * 27) return;
     const int co = i / 27, r = i - co * 27;
     out[(size_t)r * 24 + co] = w[i];
+}
+
+// every layer's packs in ONE launch (blockIdx.y = layer): the per-layer kernels above cost ~5 us of launch latency each, 150 per step
+__global__ __launch_bounds__(256) void hpack_all_kernel(const HPackDesc* __restrict__ table)
+{
+    const HPackDesc d = table[blockIdx.y];
+    const float* __restrict__ w = d.w;
+    if (d.kind == 0) {
+        const long total = (long)d.Cout * d.Cin * d.taps;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int n = (int)(i / ((long)d.Cin * d.taps));
+            const int rem = (int)(i - (long)n * d.Cin * d.taps);
+            const int ci = rem / d.taps, tap = rem - ci * d.taps;
+            const int cp = ci + (ci >= d.half ? d.gap : 0);
+            const h16 v = (h16)w[i];
+            d.wf[(((size_t)tap * (d.Kp >> 3) + (cp >> 3)) * d.Npad + n) * 8 + (cp & 7)] = v;
+            d.wb[(((size_t)(d.taps - 1 - tap) * (d.Kpb >> 3) + (n >> 3)) * d.Npadb + cp) * 8 + (n & 7)] = v;
+        }
+        if (d.b) for (int i = blockIdx.x * 256 + threadIdx.x; i < d.Cout; i += gridDim.x * 256) d.bias[i] = d.b[i];
+    } else if (d.kind == 1) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < d.Cout * 9; i += gridDim.x * 256) {
+            const int c = i / 9, tap = i - c * 9;
+            const int cp = c + (c >= d.half ? d.gap : 0);
+            d.dwf[(size_t)tap * d.Kp + cp] = w[i];
+            if (d.dwb) d.dwb[(size_t)(8 - tap) * d.Kp + cp] = w[i];
+        }
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < d.Cout; i += gridDim.x * 256) d.bias[i + (i >= d.half ? d.gap : 0)] = d.b ? d.b[i] : 0.0f;
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < 24 * 27; i += gridDim.x * 256) { const int co = i / 27, r = i - co * 27; d.dwf[(size_t)r * 24 + co] = w[i]; }
+    }
+}
+void launch_hpack_all(const HPackDesc* table_dev, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(hpack_all_kernel, dim3(16, (unsigned)n), dim3(256), 0, s, table_dev);
 }
 
 void launch_hpack_gemm(const float* w, int Cout, int Cin, int taps, int in_half, int in_gap, int Kp, int Npad, int backward, h16* out, hipStream_t s)

@@ -107,6 +107,9 @@ struct yn_handle {
     int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
     int train_dtype = 0;                  // 0 fp32, 1 fp16 storage + f16 MFMA (yn_train_precision)
     std::vector<HPack> hpacks;
+    std::vector<ynk::HPackDesc> hpack_jobs;   // recorded while the first fp16 step packs layer by layer; later steps pack everything in one launch
+    ynk::HPackDesc* hpack_table = nullptr;     // device copy
+    int hpack_table_n = 0;
     float* scale_state = nullptr;         // device float[4]: loss scale, its inverse, clean-step counter, overflow flag (kernels_h16.hip)
     std::vector<hipEvent_t> train_events;
     char* train_arena = nullptr;
@@ -823,6 +826,7 @@ void yn_destroy(yn_handle* h)
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
+    if (h->hpack_table) (void)hipFree(h->hpack_table);
     for (HPack& pk : h->hpacks) { void* q[] = {pk.wf, pk.wb, pk.bias, pk.dwf, pk.dwb}; for (void* v : q) if (v) (void)hipFree(v); }
     for (hipEvent_t e : h->train_events) (void)hipEventDestroy(e);
     if (h->train_arena) (void)hipFree(h->train_arena);

@@ -57,6 +57,7 @@ struct HBnApplyArgs {
     float* rmean; float* rvar; float momentum;
     h16* out; int out_ld, out_off;
     const h16* pass; int pass_ld, pass_off; int out_half, out_gap;      // shuffle mode
+    int lanes;                                  // filled by the launcher
 };
 void launch_hbn_apply(const HBnApplyArgs& a, hipStream_t s);
 
@@ -70,6 +71,13 @@ void launch_hgather(const h16* src, int src_ld, int src_off, int src_cs, int src
 void launch_hpack_gemm(const float* w, int Cout, int Cin, int taps, int in_half, int in_gap, int Kp, int Npad, int backward, h16* out, hipStream_t s);
 void launch_hpack_dw(const float* w, const float* bias, int C, int half, int gap, int Cp, int flip, float* out, float* bias_out, hipStream_t s);
 void launch_hpack_stem(const float* w, float* out, hipStream_t s);
+// one layer's packing job for hpack_all_kernel: kind 0 GEMM-shaped (fwd + bwd packs, bias), 1 depthwise (Kp = physical channels), 2 stem
+struct HPackDesc {
+    const float* w; const float* b;
+    int kind, Cout, Cin, taps, half, gap, Kp, Npad, Kpb, Npadb;
+    h16* wf; h16* wb; float* bias; float* dwf; float* dwb;
+};
+void launch_hpack_all(const HPackDesc* table_dev, int n, hipStream_t s);
 void launch_hstage(const float* src, int C, h16* dst, int ld, int half, int gap, long M, hipStream_t s);
 void launch_hunstage(const h16* src, int ld, int half, int gap, float* dst, int C, long M, hipStream_t s);
 void launch_rows_to_f32(const void* src, int is_h16, int src_ld, float* dst, int n, long M, hipStream_t s);
