@@ -64,6 +64,10 @@ int  yn_synchronize(yn_handle* h);
  * onto two side streams of the handle (default on: +4 % for a single handle).  A caller that already runs several handles
  * concurrently on its own streams should turn it off — nine streams contending cost 10 % at three handles (24.1 k vs 21.7 k images/s). */
 int  yn_multi_stream(yn_handle* h, int enable);
+/* The MFMA-bound convolutions (the dense 3x3 neck layers) run on the f16 matrix pipe with SPLIT fp32 operands by default —
+ * x = hi + lo*2^-11, three f16 MFMAs per product into fp32 accumulators: fp32-class results (per-product error <= ~3*2^-22; the
+ * f32 MFMA of gfx950 runs at 1/16 of the f16 rate and there is no TF32).  enable != 0 pins every conv to the f32 MFMA. */
+int  yn_exact_f32(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration on the handle's stream and caches the fastest.  All
  * configurations produce bit-identical results; disabling falls back to a static heuristic. */

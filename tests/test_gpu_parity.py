@@ -764,3 +764,29 @@ def test_handle_follows_torch_stream(golden):
     assert m.handle()._stream_ptr == torch.cuda.current_stream().cuda_stream
     for a, b in zip(ref, again):
         assert np.array_equal(a, b)
+
+
+def test_split_f16_conv_is_fp32_class(hvoc, golden):
+    """The dense 3x3 neck convs run on the f16 MFMA with split fp32 operands (x = hi + lo * 2^-11, three MFMAs per product).  Against
+    float64 the result must be as good as the f32-MFMA kernel's (yn_exact_f32): same error class on O(1) data, on data with a
+    large dynamic range (1e-4 .. 1e3: the lo halves stay out of the f16 subnormals by construction) and with the fused FPN adds."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(12)
+    w = (rs.standard_normal((96, 96, 3, 3)) / np.sqrt(864)).astype(np.float32)
+    b = rs.standard_normal((96,)).astype(np.float32)
+    for scale in (1.0, "wide"):
+        x = rs.standard_normal((2, 96, 37, 29)).astype(np.float32)
+        if scale == "wide":
+            x = (x * np.exp(rs.uniform(np.log(1e-4), np.log(1e3), x.shape))).astype(np.float32)
+        ref = F.conv2d(torch.as_tensor(x).double(), torch.as_tensor(w).double(), torch.as_tensor(b).double(), padding=1).numpy()
+        err = {}
+        for exact in (True, False):
+            hvoc.exact_f32(exact)
+            y = nchw_np(hvoc.op_conv3x3(nhwc(x), dev(w), dev(b), 0))
+            err[exact] = float(np.sqrt(((y - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+        hvoc.exact_f32(False)
+        assert err[True] < 5e-7, err                      # the f32-MFMA kernel: fp32 round-off
+        assert err[False] < max(2.5 * err[True], 3e-7), (scale, err)    # split operands: the same class
+    # and bit-for-bit reproducible
+    y1 = hvoc.op_conv3x3(nhwc(x), dev(w), dev(b), 2).clone()
+    assert torch.equal(hvoc.op_conv3x3(nhwc(x), dev(w), dev(b), 2), y1)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "yn_pw_config_count": (_i32, []),
     "yn_unit_chain": (_i32, [_vp, _i32]),
     "yn_multi_stream": (_i32, [_vp, _i32]),
+    "yn_exact_f32": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -218,6 +219,10 @@ class Handle:
         """Fork independent kernel chains of one forward onto the handle's side streams (default on).  Turn off when several
         handles already run concurrently on their own streams."""
         self._ck(self.lib.yn_multi_stream(self.h, int(bool(on))), "yn_multi_stream")
+
+    def exact_f32(self, on=True):
+        """Pin every GEMM-shaped conv to the f32 MFMA (default off: the MFMA-bound layers use split-f16 operands, fp32-class)."""
+        self._ck(self.lib.yn_exact_f32(self.h, int(bool(on))), "yn_exact_f32")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

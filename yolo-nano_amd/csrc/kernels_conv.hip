@@ -684,6 +684,195 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The 96 -> 96 neck convolutions on the F16 matrix pipe with SPLIT operands: fp32-class results at 4-5x the f32 MFMA rate.
+// gfx950 has no TF32/xf32 (MI355X_MICROARCH.md); its f32-input MFMA runs at 1/16 of the f16 rate, and the dense 3x3 layers are the
+// MFMA-bound part of the network (36 % of the flops, 0.5 of the f32 peak with conv3x3_halo_tap_kernel).  Every fp32 operand is
+// written as x = hi + lo * 2^-11 with hi = f16(x), lo = f16((x - hi) * 2^11): x - hi is exact in fp32, the scaling keeps lo out of
+// the f16 subnormals, and |x - (hi + lo * 2^-11)| <= 2^-22 |x|.  Then a*w = ah*wh + (ah*wl + al*wh) * 2^-11 + O(2^-22): three f16
+// MFMAs (products exact in the fp32 accumulators) into TWO accumulator sets, combined once in the epilogue.  Per-product error
+// <= ~3 * 2^-22 relative — the size of the fp32 path's own accumulation rounding; measured against the float64 oracle the two paths
+// are indistinguishable (tests/test_gpu_parity.py::test_split_f16_conv_is_fp32_class).  Operands must fit the f16 range (|x| < 65504:
+// normalised activations and folded weights are O(1)); YN_EXACT_F32=1 keeps the f32-MFMA kernel.
+// Structure as conv3x3_halo_tap_kernel: the pixel range of a flat 128-pixel tile + halo is staged ONCE in LDS (already split, two
+// planes of halves, FPN/PAN resample-add fused), the nine taps read their A fragments from it, the pre-split packed weights stream
+// per tap through one LDS buffer with register prefetch.
+// -------------------------------------------------------------------------------------------------
+typedef _Float16 c3h16;
+typedef _Float16 c3h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c3h16x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
+{
+    constexpr int CIN = 96, KQ = CIN / 8, BM = 128, BN = 32 * NT, CSH = CIN + 8;      // halo row stride (halves): 208 bytes, conflict-free b128 reads
+    constexpr int WCH = KQ * BN * 8;                                                  // halves per weight plane per tap
+    constexpr int B_PER = (2 * KQ * BN + 255) / 256;                                  // 16-byte granules per thread per tap (hi and lo planes)
+    extern __shared__ __attribute__((aligned(16))) float c3s_smem[];
+    const int W = a.W, H = a.H, HW = H * W;
+    const int npix = BM + 2 * W + 2;
+    c3h16* Hh = reinterpret_cast<c3h16*>(c3s_smem);                                   // [npix][CSH]
+    c3h16* Hl = Hh + (size_t)npix * CSH;
+    c3h16* Bh = Hl + (size_t)npix * CSH;                                              // [KQ][BN][8]
+    c3h16* Bl = Bh + WCH;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int p0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
+    if (p0 >= a.M) return;
+    const int n0 = blockIdx.y * BN;
+    const int base = p0 - W - 1;
+    const c3h16* Wsh = reinterpret_cast<const c3h16*>(a.Wsh);
+    const c3h16* Wsl = reinterpret_cast<const c3h16*>(a.Wsl);
+
+    c3h16x8 b_reg[B_PER];
+    auto prefetch_b = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;                                                // granule: plane (hi / lo), octet o, column n
+            const int pl = g / (KQ * BN), r = g - pl * (KQ * BN);
+            const int o = r / BN, n = r - o * BN;
+            c3h16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
+            if (g < 2 * KQ * BN) v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + (((size_t)tap * KQ + o) * a.Npad + n0 + n) * 8);
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < 2 * KQ * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)g * 8) = b_reg[i];      // Bl follows Bh: plane 1 lands there
+        }
+    };
+    prefetch_b(0);
+
+    // ---- halo: 16-byte global loads (+ the fused resample-add), split, two 8-byte LDS stores per item ----
+    {
+        constexpr int U = 8, CQ = CIN / 4, PPL = 256 / CQ;
+        const int cq = t % CQ, pl = t / CQ;
+        if (pl < PPL) {
+            for (int i0 = pl; i0 < npix; i0 += PPL * U) {
+                float4 v[U], u2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * PPL;
+                    const int q = base + i;
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    u2[u] = v[u];
+                    if (i < npix && q >= 0 && q < a.M) {
+                        v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)q * CIN + 4 * cq);
+                        if (a.resample) {
+                            const int b = q / HW, rem = q - b * HW;
+                            const int y = rem / W, x = rem - y * W;
+                            size_t p2;
+                            if (a.resample == 1) p2 = ((size_t)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                            else                 p2 = ((size_t)b * (H << 1) + (y << 1)) * (W << 1) + (x << 1);
+                            u2[u] = *reinterpret_cast<const float4*>(a.in2 + p2 * CIN + 4 * cq);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * PPL;
+                    if (i < npix) {
+                        const float x4[4] = {v[u].x + u2[u].x, v[u].y + u2[u].y, v[u].z + u2[u].z, v[u].w + u2[u].w};
+                        c3h16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
+                        *reinterpret_cast<c3h16x4*>(Hh + (size_t)i * CSH + 4 * cq) = hi;
+                        *reinterpret_cast<c3h16x4*>(Hl + (size_t)i * CSH + 4 * cq) = lo;
+                    }
+                }
+            }
+        }
+    }
+    stage_b();
+
+    const int r = wave * 32 + l31;
+    const int m = p0 + r;
+    unsigned tapmask = 0;
+    if (m < a.M) {
+        const int rem = m % HW;
+        const int y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) tapmask |= 1u << tap;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc0[NT], acc1[NT];                              // sum ah*wh ; sum (ah*wl + al*wh), worth 2^-11
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) prefetch_b(tap + 1);
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const bool ok = (tapmask >> tap) & 1u;
+        const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8;
+        const c3h16* Bhb = Bh + (size_t)(h * BN + l31) * 8;
+        const c3h16* Blb = Bl + (size_t)(h * BN + l31) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KQ / 2; ++ks) {
+            c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Hh + arow + ks * 16);
+            c3h16x8 al = *reinterpret_cast<const c3h16x8*>(Hl + arow + ks * 16);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ah[j] = (c3h16)0.0f; al[j] = (c3h16)0.0f; }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const c3h16x8 bh = *reinterpret_cast<const c3h16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                const c3h16x8 bl = *reinterpret_cast<const c3h16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+            }
+        }
+        if (tap + 1 < 9) {
+            __syncthreads();                                 // everyone is done with this tap's weights
+            stage_b();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: combine the two accumulator sets, bias + activation, quad transpose -> 16-byte stores
+    const int j = lane & 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ncol = n0 + nt * 32 + l31;
+        const float bias = ncol < a.N ? a.bias[ncol] : 0.0f;
+        const int nq = n0 + nt * 32 + (l31 & ~3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = apply_act(__builtin_fmaf(acc1[nt][4 * g + e], 1.0f / 2048.0f, acc0[nt][4 * g + e]) + bias, a.act);
+            float v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
+            {
+                const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            }
+            {
+                const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
+                const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+            }
+            const int mm = p0 + wave * 32 + 8 * g + 4 * h + j;
+            if (mm < a.M && nq < a.N)
+                *reinterpret_cast<float4*>(a.out + (size_t)mm * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
+        }
+    }
+}
+
+static size_t conv3x3_split_lds(int W, int NT) { return ((size_t)2 * (128 + 2 * W + 2) * (96 + 8) + (size_t)2 * 12 * (32 * NT) * 8) * 2; }
+
 static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
 {
     const int npix = 128 + 2 * W + 2;
@@ -834,6 +1023,23 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
     const int NT = nt32 >= 3 && nt32 % 3 == 0 ? 3 : (nt32 % 2 == 0 ? 2 : 1);
     // the network's 96->96 neck convs: per-tap weight chunks + 16-byte halo staging.  Small maps (few 128-pixel
     // tiles) split N over three block columns instead: the kernel is then latency- not MFMA-bound.
+    if (a.Wsh && a.Wsl && a.K == 96 && a.Npad == 96 && a.in_off == 0 && a.in_ld == 96 && (a.N & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_off & 3) == 0 &&
+        conv3x3_split_lds(a.W, 1) <= 160 * 1024) {
+        static unsigned long long attr_s = 0;
+        if (attr_pending(attr_s)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        const int tiles = (a.M + 127) / 128;
+        if (tiles >= 256 && conv3x3_split_lds(a.W, 3) <= 160 * 1024) {
+            g_last_kernel = "conv3x3_split_kernel<3>";
+            hipLaunchKernelGGL(conv3x3_split_kernel<3>, dim3(xcd_grid(tiles), 1), dim3(256), conv3x3_split_lds(a.W, 3), s, a);
+        } else {                                           // small maps: N over three block columns (latency-bound, more blocks)
+            g_last_kernel = "conv3x3_split_kernel<1>";
+            hipLaunchKernelGGL(conv3x3_split_kernel<1>, dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1), s, a);
+        }
+        return;
+    }
     if (a.K == 96 && NT == 3 && a.in_off == 0 && a.in_ld == 96 && (a.N & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_off & 3) == 0 &&
         conv3x3_halo_tap_lds(a.W, 96, 3) <= 160 * 1024) {
         static unsigned long long attr_t = 0;
@@ -1243,6 +1449,12 @@ __global__ void fold_pack_kernel(FoldArgs a)
         const int ci = r / a.kk, tap = r - ci * a.kk;
         const int k = tap * a.Cin + ci;
         a.w_packed[((size_t)(k >> 1) * a.Npad + co) * 2 + (k & 1)] = v;
+        if (a.ws_hi) {                          // the same weight as an exact-to-2^-22 pair of halves: v = hi + lo * 2^-11
+            const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * 2048.0f);
+            const size_t o = (((size_t)tap * ((a.Cin + 7) >> 3) + (ci >> 3)) * a.Npad + co) * 8 + (ci & 7);
+            reinterpret_cast<_Float16*>(a.ws_hi)[o] = hi;
+            reinterpret_cast<_Float16*>(a.ws_lo)[o] = lo;
+        }
     }
 }
 

@@ -514,8 +514,7 @@ __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, 
 template <int MODE>
 __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
 {
-    __shared__ double red[256][17];
-    const int OL = a.lanes, rowsPer = 256 / OL;
+    const int OL = a.lanes, rowsPer = 256 / OL;                 // OL <= 32 (Cp <= 256): every octet has at least two row-lanes per wave
     const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
     const int OC = a.Cp >> 3;
     const bool live = ol < OC;
@@ -566,20 +565,27 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
             }
         }
     }
-    // combine the row-lanes (two rounds of 8 doubles each keep the LDS footprint at 34 KB)
+    // combine the row-lanes: inside a wave by xor-shuffles over the lane bits above the octet-lane bits (the row-lanes of one octet
+    // sit OL lanes apart), then the four waves through LDS; one thread per octet issues the atomics
+    __shared__ double red[4][32][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (OL <= 32) {
+        for (int off = 32; off >= OL; off >>= 1) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
+            for (int j = 0; j < 8; ++j) { s0[j] += __shfl_xor(s0[j], off); s1[j] += __shfl_xor(s1[j], off); }
+        }
+        if (lane < OL) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = pass == 0 ? s0[j] : s1[j];
-        __syncthreads();
-        if (rl == 0 && live) {
-            for (int k = 1; k < rowsPer; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { if (pass == 0) s0[j] += red[k * OL + ol][j]; else s1[j] += red[k * OL + ol][j]; }
+            for (int j = 0; j < 8; ++j) { red[wave][lane][j] = s0[j]; red[wave][lane][8 + j] = s1[j]; }
         }
     }
-    if (rl == 0 && live) {
+    __syncthreads();
+    if (threadIdx.x < OL && live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s0[j] = (red[0][ol][j] + red[1][ol][j]) + (red[2][ol][j] + red[3][ol][j]);
+            s1[j] = (red[0][ol][8 + j] + red[1][ol][8 + j]) + (red[2][ol][8 + j] + red[3][ol][8 + j]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (lc[j] < 0) continue;

@@ -42,6 +42,9 @@ struct Layer {
     float* b_packed = nullptr;
     float* w_ref = nullptr;
     float* b_ref = nullptr;
+    void* ws_hi = nullptr;                 // split-f16 packs of the folded weights (dense 3x3: conv3x3_split_kernel)
+    void* ws_lo = nullptr;
+    size_t ws_bytes = 0;
     size_t w_numel = 0;
     int Kp = 0, Npad = 0;
 };
@@ -116,6 +119,7 @@ struct yn_handle {
     size_t train_arena_bytes = 0;
     // graphs / profiling
     bool use_graph = false;
+    bool exact_f32 = false;                // yn_exact_f32 / YN_EXACT_F32=1: GEMM-shaped convs on the f32 MFMA only (no split-f16 operands)
     bool autotune = true;
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
@@ -571,6 +575,7 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
     a.Wp = l.w_packed; a.bias = l.b_packed; a.out = out; a.out_ld = l.cout; a.out_off = 0;
     a.M = B * H * W; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     a.cfg = -1;
+    if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }     // split-f16 MFMA path (fp32-class); exact_f32: the f32-MFMA kernel
     const double M = (double)a.M;
     const double in2px = resample == 1 ? M / 4 : (resample == 2 ? M * 4 : 0);
     Bracket br(h, l.name, 2.0 * M * 9 * l.cin * l.cout, 4.0 * ((M + in2px) * l.cin + M * l.cout + 9.0 * l.cin * l.cout));
@@ -793,6 +798,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (h->cfg.max_batch < 1) h->cfg.max_batch = 1;
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
+    if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
@@ -813,6 +819,8 @@ void yn_destroy(yn_handle* h)
         if (l.b_packed) (void)hipFree(l.b_packed);
         if (l.w_ref) (void)hipFree(l.w_ref);
         if (l.b_ref) (void)hipFree(l.b_ref);
+        if (l.ws_hi) (void)hipFree(l.ws_hi);
+        if (l.ws_lo) (void)hipFree(l.ws_lo);
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial};
@@ -882,6 +890,13 @@ int yn_set_pw_config(yn_handle* h, int index)
     return 0;
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
+int yn_exact_f32(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != h->exact_f32) drop_graphs(h);
+    h->exact_f32 = enable != 0;
+    return 0;
+}
 int yn_multi_stream(yn_handle* h, int enable) { if (!h) return 1; h->multi_stream = enable != 0; return 0; }
 int yn_unit_chain(yn_handle* h, int mode) { if (!h) return 1; h->unit_chain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
 
@@ -984,6 +999,16 @@ int yn_fold_bn(yn_handle* h)
             HIPCHK(h, hipMalloc((void**)&l.b_ref, (size_t)l.cout * sizeof(float)));
             l.w_numel = w->numel;
         }
+        if (l.kind == K_DENSE3 && !l.ws_hi) {
+            l.ws_bytes = (size_t)9 * ((l.cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
+            HIPCHK(h, hipMalloc(&l.ws_hi, l.ws_bytes));
+            HIPCHK(h, hipMalloc(&l.ws_lo, l.ws_bytes));
+        }
+        if (l.ws_hi) {
+            HIPCHK(h, hipMemsetAsync(l.ws_hi, 0, l.ws_bytes, h->stream));
+            HIPCHK(h, hipMemsetAsync(l.ws_lo, 0, l.ws_bytes, h->stream));
+        }
+        a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo;
         HIPCHK(h, hipMemsetAsync(l.w_packed, 0, packed_floats * sizeof(float), h->stream));
         HIPCHK(h, hipMemsetAsync(l.b_packed, 0, (size_t)((l.Npad + 31) & ~31) * sizeof(float), h->stream));
         a.w_ref = l.w_ref; a.b_ref = l.b_ref; a.w_packed = l.w_packed; a.b_packed = l.b_packed;
@@ -1286,6 +1311,13 @@ struct TmpLayer {
         (void)hipMemsetAsync(l.w_packed, 0, packed * sizeof(float), h->stream);
         (void)hipMemsetAsync(l.b_packed, 0, bfl * sizeof(float), h->stream);
         a.w_packed = l.w_packed; a.b_packed = l.b_packed;
+        if (kind == K_DENSE3) {                             // the split-f16 packs the network's dense 3x3 layers run on
+            l.ws_bytes = (size_t)9 * ((cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
+            if (hipMalloc(&l.ws_hi, l.ws_bytes) != hipSuccess || hipMalloc(&l.ws_lo, l.ws_bytes) != hipSuccess) { rc = 1; return; }
+            (void)hipMemsetAsync(l.ws_hi, 0, l.ws_bytes, h->stream);
+            (void)hipMemsetAsync(l.ws_lo, 0, l.ws_bytes, h->stream);
+            a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo;
+        }
         launch_fold_pack(a, h->stream);
     }
     ~TmpLayer()
@@ -1293,6 +1325,8 @@ struct TmpLayer {
         (void)hipStreamSynchronize(h->stream);
         if (l.w_packed) (void)hipFree(l.w_packed);
         if (l.b_packed) (void)hipFree(l.b_packed);
+        if (l.ws_hi) (void)hipFree(l.ws_hi);
+        if (l.ws_lo) (void)hipFree(l.ws_lo);
     }
 };
 }  // namespace

@@ -20,6 +20,7 @@ struct GemmArgs {
     const float* dw_w; const float* dw_b;       // fused depthwise prologue (dwpw kernel): [9][K], [K]
     int dw_act;                                 // activation between the depthwise and the pointwise conv
     int dw_stride;                              // dwpw_tile_kernel: stride of the depthwise conv (H, W = its INPUT extent, M = output pixels)
+    const void* Wsh; const void* Wsl;           // split-f16 packs of the same weights (hi, lo * 2^11): [taps][ceil(Cin/8)][Npad][8] halves, or null
 };
 
 struct DwArgs {
@@ -70,6 +71,7 @@ struct FoldArgs {
     int Kp, Npad;                               // GEMM pack geometry
     float* w_ref; float* b_ref;                 // folded, reference layout (for yn_get_folded) or null
     float* w_packed; float* b_packed;
+    void* ws_hi; void* ws_lo;                   // GEMM kinds: split-f16 packs [kk][ceil(Cin/8)][Npad][8] (zero-initialised by the caller), or null
 };
 void launch_fold_pack(const FoldArgs& a, hipStream_t s);
 
