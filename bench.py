@@ -27,6 +27,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
+PEAK_SPLIT_TFLOPS = 2500.0 / 3  # split-f16 kernels: three f16 MFMAs (2.5 PF dense) per fp32 product => 833 TFLOP/s of fp32-class work
 PMC_LAYERS_FILE = "r02_pmc_layers.json"
 
 
@@ -506,9 +507,12 @@ def main():
                 n = a["launches"]
                 avg_ms = a["ms"] / n
                 ai = a["flops"] / max(a["bytes"], 1.0)
-                bound = "mfma" if ai > ridge else "hbm"
+                split = "split" in kern                          # f16 MFMA with split fp32 operands: never MFMA-bound at these shapes
+                bound = "mfma" if (ai > ridge and not split) else "hbm"
+                if ai > PEAK_SPLIT_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    bound = "mfma"
                 if bound == "mfma":
-                    ach, peak, unit = a["flops"] / n / (avg_ms * 1e-3) / 1e12, PEAK_F32_TFLOPS, "TFLOP/s"
+                    ach, peak, unit = a["flops"] / n / (avg_ms * 1e-3) / 1e12, (PEAK_SPLIT_TFLOPS if split else PEAK_F32_TFLOPS), "TFLOP/s"
                 else:
                     ach, peak, unit = a["bytes"] / n / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
                 kernels.append({"kernel": kern, "launches_per_step": n // args.profile_steps, "avg_us": round(avg_ms * 1e3, 2),
@@ -536,9 +540,14 @@ def main():
                     "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
                     "avg_us": d["avg_us"], "share_of_step": d["share"]}
             fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
+            fl_split = sum(a["flops"] for k, a in agg.items() if "split" in k) / args.profile_steps
             by = sum(a["bytes"] for a in agg.values()) / args.profile_steps
-            floor_ms = max(fl / (PEAK_F32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3
-            pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
+            # matrix-pipe time: the split-f16 kernels at 833 TFLOP/s of fp32-class work, everything else at the f32-MFMA peak
+            mfma_ms = ((fl - fl_split) / (PEAK_F32_TFLOPS * 1e12) + fl_split / (PEAK_SPLIT_TFLOPS * 1e12)) * 1e3
+            floor_ms = max(mfma_ms, by / (PEAK_HBM_GBS * 1e9) * 1e3)
+            pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_gflop_on_split_f16_kernels": round(fl_split / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
+                        "mfma_floor_ms": round(mfma_ms, 4), "hbm_floor_ms": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                        "f32_mfma_only_floor_ms": round(fl / (PEAK_F32_TFLOPS * 1e12) * 1e3, 4),
                         "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
 
         # ---- the second half of BASELINE's metric: p50 latency at bs=1 (rank 0, after the timed region; benchmark.py:62-75 protocol:

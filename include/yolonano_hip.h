@@ -69,13 +69,17 @@ int  yn_multi_stream(yn_handle* h, int enable);
  * f32 MFMA of gfx950 runs at 1/16 of the f16 rate and there is no TF32).  enable != 0 pins every conv to the f32 MFMA. */
 int  yn_exact_f32(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
- * shape times every instantiated tile configuration on the handle's stream and caches the fastest.  All
- * configurations produce bit-identical results; disabling falls back to a static heuristic. */
+ * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on
+ * the handle's stream and caches the fastest.  All configurations of a family produce bit-identical results; disabling falls back
+ * to a static heuristic. */
 int  yn_autotune(yn_handle* h, int enable);
 /* Testing aid: pin every pointwise GEMM of this handle to tile configuration `index` (0 <= index < yn_pw_config_count();
  * a configuration that does not cover a layer's strides falls back to the heuristic one); index < 0 restores the autotuner. */
 int  yn_set_pw_config(yn_handle* h, int index);
 int  yn_pw_config_count(void);
+/* Configurations [0, yn_pw_f32_config_count()) are the f32-MFMA family (LDS-tiled, then register-direct), the rest the split-f16
+ * family (gemm_split_kernel); results are bit-identical INSIDE a family. */
+int  yn_pw_f32_config_count(void);
 /* The stride-1 ShuffleV2 units run as one kernel each (depthwise -> pw2 -> concat+shuffle -> next unit's pw1).  mode 1
  * (default): on the stages whose map is large enough for that to pay; 0: three kernels per unit everywhere; 2: one kernel per
  * unit everywhere.  All three give bit-identical results (A/B measurements, tests). */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "yn_autotune": (_i32, [_vp, _i32]),
     "yn_set_pw_config": (_i32, [_vp, _i32]),
     "yn_pw_config_count": (_i32, []),
+    "yn_pw_f32_config_count": (_i32, []),
     "yn_unit_chain": (_i32, [_vp, _i32]),
     "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_exact_f32": (_i32, [_vp, _i32]),
@@ -226,6 +227,14 @@ class Handle:
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())
+
+    def pw_f32_config_count(self):
+        return int(self.lib.yn_pw_f32_config_count())
+
+    def pw_families(self):
+        """The two families of pointwise tile configurations: indices of the f32-MFMA one, indices of the split-f16 one."""
+        n, nf = self.pw_config_count(), self.pw_f32_config_count()
+        return list(range(nf)), list(range(nf, n))
 
     def synchronize(self):
         self._ck(self.lib.yn_synchronize(self.h), "yn_synchronize")

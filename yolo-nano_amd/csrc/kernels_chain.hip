@@ -1,5 +1,4 @@
-// kernels_chain.hip — multi-layer tile kernels: unit_chain_kernel (one launch per stride-1 ShuffleV2 unit, cut at the
-// depthwise conv) and dwpw_tile_kernel (a depthwise conv fused into its pointwise consumer through an LDS tile).
+// kernels_chain.hip — multi-layer tile kernel: unit_chain_kernel (one launch per stride-1 ShuffleV2 unit, cut at the depthwise conv).
 #include "yn_internal.h"
 #include "yn_device.h"
 
@@ -361,200 +360,5 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
 }
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
 bool unit_chain_covers(const ChainArgs& a) { return unit_chain_dispatch(a, nullptr, true); }
-
-// -------------------------------------------------------------------------------------------------
-// Depthwise 3x3 (stride 1 or 2) + the pointwise conv that consumes it, as one kernel: the first two phases of
-// unit_chain_kernel with the GEMM's ordinary epilogue (bias, activation, optional concat+shuffle with a pass-through
-// tensor).  Each depthwise output is computed ONCE from global memory into the LDS tile T [BM][K+2] (dwpw_halo_kernel, the
-// earlier attempt, recomputed it per MFMA fragment from an LDS halo and lost to two kernels); the depthwise activation never
-// reaches memory.  Used for branch1 / the tail of branch2 of the stride-2 ShuffleV2 units and for the heads' dw -> pw pairs.
-// Same fma chain and same k order as dwconv3x3_kernel + gemm_conv_kernel: bit-identical.
-// -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT, int V, int STRIDE>
-__global__ __launch_bounds__(256, 2) void dwpw_tile_kernel(GemmArgs a)
-{
-    typedef typename VecT<V>::type vec;
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KP = 16, BS = BN * 2, B_PER = KP * BN / 512;
-    static_assert(WM * WN == 4 && B_PER >= 1, "4 waves");
-    extern __shared__ __attribute__((aligned(16))) float dt_smem[];
-    const int K = a.K, CS = K + 2, W = a.W, H = a.H;
-    const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1, HWo = Ho * Wo;
-    float* T = dt_smem;                                      // [BM][CS]
-    float* Bs = dt_smem + ((BM * CS + 3) & ~3);              // [KP][BS]
-    float* Wd = Bs + KP * BS;                                // [10][K]
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = wave % WM, wn = wave / WM;
-    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
-    if (m0 >= a.M) return;
-    const int nchunks = (K + 2 * KP - 1) / (2 * KP), kp_total = K >> 1;
-
-    float4 b_reg[B_PER];
-    auto prefetch_b = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            const int kpg = c * KP + kp;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kpg < kp_total) v = *reinterpret_cast<const float4*>(a.Wp + ((size_t)kpg * a.Npad + c4 * 2) * 2);
-            b_reg[i] = v;
-        }
-    };
-    auto stage_b = [&]() {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int idx = t + 256 * i;
-            const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + kp * BS + c4 * 4) = b_reg[i];
-        }
-    };
-    prefetch_b(0);
-
-    // ---- depthwise conv of the block's BM output pixels -> T ---------------------------------------------------
-    {
-        const int cgn = K / V, ppl = 256 / cgn;
-        const int cg = t % cgn, pl = t / cgn, c = cg * V;
-        for (int i = t; i < 10 * K; i += 256) Wd[i] = i < 9 * K ? a.dw_w[i] : a.dw_b[i - 9 * K];
-        const bool worker = pl < ppl;
-        constexpr int U = 2;                                 // output pixels per batch of loads (18 loads in flight)
-        vec col[U][9];
-        auto issue = [&](int r0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * ppl;
-                const int m = m0 + r;
-                const bool live = r < BM && m < a.M;
-                const int mc = live ? m : m0;
-                const int b = mc / HWo, rem = mc - b * HWo;
-                const int oy = rem / Wo, ox = rem - oy * Wo;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = oy * STRIDE - 1 + ky;
-                    const bool yok = live && iy >= 0 && iy < H;
-                    const float* row = a.in + ((size_t)(b * H + (yok ? iy : 0)) * W) * a.in_ld + a.in_off + c;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = ox * STRIDE - 1 + kx;
-                        const unsigned mk = opaque_mask(yok && ix >= 0 && ix < W);
-                        col[u][ky * 3 + kx] = vmask(*reinterpret_cast<const vec*>(row + (size_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * a.in_ld), mk);
-                    }
-                }
-            }
-        };
-        auto finish = [&](int r0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * ppl;
-                if (r < BM) {
-                    vec acc = *reinterpret_cast<const vec*>(Wd + 9 * K + c);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) vfma(acc, col[u][k], *reinterpret_cast<const vec*>(Wd + k * K + c));
-                    acc = vact(acc, a.dw_act);
-                    float* d = T + r * CS + c;               // row stride CS*4 bytes is only 8-byte aligned
-                    if constexpr (V == 4) {
-                        *reinterpret_cast<float2*>(d) = make_float2(acc.x, acc.y);
-                        *reinterpret_cast<float2*>(d + 2) = make_float2(acc.z, acc.w);
-                    } else {
-                        *reinterpret_cast<float2*>(d) = acc;
-                    }
-                }
-            }
-        };
-        if (worker) issue(pl);
-        stage_b();
-        __syncthreads();                                     // Wd visible
-        if (worker) {
-            for (int r0 = pl; r0 < BM; r0 += ppl * U) {
-                finish(r0);
-                if (r0 + ppl * U < BM) issue(r0 + ppl * U);
-            }
-        }
-        for (int r = t; r < BM; r += 256) *reinterpret_cast<float2*>(T + r * CS + K) = make_float2(0.0f, 0.0f);   // pad columns (K tail)
-    }
-    __syncthreads();
-
-    // ---- pointwise GEMM from the LDS tile ------------------------------------------------------------------------
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[i][k] = 0.0f;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) prefetch_b(c + 1);
-        const int krem = K - c * 2 * KP;
-        const int nq = krem >= 2 * KP ? KP / 2 : ((krem + 3) >> 2);
-        const float* Ab = T + (wm * 32 + l31) * CS + c * 2 * KP + 2 * h;
-        const float* Bb = Bs + (wn * NT * 32 + l31) * 2 + h * BS;
-        float2 av = *reinterpret_cast<const float2*>(Ab);
-        float2 bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float2*>(Bb + nt * 64);
-#pragma unroll
-        for (int q = 0; q < KP / 2; ++q) {
-            if (q < nq) {                                   // wave-uniform
-                float2 av_n = av, bv_n[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[nt] = bv[nt];
-                if (q + 1 < nq) {
-                    av_n = *reinterpret_cast<const float2*>(Ab + 4 * (q + 1));
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv_n[nt] = *reinterpret_cast<const float2*>(Bb + 2 * (q + 1) * BS + nt * 64);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[nt], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                av = av_n;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bv_n[nt];
-            }
-        }
-        if (c + 1 < nchunks) {
-            __syncthreads();
-            stage_b();
-            __syncthreads();
-        }
-    }
-    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
-    gemm_epilogue<NT>(a, acc, m0 + wm * 32, wn * NT * 32, vecO, lane);
-}
-
-static size_t dwpw_tile_lds(int K, int BM, int BN) { return ((size_t)((BM * (K + 2) + 3) & ~3) + (size_t)16 * BN * 2 + 10 * (size_t)K) * sizeof(float); }
-
-// false when no instantiated tile covers the shape (Npad must be one block column)
-bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s)
-{
-    const int stride = a.dw_stride == 2 ? 2 : 1;
-    if ((a.K & 1) || a.K > 256) return false;
-    const bool v4 = (a.K & 3) == 0 && ((a.in_ld | a.in_off) & 3) == 0;
-    if (!v4 && ((a.in_ld | a.in_off) & 1)) return false;
-#define YN_DT(WMv, WNv, NTv, Vv, Sv)                                                                                   \
-    {                                                                                                                  \
-        constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
-        const size_t lds = dwpw_tile_lds(a.K, BM, BN);                                                                 \
-        static unsigned long long attr = 0;                                                                                      \
-        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } \
-        set_last_kernel_name("dwpw_tile_kernel<" #WMv "," #WNv "," #NTv "," #Vv "," #Sv ">");                               \
-        hipLaunchKernelGGL((dwpw_tile_kernel<WMv, WNv, NTv, Vv, Sv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
-        return true;                                                                                                   \
-    }
-    if (stride == 2) {
-        if (a.Npad == 64 && !v4) YN_DT(2, 2, 1, 2, 2)
-        if (a.Npad == 64 && v4) YN_DT(2, 2, 1, 4, 2)
-        if (a.Npad == 128 && v4) YN_DT(2, 2, 2, 4, 2)
-        if (a.Npad == 256 && v4) YN_DT(1, 4, 2, 4, 2)
-        if (a.Npad == 32 && v4) YN_DT(4, 1, 1, 4, 2)
-        if (a.Npad == 96 && v4) YN_DT(4, 1, 3, 4, 2)
-    } else {
-        if (a.Npad == 96 && v4) YN_DT(4, 1, 3, 4, 1)
-    }
-#undef YN_DT
-    return false;
-}
 
 }  // namespace ynk

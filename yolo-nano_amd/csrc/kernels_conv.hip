@@ -885,6 +885,140 @@ static size_t conv3x3_halo_lds(int W, int Cin, int NT)
     return ((size_t)((npix * (Cin + 2) + 3) & ~3) + 2 * 16 * (32 * NT * 2)) * sizeof(float);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolution on the f16 matrix pipe with split fp32 operands — the scheme of conv3x3_split_kernel (x = hi + lo*2^-11,
+// three f16 MFMAs per product into two fp32 accumulator sets) for the GEMMs of the network, whose f32-MFMA form spends as long in
+// its MFMA phase as in its memory phase (profiles/r01_sq_counters.md: 50 % issue-stalled on the matrix pipe).  Block = 4 waves as
+// WM x WN, 32 x (32*NT) per wave; K walks in chunks of 32: the fp32 A rows are loaded coalesced (16- or 8-byte accesses), split in
+// registers and staged as two planes of halves, the pre-split packed weights are copied straight; next chunk's global loads fly
+// during the MFMAs.  Epilogue = gemm_epilogue (bias, activation, concat+shuffle interleave, 16-byte stores).  Every configuration
+// runs the same MFMA sequence per k-chunk in the same chunk order: all split configurations are bit-identical to each other (not
+// to the f32-MFMA family, which rounds once per product-add; against float64 the split form is the more accurate of the two).
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a)
+{
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KC = 32, AST = KC + 8;
+    constexpr int A_PER = (BM * 4 + 255) / 256;             // (row, octet) granules per thread per chunk
+    constexpr int B_PER = (2 * 4 * BN + 255) / 256;         // 16-byte granules per thread per chunk (hi and lo planes)
+    __shared__ __attribute__((aligned(16))) c3h16 smem[2 * BM * AST + 2 * 4 * BN * 8];
+    c3h16* Ah = smem;
+    c3h16* Al = smem + BM * AST;
+    c3h16* Bh = smem + 2 * BM * AST;                        // [4][BN][8], then the lo plane
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const unsigned gy = (unsigned)(a.Npad + BN - 1) / BN, gx8 = gridDim.x / gy;     // XCD-aware decode (see gemm_conv_kernel)
+    const unsigned slot = blockIdx.x >> 3;
+    const int m0 = (int)((blockIdx.x & 7u) * (gx8 >> 3) + slot / gy) * BM;
+    const int n0 = (int)(slot % gy) * BN;
+    if (m0 >= a.M) return;
+    const int KQ = (a.K + 7) >> 3, nchunks = (a.K + KC - 1) / KC;
+    const bool vecA = ((a.K | a.in_ld | a.in_off) & 3) == 0;
+    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
+    const c3h16* Wsh = reinterpret_cast<const c3h16*>(a.Wsh);
+    const c3h16* Wsl = reinterpret_cast<const c3h16*>(a.Wsl);
+
+    float4 a_reg[A_PER][2];
+    c3h16x8 b_reg[B_PER];
+    auto prefetch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int g = t + 256 * i;
+            const int row = g >> 2, k = c * KC + (g & 3) * 8;
+            const int m = m0 + row;
+            const bool rok = g < BM * 4 && m < a.M;
+            const float* p = a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off;
+            if (vecA) {
+                const bool k0 = k < a.K, k1 = k + 4 < a.K;
+                a_reg[i][0] = vmask(*reinterpret_cast<const float4*>(p + (k0 ? k : 0)), opaque_mask(rok && k0));
+                a_reg[i][1] = vmask(*reinterpret_cast<const float4*>(p + (k1 ? k + 4 : 0)), opaque_mask(rok && k1));
+            } else {
+                float2 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool kj = k + 2 * j < a.K;
+                    v[j] = vmask(*reinterpret_cast<const float2*>(p + (kj ? k + 2 * j : 0)), opaque_mask(rok && kj));
+                }
+                a_reg[i][0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+                a_reg[i][1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;                      // plane, octet, column
+            const int pl = g / (4 * BN), r = g - pl * (4 * BN);
+            const int o = r / BN, n = r - o * BN;
+            const int kq = c * (KC / 8) + o;
+            const bool ok = g < 2 * 4 * BN && kq < KQ && n0 + n < a.Npad;
+            c3h16x8 v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n0 + n : 0)) * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < BM * 4) {
+                const float x8[8] = {a_reg[i][0].x, a_reg[i][0].y, a_reg[i][0].z, a_reg[i][0].w, a_reg[i][1].x, a_reg[i][1].y, a_reg[i][1].z, a_reg[i][1].w};
+                c3h16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hi[j] = (c3h16)x8[j]; lo[j] = (c3h16)((x8[j] - (float)hi[j]) * 2048.0f); }
+                *reinterpret_cast<c3h16x8*>(Ah + (g >> 2) * AST + (g & 3) * 8) = hi;
+                *reinterpret_cast<c3h16x8*>(Al + (g >> 2) * AST + (g & 3) * 8) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < 2 * 4 * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)g * 8) = b_reg[i];
+        }
+    };
+    f32x16 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.0f; acc1[i][r] = 0.0f; }
+
+    prefetch(0);
+    stage();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) prefetch(c + 1);
+        const c3h16* Ahb = Ah + (wm * 32 + l31) * AST + h * 8;
+        const c3h16* Alb = Al + (wm * 32 + l31) * AST + h * 8;
+        const c3h16* Bhb = Bh + (size_t)(h * BN + wn * NT * 32 + l31) * 8;
+        const c3h16* Blb = Bhb + 4 * BN * 8;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Ahb + ks * 16);
+            const c3h16x8 al = *reinterpret_cast<const c3h16x8*>(Alb + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const c3h16x8 bh = *reinterpret_cast<const c3h16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                const c3h16x8 bl = *reinterpret_cast<const c3h16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) {
+            __syncthreads();
+            stage();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+    gemm_epilogue<NT>(a, acc0, m0 + wm * 32, n0 + wn * NT * 32, vecO, lane);
+}
+
 struct TileCfg { int WM, WN, NT, KP, NBUF; };
 
 // Every instantiated tile configuration of the pointwise GEMM.  All of them compute bit-identical results,
@@ -926,8 +1060,53 @@ static const char* const g_pwd_names[] = {
 };
 constexpr int N_PWD_CFGS = (int)(sizeof(g_pwd_cfgs) / sizeof(g_pwd_cfgs[0]));
 
-// tile configurations of gemm_conv_kernel, then the register-direct configurations
-int pw_config_count() { return N_PW_CFGS + N_PWD_CFGS; }
+// split-f16 configurations (gemm_split_kernel<WM, WN, NT>): bit-identical to each other; used when the layer carries split packs
+#define YN_PWS_CONFIGS(X) X(4, 1, 1) X(4, 1, 2) X(4, 1, 3) X(4, 1, 4) X(2, 2, 1) X(2, 2, 2) X(1, 4, 1) X(1, 4, 2) X(2, 2, 4)
+struct SplitCfg { int WM, WN, NT; };
+static const SplitCfg g_pws_cfgs[] = {
+#define X(wm, wn, nt) {wm, wn, nt},
+    YN_PWS_CONFIGS(X)
+#undef X
+};
+static const char* const g_pws_names[] = {
+#define X(wm, wn, nt) "gemm_split_kernel<" #wm "," #wn "," #nt ">",
+    YN_PWS_CONFIGS(X)
+#undef X
+};
+constexpr int N_PWS_CFGS = (int)(sizeof(g_pws_cfgs) / sizeof(g_pws_cfgs[0]));
+
+// tile configurations of gemm_conv_kernel, then the register-direct configurations (the f32-MFMA family), then the split-f16 family
+int pw_config_count() { return N_PW_CFGS + N_PWD_CFGS + N_PWS_CFGS; }
+int pw_f32_config_count() { return N_PW_CFGS + N_PWD_CFGS; }
+
+static bool launch_pw_split(const GemmArgs& a, int idx, hipStream_t s)
+{
+    if (!a.Wsh || !a.Wsl || (a.K & 1) || (a.in_ld & 1) || (a.in_off & 1)) return false;
+    if (idx < 0 || idx >= N_PWS_CFGS) {                     // heuristic: widest tile that still gives >= 2 blocks per CU
+        const int nt32 = a.Npad / 32;
+        idx = 0;
+        long best = -1;
+        for (int i = 0; i < N_PWS_CFGS; ++i) {
+            const SplitCfg& c = g_pws_cfgs[i];
+            const long BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+            if (BN > 32 * nt32 + 31 && BN != 32) continue;
+            const long blocks = ((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN);
+            const long waste = ((a.Npad + BN - 1) / BN) * BN - a.Npad;
+            const long score = (blocks >= 512 ? 1000000 : blocks * 1000) + BM * BN / 64 - waste * 50;
+            if (score > best) { best = score; idx = i; }
+        }
+    }
+    const SplitCfg& c = g_pws_cfgs[idx];
+    const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+    dim3 grid(xcd_grid((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN));
+    g_last_kernel = g_pws_names[idx];
+    int i = 0;
+#define X(wm, wn, nt)                                                                                      \
+    if (i++ == idx) { hipLaunchKernelGGL((gemm_split_kernel<wm, wn, nt>), grid, dim3(256), 0, s, a); return true; }
+    YN_PWS_CONFIGS(X)
+#undef X
+    return false;
+}
 
 // false when the layer's strides do not allow 16-byte A loads
 static bool launch_pw_direct(const GemmArgs& a, int idx, hipStream_t s)
@@ -988,6 +1167,9 @@ static int choose_pw_cfg(int M, int K, int Npad)
 void launch_pw(const GemmArgs& a, hipStream_t s)
 {
     int idx = a.cfg;
+    // layers that carry split packs run on the split-f16 family unless an f32 configuration is requested explicitly
+    if (a.Wsh && (idx < 0 || idx >= N_PW_CFGS + N_PWD_CFGS) && launch_pw_split(a, idx < 0 ? -1 : idx - N_PW_CFGS - N_PWD_CFGS, s)) return;
+    if (idx >= N_PW_CFGS + N_PWD_CFGS) idx = -1;
     if (idx >= N_PW_CFGS && idx < N_PW_CFGS + N_PWD_CFGS && launch_pw_direct(a, idx - N_PW_CFGS, s)) return;
     if (idx < 0 || idx >= N_PW_CFGS) idx = choose_pw_cfg(a.M, a.K, a.Npad);
     const TileCfg& c = g_pw_cfgs[idx];

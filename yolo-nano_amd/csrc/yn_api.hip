@@ -123,7 +123,6 @@ struct yn_handle {
     bool autotune = true;
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
-    bool dwpw_tile = false;                        // other depthwise convs fused into their pointwise consumer (dwpw_tile_kernel): parity-tested, measured slower — YN_DWPW_TILE=1
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
@@ -403,8 +402,10 @@ int tune_pw(yn_handle* h, GemmArgs a)
     if (forced >= 0) return forced;
     if (h->force_pw_cfg >= 0) return h->force_pw_cfg;
     if (!h->autotune) return -1;
+    // the candidates: the split-f16 family for a layer that carries split packs, else the f32-MFMA family (each bit-identical inside)
+    const int c_lo = a.Wsh ? pw_f32_config_count() : 0, c_hi = a.Wsh ? pw_config_count() : pw_f32_config_count();
     // one table per process, shared by every handle (bench.py runs four per GPU: the layer shapes are timed once, not four times)
-    const std::vector<int> key = {h->cfg.device, a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0};
+    const std::vector<int> key = {h->cfg.device, a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0, a.Wsh ? 1 : 0};
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = g_pw_tuned.find(key);
@@ -416,7 +417,7 @@ int tune_pw(yn_handle* h, GemmArgs a)
     if (!h->tune_e0) { (void)hipEventCreate(&h->tune_e0); (void)hipEventCreate(&h->tune_e1); }
     int best = -1;
     float best_ms = 1e30f;
-    for (int c = 0; c < pw_config_count(); ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         a.cfg = c;
         launch_pw(a, h->cur);                               // warm-up
         (void)hipEventRecord(h->tune_e0, h->cur);
@@ -445,6 +446,7 @@ void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     if (n_store > l.cout && n_store <= l.Npad) a.N = n_store;     // padded output row: the extra (zero-weight) columns are stored too
+    if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }      // split-f16 MFMA family (fp32-class); exact_f32: the f32-MFMA kernels
     a.cfg = -1;
     a.cfg = tune_pw(h, a);
     Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
@@ -485,7 +487,8 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
 // the stage ran, *result = final [M][C]; -1 on an error (latched in the handle).
 int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
 {
-    if (!h->unit_chain) return 0;
+    if (!h->unit_chain || !h->exact_f32) return 0;           // unit_chain_kernel is an f32-MFMA kernel: with split operands (default) the units run as
+                                                             // three kernels on gemm_split_kernel, which is faster than the f32 chain and keeps ONE numerics for every batch size
     const int bf = C / 2;
     const long M = (long)B * H * W;
     // A chain kernel's block runs its five phases back to back (17 / 27 / 47 us for bf = 58 / 116 / 232) whatever M is, so on
@@ -550,20 +553,6 @@ void run_dwpw(yn_handle* h, const Layer& dw, const Layer& pw, const float* in, i
 {
     const int Ho = (H - 1) / dw.stride + 1, Wo = (W - 1) / dw.stride + 1;
     const long M = (long)B * Ho * Wo;                       // output pixels
-    if (h->dwpw_tile) {
-        // dwpw_tile_kernel: the depthwise output lives in an LDS tile only (kernels_conv.hip)
-        GemmArgs a{};
-        a.in = in; a.in_ld = in_ld; a.in_off = in_off; a.H = H; a.W = W;
-        a.Wp = pw.w_packed; a.bias = pw.b_packed;
-        a.out = out; a.out_ld = out_ld; a.out_off = out_off;
-        a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
-        a.M = (int)M; a.K = pw.cin; a.N = pw.cout; a.Npad = pw.Npad; a.act = pw.act; a.cfg = -1;
-        a.dw_w = dw.w_packed; a.dw_b = dw.b_packed; a.dw_act = dw.act; a.dw_stride = dw.stride;
-        Bracket br(h, dw.name + "+" + pw.name, 2.0 * M * (9.0 * dw.cout + (double)pw.cin * pw.cout),
-                   4.0 * ((double)B * H * W * pw.cin + M * (double)(pw.cout + (pass ? 2 * pw.cout : 0)) + (double)pw.cin * pw.cout));
-        if (dw.cout == pw.cin && launch_dwpw_tile(a, h->cur)) return;
-        br.cancel();
-    }
     run_dw(h, dw, in, in_ld, in_off, B, H, W, tmp, dw.cout, 0);
     run_pw(h, pw, tmp, dw.cout, 0, M, out, out_ld, out_off, pass, pass_ld, pass_off);
 }
@@ -655,13 +644,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         const std::string P0 = nm;
         // stride-2 block: backbone/shufflenetv2.py:73-74
         fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
-        if (h->dwpw_tile) {                                 // depthwise fused into its pointwise consumer (default off: slower)
-            run_dwpw(h, L(h, P0 + ".b1.dw"), L(h, P0 + ".b1.pw"), cur, curC, 0, B, curH, curH, tdw1, tb1, bf, 0, nullptr, 0, 0);
-            back_to_main(h);
-            run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
-            join_from(h, 0);
-            run_dwpw(h, L(h, P0 + ".b2.dw"), L(h, P0 + ".b2.pw2"), t1, bf, 0, B, curH, curH, t2, oA, C, 0, tb1, bf, 0);
-        } else {
+        {
             run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
             run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
             back_to_main(h);
@@ -800,7 +783,6 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
-    if (const char* e5 = getenv("YN_DWPW_TILE")) h->dwpw_tile = atoi(e5) != 0;      // A/B switch for dwpw_tile_kernel
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
@@ -890,6 +872,7 @@ int yn_set_pw_config(yn_handle* h, int index)
     return 0;
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
+int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
 int yn_exact_f32(yn_handle* h, int enable)
 {
     if (!h) return 1;
@@ -999,8 +982,8 @@ int yn_fold_bn(yn_handle* h)
             HIPCHK(h, hipMalloc((void**)&l.b_ref, (size_t)l.cout * sizeof(float)));
             l.w_numel = w->numel;
         }
-        if (l.kind == K_DENSE3 && !l.ws_hi) {
-            l.ws_bytes = (size_t)9 * ((l.cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
+        if ((l.kind == K_DENSE3 || l.kind == K_PW) && !l.ws_hi) {
+            l.ws_bytes = (size_t)(l.kind == K_DENSE3 ? 9 : 1) * ((l.cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
             HIPCHK(h, hipMalloc(&l.ws_hi, l.ws_bytes));
             HIPCHK(h, hipMalloc(&l.ws_lo, l.ws_bytes));
         }
@@ -1311,8 +1294,8 @@ struct TmpLayer {
         (void)hipMemsetAsync(l.w_packed, 0, packed * sizeof(float), h->stream);
         (void)hipMemsetAsync(l.b_packed, 0, bfl * sizeof(float), h->stream);
         a.w_packed = l.w_packed; a.b_packed = l.b_packed;
-        if (kind == K_DENSE3) {                             // the split-f16 packs the network's dense 3x3 layers run on
-            l.ws_bytes = (size_t)9 * ((cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
+        if (kind == K_DENSE3 || kind == K_PW) {             // the split-f16 packs the network's GEMM-shaped layers run on
+            l.ws_bytes = (size_t)(kind == K_DENSE3 ? 9 : 1) * ((cin + 7) / 8) * l.Npad * 8 * sizeof(_Float16);
             if (hipMalloc(&l.ws_hi, l.ws_bytes) != hipSuccess || hipMalloc(&l.ws_lo, l.ws_bytes) != hipSuccess) { rc = 1; return; }
             (void)hipMemsetAsync(l.ws_hi, 0, l.ws_bytes, h->stream);
             (void)hipMemsetAsync(l.ws_lo, 0, l.ws_bytes, h->stream);

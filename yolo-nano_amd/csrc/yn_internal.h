@@ -47,11 +47,10 @@ bool unit_chain_covers(const ChainArgs& a);     // same selection, nothing launc
 
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
 void set_last_kernel_name(const char* n);
-int  pw_config_count();
+int  pw_config_count();                    // f32-MFMA family (tiled, then register-direct) followed by the split-f16 family
+int  pw_f32_config_count();
 void launch_pw(const GemmArgs& a, hipStream_t s);
 void launch_conv3x3(const GemmArgs& a, hipStream_t s);
-// depthwise 3x3 + the pointwise 1x1 that consumes it in one kernel; returns false when the shape does not fit
-bool launch_dwpw_tile(const GemmArgs& a, hipStream_t s);
 void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
                  int Cout, int act, float* y, hipStream_t s);
