@@ -560,13 +560,15 @@ def test_unit_chain_bit_identical_to_three_kernel_path(capi, backbone, C, S, B):
     h.load_state_dict(weights.make_state_dict(backbone, C))
     h.fold_bn()
     x = dev(weights.make_input(B, S, seed=S + B))
-    h.exact_f32(True)                                        # unit_chain_kernel belongs to the f32-MFMA family (the split-f16 default runs three kernels per unit)
-    h.unit_chain(True)
-    a = [t.clone() for t in h.forward_raw(x)]
-    h.unit_chain(False)
-    b = [t.clone() for t in h.forward_raw(x)]
-    for u, v in zip(a, b):
-        assert torch.equal(u, v)
+    for exact in (False, True):                              # the split-f16 family (default) and the f32-MFMA family: each has its chain kernel
+        h.exact_f32(exact)
+        h.unit_chain(True)
+        a = [t.clone() for t in h.forward_raw(x)]
+        h.unit_chain(False)
+        b = [t.clone() for t in h.forward_raw(x)]
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), "exact_f32=%s" % exact
+    h.exact_f32(False)
     h.profile_enable(True)                                   # the chain really ran (kernel names of the profiled call)
     h.unit_chain(True)
     h.forward_raw(x)

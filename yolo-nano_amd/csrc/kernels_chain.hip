@@ -325,6 +325,273 @@ __global__ __launch_bounds__(256, 2) void unit_chain_kernel(ChainArgs a)
 #undef YN_TS
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same chain on the split-f16 family (gemm_split_kernel's numerics: x = hi + lo*2^-11, three f16 MFMAs per product, K in chunks
+// of 32 in the same order => bit-identical to the three-kernel path on gemm_split_kernel).  With the GEMM phases 4-5x shorter the
+// unit is the depthwise (memory) phase plus two short matrix phases, so ONE launch per unit beats three again.  LDS: the depthwise
+// output / x2' as two planes of halves P[2][BM][PS] (A operands), the fp32 tile T32 [BM][bf+2] for y (the interleave pass needs y
+// in full precision), one buffer of pre-split weight chunks.
+// -------------------------------------------------------------------------------------------------
+typedef _Float16 uch16;
+typedef _Float16 uch16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 uch16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 uch16x2 __attribute__((ext_vector_type(2)));
+
+template <int WM, int WN, int NT, int V>
+__global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
+{
+    typedef typename VecT<V>::type vec;
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KC = 32, G = V / 2;
+    constexpr int B_PER = (2 * 4 * BN + 255) / 256;
+    constexpr int MAXB = (BM * (BN / (2 * G)) + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float ucs_smem[];
+    const int bf = a.bf, CS = bf + 2, W = a.W, H = a.H, HW = H * W;
+    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, nchunks = (bf + KC - 1) / KC;
+    float* T32 = ucs_smem;                                              // [BM][CS]
+    uch16* Ph = reinterpret_cast<uch16*>(ucs_smem + ((BM * CS + 3) & ~3));  // [BM][PS]
+    uch16* Pl = Ph + BM * PS;
+    uch16* Bh = Pl + BM * PS;                                           // [4][BN][8], then the lo plane
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
+    if (m0 >= a.M) return;
+
+    uch16x8 b_reg[B_PER];
+    auto prefetch_b = [&](const void* Wh, const void* Wl, int c) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;
+            const int pl = g / (4 * BN), r = g - pl * (4 * BN);
+            const int o = r / BN, n = r - o * BN;
+            const int kq = c * (KC / 8) + o;
+            const bool ok = g < 2 * 4 * BN && kq < KQ && n < a.Npad;
+            uch16x8 v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? Wl : Wh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < 2 * 4 * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)g * 8) = b_reg[i];
+        }
+    };
+    auto split_store = [&](int r, int c, float v0, float v1) {           // two adjacent channels of row r -> both planes
+        uch16x2 hi, lo;
+        hi[0] = (uch16)v0; hi[1] = (uch16)v1;
+        lo[0] = (uch16)((v0 - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((v1 - (float)hi[1]) * 2048.0f);
+        *reinterpret_cast<uch16x2*>(Ph + r * PS + c) = hi;
+        *reinterpret_cast<uch16x2*>(Pl + r * PS + c) = lo;
+    };
+
+    float bias2[NT], bias1n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias1n[nt] = (a.Wp1n && n < bf) ? a.b1n[n] : 0.0f;
+    }
+    const int hipr = bf / (2 * G), jhi = bf >> 1;
+    float2 xg[MAXB], xl[MAXB];
+    auto x1_prefetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int it = t + 256 * i;
+        const int r = it / hipr, j0 = (it - r * hipr) * G;
+        const int m = m0 + r < a.M ? m0 + r : a.M - 1;
+        xg[i] = make_float2(0.0f, 0.0f); xl[i] = xg[i];
+        if (it < BM * hipr) {
+            const float* px = a.x1 + (size_t)m * a.x1_ld + a.x1_off + j0;
+            if constexpr (G == 2) {
+                xg[i] = *reinterpret_cast<const float2*>(px);
+                xl[i] = *reinterpret_cast<const float2*>(px + jhi);
+            } else {
+                xg[i].x = px[0];
+                xl[i].x = px[jhi];
+            }
+        }
+    }
+    };
+
+    // ---- 1. depthwise 3x3 of the block's pixels -> split planes (the same fma chain as dwconv3x3_kernel) ------------------------
+    {
+        const int cgn = bf / V, ppl = 256 / cgn;
+        const int cg = t % cgn, pl = t / cgn, c = cg * V;
+        const bool worker = pl < ppl;
+        constexpr int R = 4;
+        auto issue = [&](int run, vec (&win)[3][R + 2]) {
+            const int q0 = m0 + run * R - 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int i = 0; i < R + 2; ++i) {
+                    int q = q0 + (dy - 1) * W + i;
+                    q = q < 0 ? 0 : (q >= a.M ? a.M - 1 : q);
+                    win[dy][i] = *reinterpret_cast<const vec*>(a.t1 + (size_t)q * a.t1_ld + a.t1_off + c);
+                }
+        };
+        vec w[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const vec*>(a.wdw + k * bf + c);
+        const vec bias = *reinterpret_cast<const vec*>(a.bdw + c);
+        auto finish = [&](int run, vec (&win)[3][R + 2]) {
+            const int mrun = m0 + run * R;
+            const int rem0 = (mrun < a.M ? mrun : m0) % HW;
+            int y = rem0 / W, x = rem0 - y * W;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = run * R + i;
+                const bool live = mrun + i < a.M;
+                const bool yk[3] = {live && y >= 1, live, live && y + 1 < H};
+                const bool xk[3] = {x >= 1, true, x + 1 < W};
+                vec acc = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool ok = yk[ky] && xk[kx];
+                        vec v = win[ky][i + kx];
+                        if constexpr (V == 4) v = make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+                        else v = make_float2(ok ? v.x : 0.0f, ok ? v.y : 0.0f);
+                        vfma(acc, v, w[ky * 3 + kx]);
+                    }
+                acc = vact(acc, a.dw_act);
+                if constexpr (V == 4) { split_store(r, c, acc.x, acc.y); split_store(r, c + 2, acc.z, acc.w); }
+                else split_store(r, c, acc.x, acc.y);
+                if (++x == W) { x = 0; if (++y == H) y = 0; }
+            }
+        };
+        vec win[3][R + 2];
+        if (worker) issue(pl, win);
+        prefetch_b(a.Ws2h, a.Ws2l, 0);
+        x1_prefetch();
+        stage_b();
+        if (nchunks > 1) prefetch_b(a.Ws2h, a.Ws2l, 1);
+        if (worker) {
+            for (int run = pl; run < BM / R; run += ppl) {
+                finish(run, win);
+                if (run + ppl < BM / R) issue(run + ppl, win);
+            }
+        }
+        // K tail: the columns [bf, PS) of both planes are zero (they meet zero weight rows, but must not be NaN bit patterns)
+        const int padn = PS - bf;
+        for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (uch16)0.0f; Pl[r * PS + c2] = (uch16)0.0f; }
+    }
+    __syncthreads();
+
+    f32x16 acc0[NT], acc1[NT];
+    // entry state: chunk 0 staged (visible), chunk 1 requested into b_reg
+    auto gemm = [&](const void* Wh, const void* Wl) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+        for (int c = 0; c < nchunks; ++c) {
+            const uch16* Ahb = Ph + (wm * 32 + l31) * PS + c * KC + h * 8;
+            const uch16* Alb = Pl + (wm * 32 + l31) * PS + c * KC + h * 8;
+            const uch16* Bhb = Bh + (size_t)(h * BN + wn * NT * 32 + l31) * 8;
+            const uch16* Blb = Bhb + 4 * BN * 8;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                if (c * (KC / 8) + ks * 2 >= KQ) break;                 // wave-uniform: this 16-deep step lies beyond the (zero-padded) K
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                    const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nchunks) {
+                __syncthreads();                                        // every wave is done with this chunk's weights
+                stage_b();
+                __syncthreads();
+                if (c + 2 < nchunks) prefetch_b(Wh, Wl, c + 2);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+    };
+    gemm(a.Ws2h, a.Ws2l);
+    if (a.Wp1n) prefetch_b(a.Ws1h, a.Ws1l, 0);
+    __syncthreads();                                                    // all waves are done reading the planes and the weights
+
+    // ---- 3. y = act(acc + b2) -> T32 ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        if (n < bf) {
+            const float bias = bias2[nt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T32[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + n] = apply_act(acc0[nt][r] + bias, a.act2);
+        }
+    }
+    if (a.Wp1n) {
+        stage_b();
+        if (nchunks > 1) prefetch_b(a.Ws1h, a.Ws1l, 1);
+    }
+    __syncthreads();
+
+    // interleave pass (as unit_chain_kernel): first half-row -> global; second half-row -> global (last unit) or x2' -> planes
+    float2 yl[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int it = t + 256 * i;
+        const int r = it / hipr, j0 = (it - r * hipr) * G, m = m0 + r;
+        yl[i] = make_float2(0.0f, 0.0f);
+        if (it < BM * hipr) {
+            float2 y = make_float2(0.0f, 0.0f);
+            if constexpr (G == 2) { y = *reinterpret_cast<const float2*>(T32 + r * CS + j0); yl[i] = *reinterpret_cast<const float2*>(T32 + r * CS + jhi + j0); }
+            else { y.x = T32[r * CS + j0]; yl[i].x = T32[r * CS + jhi + j0]; }
+            if (m < a.M) {
+                float* o = a.out + (size_t)m * a.out_ld + 2 * j0;
+                if constexpr (G == 2) {
+                    *reinterpret_cast<float4*>(o) = make_float4(xg[i].x, y.x, xg[i].y, y.y);
+                    if (!a.Wp1n) *reinterpret_cast<float4*>(o + 2 * jhi) = make_float4(xl[i].x, yl[i].x, xl[i].y, yl[i].y);
+                } else {
+                    *reinterpret_cast<float2*>(o) = make_float2(xg[i].x, y.x);
+                    if (!a.Wp1n) *reinterpret_cast<float2*>(o + 2 * jhi) = make_float2(xl[i].x, yl[i].x);
+                }
+            }
+        }
+    }
+    if (!a.Wp1n) return;
+    // x2' = interleave(x1[bf/2:], y[bf/2:]) -> the planes (free since the first GEMM; their pad columns are still zero)
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int it = t + 256 * i;
+        const int r = it / hipr, c0 = 2 * (it - r * hipr) * G;
+        if (it < BM * hipr) {
+            split_store(r, c0, xl[i].x, yl[i].x);
+            if constexpr (G == 2) split_store(r, c0 + 2, xl[i].y, yl[i].y);
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. the next unit's pw1 on x2' -> global ------------------------------------------------------------------------------
+    gemm(a.Ws1h, a.Ws1l);
+    GemmArgs e{};
+    e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = a.M; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
+    gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
+}
+
+static size_t unit_chain_split_lds(int bf, int BM, int BN)
+{
+    const int PS = ((bf + 7) / 8) * 8 + 8;
+    return (size_t)((BM * (bf + 2) + 3) & ~3) * sizeof(float) + ((size_t)2 * BM * PS + (size_t)2 * 4 * BN * 8) * 2;
+}
+
 static size_t unit_chain_lds(int bf, int BM, int BN) { return ((size_t)((BM * (bf + 2) + 3) & ~3) + (size_t)2 * 16 * BN * 2) * sizeof(float); }
 
 // false when no instantiated tile covers the shape (Npad must be one block column; bf % 4 == 0 or the 2-channel variant)
@@ -348,6 +615,29 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
         hipLaunchKernelGGL((unit_chain_kernel<WMv, WNv, NTv, Vv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
         return true;                                                                                                   \
     }
+#define YN_UCS(WMv, WNv, NTv, Vv)                                                                                      \
+    {                                                                                                                  \
+        constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
+        const size_t lds = unit_chain_split_lds(a.bf, BM, BN);                                                         \
+        if (lds > 160 * 1024) return false;                                                                            \
+        if (dry) return true;                                                                                          \
+        static unsigned long long attr = 0;                                                                            \
+        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain_split_kernel<WMv, WNv, NTv, Vv>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }              \
+        set_last_kernel_name("unit_chain_split_kernel<" #WMv "," #WNv "," #NTv "," #Vv ">");                            \
+        hipLaunchKernelGGL((unit_chain_split_kernel<WMv, WNv, NTv, Vv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
+        return true;                                                                                                   \
+    }
+    if (a.Ws2h) {                                            // split-f16 family
+        if (a.Npad == 64 && !v4) YN_UCS(2, 2, 1, 2)
+        if (a.Npad == 64 && v4) YN_UCS(2, 2, 1, 4)
+        if (a.Npad == 128 && v4) YN_UCS(2, 2, 2, 4)
+        if (a.Npad == 256 && v4) YN_UCS(2, 2, 4, 4)
+        if (a.Npad == 32 && v4) YN_UCS(4, 1, 1, 4)
+        if (a.Npad == 96 && v4) YN_UCS(4, 1, 3, 4)
+        return false;
+    }
+#undef YN_UCS
     const int tiles64 = (a.M + 63) / 64;
     if (a.Npad == 64 && !v4) YN_UC(2, 2, 1, 2)
     if (a.Npad == 64 && v4) YN_UC(2, 2, 1, 4)

@@ -487,8 +487,7 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
 // the stage ran, *result = final [M][C]; -1 on an error (latched in the handle).
 int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
 {
-    if (!h->unit_chain || !h->exact_f32) return 0;           // unit_chain_kernel is an f32-MFMA kernel: with split operands (default) the units run as
-                                                             // three kernels on gemm_split_kernel, which is faster than the f32 chain and keeps ONE numerics for every batch size
+    if (!h->unit_chain) return 0;
     const int bf = C / 2;
     const long M = (long)B * H * W;
     // A chain kernel's block runs its five phases back to back (17 / 27 / 47 us for bf = 58 / 116 / 232) whatever M is, so on
@@ -506,6 +505,7 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
         for (int first = 0; first < 2; ++first) {
             ChainArgs q{};
             q.t1_ld = bf; q.x1_ld = first ? C : bf; q.out_ld = bf; q.bf = bf; q.Npad = L(h, name(1) + ".b2.pw2").Npad; q.M = (int)M;
+            if (!h->exact_f32) q.Ws2h = L(h, name(1) + ".b2.pw2").ws_hi;
             if (!unit_chain_covers(q)) return 0;
             q.out_ld = C;
             if (!unit_chain_covers(q)) return 0;
@@ -526,9 +526,11 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
         a.x1 = x1; a.x1_ld = x1_ld; a.x1_off = 0;
         a.wdw = dw.w_packed; a.bdw = dw.b_packed; a.dw_act = dw.act;
         a.Wp2 = pw2.w_packed; a.b2 = pw2.b_packed; a.act2 = pw2.act;
+        if (!h->exact_f32) { a.Ws2h = pw2.ws_hi; a.Ws2l = pw2.ws_lo; }
         if (!last) {
             const Layer& pw1n = L(h, name(bi + 1) + ".b2.pw1");
             a.Wp1n = pw1n.w_packed; a.b1n = pw1n.b_packed; a.act1n = pw1n.act;
+            if (!h->exact_f32) { a.Ws1h = pw1n.ws_hi; a.Ws1l = pw1n.ws_lo; }
             a.out = pbuf[(bi - 1) & 1]; a.out_ld = bf; a.t1n = tB;
         } else {
             a.out = final_out; a.out_ld = C;

@@ -38,6 +38,7 @@ struct ChainArgs {
     const float* wdw; const float* bdw; int dw_act;     // depthwise [9][bf], [bf] (BN folded)
     const float* Wp2; const float* b2; int act2;        // pw2: packed [bf/2][Npad][2], bias [Npad]
     const float* Wp1n; const float* b1n; int act1n;     // next unit's pw1 (null: last unit of the stage)
+    const void *Ws2h, *Ws2l, *Ws1h, *Ws1l;              // split-f16 packs of pw2 / the next pw1 (null: the f32-MFMA chain kernel)
     float* out; int out_ld;                     // next != null: first half of the shuffled output, [M][bf]; else the whole output [M][2*bf]
     float* t1n;                                 // next unit's depthwise input [M][bf]
     int B, H, W, bf, Npad, M;
