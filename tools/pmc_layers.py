@@ -42,7 +42,7 @@ def calls_of(path, layers, reps):
 def family(name):
     name = name.replace("void ", "").replace("ynk::", "")
     name = name.split("<")[0].split("(")[0].strip()
-    return "pointwise_gemm" if name in ("gemm_conv_kernel", "gemm_direct_kernel", "gemm_persist_kernel") else name   # autotuned per process
+    return "pointwise_gemm" if name in ("gemm_conv_kernel", "gemm_direct_kernel", "gemm_split_kernel") else name   # autotuned per process
 
 
 def main():
@@ -51,7 +51,7 @@ def main():
     reps = 3
     f, w = calls_of(fetch_csv, layers, reps), calls_of(write_csv, layers, reps)
     out = {"_meta": {"workload": layers and layers[0].get("workload"), "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes",
-                     "calls_averaged": reps}}
+                     "calls_averaged": reps, "source_hash": layers and layers[0].get("source_hash")}}
     print("| # | layer | kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM MB = (2F+W)*1024 | algorithmic MB |\n|---|---|---|---|---|---|---|")
     for i, rec in enumerate(layers):
         fk = sum(c[i] for c in f) / reps
