@@ -19,8 +19,10 @@ def load(path):
             continue
         n = n.replace("void ynk::", "").replace("ynk::", "")
         n = n[:n.index("(")] if "(" in n else n
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, int(r.get("LDS_Block_Size", 0) or 0), int(r.get("VGPR_Count", 0) or 0),
-                     int(r.get("Workgroup_Size", 256) or 256), int(r.get("Grid_Size", 0) or 0)))
+        wg = int(r.get("Workgroup_Size_X", 256) or 256) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
+        grid = int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, int(r.get("LDS_Block_Size", 0) or 0),
+                     int(r.get("VGPR_Count", 0) or 0) + int(r.get("Accum_VGPR_Count", 0) or 0), wg, grid, r.get("Queue_Id", "?")))
     rows.sort()
     return rows
 
@@ -38,7 +40,7 @@ def main():
     for s, e, n, *_ in single:
         solo[n].append((e - s) / 1e3)
     agg = collections.defaultdict(lambda: {"d": [], "res": None})
-    for s, e, n, lds, vg, wg, grid in multi:
+    for s, e, n, lds, vg, wg, grid, q in multi:
         agg[n]["d"].append((e - s) / 1e3)
         agg[n]["res"] = (lds, vg, wg, grid)
     # kernels in flight over time (sweep)
@@ -52,7 +54,7 @@ def main():
         cur += d; last = t
     span = sum(hist.values())
     busy = sum((e - s) for s, e, *_ in multi)
-    print("## kernels in flight (default run, steady-state half of the trace)\n")
+    print("## kernels in flight (default run, steady-state half of the trace; HSA queues used: %s)\n" % sorted({r[7] for r in multi}))
     print("time-weighted mean %.2f; " % (busy / span) + ", ".join("%d: %.1f %%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
     print("\n## per kernel symbol\n")
     print("| kernel | calls | avg us alone (1 stream) | avg us in the 4-stream run | inflation | LDS B/block | VGPRs | blocks | blocks/CU its resources allow | share of the chip's block slots it fills alone |")
@@ -72,7 +74,7 @@ def main():
         s_avg = sum(s1) / len(s1) if s1 else float("nan")
         print("| `%s` | %d | %.1f | %.1f | %.2f | %d | %d | %d | %d | %.2f |" % (n[:48], len(v["d"]), s_avg, a, a / s_avg if s1 else float("nan"), lds, vg, blocks, per_cu,
                                                                         min(1.0, blocks / (256.0 * per_cu))))
-    print("\nsum of kernel time / wall span = %.2f (kernel-time per step is inflated by that much less than the stream count)" % (tot_m / span))
+    print("\nsum of kernel durations / wall span = %.2f" % (tot_m * 1e3 / span))
 
 
 if __name__ == "__main__":
