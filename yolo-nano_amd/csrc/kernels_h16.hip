@@ -478,7 +478,7 @@ void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H,
 // =================================================================================================
 // Column reductions over an [M][Cp] h16 matrix.  Block = OL octet-lanes x (256/OL) row-lanes; a thread owns 8 channels and
 // walks down the rows with four independent 16-byte loads in flight, accumulating in double; row-lanes are combined through
-// LDS and ONE double atomic per channel per block goes into the block's accumulator slot (ACC_SLOTS copies, kernels_bwd.hip).
+// LDS and ONE double atomic per channel per block goes into the block's accumulator slot (HACC_SLOTS copies).
 //   MODE 0  stats:     acc[0][c] += sum y,   acc[1][c] += sum y*y
 //   MODE 2  BN bwd:    acc[0][c] += sum dyh, acc[1][c] += sum dyh * xhat      (dyh = dz * act'(BN(y)), xhat = (y - mean) * invstd)
 //   MODE 3  column sum of y into the fp32 gradient slots (bias gradient)
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
             if (MODE == 3) {
                 atomicAdd(a.facc + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * a.slot_stride + lc[j], (float)s0[j]);
             } else {
-                double* acc = a.acc + (size_t)(blockIdx.x & (ACC_SLOTS - 1)) * 2 * a.C;
+                double* acc = a.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * a.C;
                 atomicAdd(acc + lc[j], s0[j]);
                 atomicAdd(acc + a.C + lc[j], s1[j]);
             }
@@ -613,7 +613,9 @@ void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
 {
     HRedArgs a = a0;
     a.lanes = hlanes_for(a.Cp);
-    static const int gmax = getenv("YN_RED_G") ? atoi(getenv("YN_RED_G")) : 512;
+    // one block per CU measured best (11.9 ms per 608 / bs-32 step against 12.0 at 512 and 12.4 at 1024 blocks): the per-block tail
+    // (cross-wave combine + 2*C fp64 atomics) outweighs the extra loads in flight
+    static const int gmax = getenv("YN_RED_G") ? atoi(getenv("YN_RED_G")) : 256;
     const dim3 grid(hreduce_blocks(a.M, 256 / a.lanes, gmax));
     if (mode == 0) hipLaunchKernelGGL(hcol_reduce_kernel<0>, grid, dim3(256), 0, s, a);
     else if (mode == 2) hipLaunchKernelGGL(hcol_reduce_kernel<2>, grid, dim3(256), 0, s, a);
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
     for (int c = threadIdx.x; c < a.C; c += 256) {
         double m = 0.0, q = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < ACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * a.C + c]; q += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+        for (int sl = 0; sl < HACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * a.C + c]; q += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
         m *= invM;
         double var = q * invM - m * m;
         if (var < 0.0) var = 0.0;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restric
     for (int c = threadIdx.x; c < a.C; c += 256) {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < ACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+        for (int sl = 0; sl < HACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
         cst[0][c] = a.mean[c]; cst[1][c] = a.invstd[c]; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
         cst[4][c] = (float)(s0 * invM); cst[5][c] = (float)(s1 * invM);
         if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }

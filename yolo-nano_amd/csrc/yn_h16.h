@@ -5,6 +5,9 @@
 namespace ynk {
 
 typedef _Float16 h16;
+// copies of every BatchNorm sum accumulator the fp16 step spreads its atomics over (same-address fp64 atomics serialise at the
+// memory side: with 8 copies and 512 blocks the tail of a reduction was longer than its streaming phase)
+constexpr int HACC_SLOTS = 32;
 
 // C[M][Np] (+)= A[M][Kp] (x taps) * Wp + bias — see hgemm_kernel
 struct HGemmArgs {
