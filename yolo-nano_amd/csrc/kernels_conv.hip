@@ -725,6 +725,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
     const c3h16* Wsh = reinterpret_cast<const c3h16*>(a.Wsh);
     const c3h16* Wsl = reinterpret_cast<const c3h16*>(a.Wsl);
 
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
     c3h16x8 b_reg[B_PER];
     auto prefetch_b = [&](int tap) {
 #pragma unroll
@@ -748,7 +755,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
     };
     prefetch_b(0);
 
-    // ---- halo: 16-byte global loads (+ the fused resample-add), split, two 8-byte LDS stores per item ----
+    // ---- halo: 16-byte global loads (+ the fused resample-add), split, two 8-byte LDS stores per item.  Phase timing (tools/c3_timing.sh,
+    //      smooth_1: W = 52, one block per CU): halo 19 k cycles, nine taps 31.7 k (486 MFMAs = 15.5 k), epilogue 9 k per 128-pixel tile.
+    //      The halo phase is BANDWIDTH-bound, not latency-bound: 180 KB per tile (halo factor 1.83 at W = 52 + the up2 source) at the
+    //      ~10 B/clk/CU every CU gets when all of them stream at once; 24 loads in flight per thread instead of 8 changed nothing ----
     {
         constexpr int U = 8, CQ = CIN / 4, PPL = 256 / CQ;
         const int cq = t % CQ, pl = t / CQ;
@@ -788,6 +798,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
             }
         }
     }
+    YN_TS();
     stage_b();
 
     const int r = wave * 32 + l31;
@@ -803,6 +814,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
         }
     }
     __syncthreads();
+    YN_TS();
 
     f32x16 acc0[NT], acc1[NT];                              // sum ah*wh ; sum (ah*wl + al*wh), worth 2^-11
 #pragma unroll
@@ -841,6 +853,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
         }
     }
 
+    YN_TS();
     // epilogue: combine the two accumulator sets, bias + activation, quad transpose -> 16-byte stores
     const int j = lane & 3;
 #pragma unroll
@@ -869,8 +882,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
                 *reinterpret_cast<float4*>(a.out + (size_t)mm * a.out_ld + a.out_off + nq) = make_float4(v0, v1, v2, v3);
         }
     }
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && (blockIdx.x % 61) == 7 && blockIdx.y == 0)
+        printf("c3split NT %d blk %d start %lld halo %lld stageb+sync %lld taps %lld epi %lld\n", NT, (int)blockIdx.x, TS[0], TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2], TS[4] - TS[3]);
+#endif
+#undef YN_TS
 }
-
 static size_t conv3x3_split_lds(int W, int NT) { return ((size_t)2 * (128 + 2 * W + 2) * (96 + 8) + (size_t)2 * 12 * (32 * NT) * 8) * 2; }
 
 static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
