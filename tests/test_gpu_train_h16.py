@@ -232,3 +232,32 @@ def test_h16_full_size_directional_derivative():
     h.flat_params.copy_(p0)
     assert all(0.6 < r < 1.2 for r in ratios), (l0, g2, ratios)
     h.close()
+
+
+def test_shim_trains_in_f16_with_the_reference_loop(golden):
+    """train.py:219-231 on the shim with `model.train_precision('f16')`: same loop, fp32 parameters / gradients, losses within the
+    fp16-storage band of the reference's recorded fp32 losses, parameters move, no step skipped."""
+    import yolo_nano_amd
+    g = golden("train.npz")
+    S, C, B, lr = int(g["S"]), int(g["C"]), int(g["B"]), float(g["lr"])
+    model = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=True, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in weights.make_state_dict("1.0x", C).items()}, strict=False)
+    model.init_bias()
+    model = model.to("cuda").train().train_precision("f16")
+    opt = yolo_nano_amd.SGD(model, lr=lr, momentum=0.9, weight_decay=5e-4)
+    images = torch.as_tensor(weights.make_input(B, S, seed=10)).cuda()
+    targets = torch.as_tensor(g["target"]).cuda()
+    before = model.flat_parameters().clone() if hasattr(model, "flat_parameters") else None
+    losses = model(images, target=targets)
+    total = sum(losses)
+    total.backward()
+    got = np.array([float(v) for v in losses])
+    assert np.all(np.abs(got - g["losses_0"]) <= 0.05 * np.abs(g["losses_0"]) + 0.05 * np.abs(g["losses_0"]).max()), (got, g["losses_0"])
+    named = dict(model.named_parameters())
+    assert all(p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in named.values())
+    w0 = named["head_det_1.4.bias"].detach().clone()
+    opt.step(); opt.zero_grad()
+    assert (named["head_det_1.4.bias"].detach() - w0).abs().max().item() > 0
+    assert model._bound.skipped_steps() == 0
+    with pytest.raises(yolo_nano_amd.YnError):
+        model.train_precision("bf16")

@@ -177,6 +177,7 @@ class YOLONano(nn.Module):
         self._stats_stale = False            # module BN buffers newer than the handle's
         self._stats_dirty = False            # handle BN statistics newer than the module's
         self.dp_average = True               # data-parallel: average gradients over ranks inside backward()
+        self._train_dtype = "f32"            # arithmetic of the training step (train_precision)
 
     def __deepcopy__(self, memo):
         """deepcopy (utils/misc.py:70 ModelEMA) must not clone the native handle; the copy builds its own."""
@@ -337,6 +338,7 @@ class YOLONano(nn.Module):
                 raise YnError("flat parameter buffer holds %d values, the module %d" % (n, off))
             self._bound = h
             self._stats_stale = False
+            h.train_precision(self._train_dtype)
         h.follow_current_stream()
         if h.S != self.input_size:                           # multi-scale training: train.py:202-208
             h.set_grid(self.input_size)
@@ -346,6 +348,16 @@ class YOLONano(nn.Module):
                     h.load_param(k, v)
             self._stats_stale = False
         return h
+
+    def train_precision(self, dtype="f32"):
+        """Arithmetic of the training step: "f32" (what train.py runs) or "f16" (BASELINE configs[2]: fp16 activation / gradient
+        storage and f16 MFMA, fp32 master weights, loss scale on the device - yn_train_precision). Returns self."""
+        if dtype not in ("f32", "fp32", "f16", "fp16"):
+            raise YnError("train_precision: %r is not one of 'f32', 'f16'" % (dtype,))
+        self._train_dtype = "f16" if dtype in ("f16", "fp16") else "f32"
+        if self._bound is not None:
+            self._bound.train_precision(self._train_dtype)
+        return self
 
     def make_targets(self, label_lists):
         """tools.multi_gt_creator for this model's input size / anchors, on the model's device -> [B, N, 11] CUDA tensor."""
