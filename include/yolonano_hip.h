@@ -68,6 +68,11 @@ int  yn_multi_stream(yn_handle* h, int enable);
  * x = hi + lo*2^-11, three f16 MFMAs per product into fp32 accumulators: fp32-class results (per-product error <= ~3*2^-22; the
  * f32 MFMA of gfx950 runs at 1/16 of the f16 rate and there is no TF32).  enable != 0 pins every conv to the f32 MFMA. */
 int  yn_exact_f32(yn_handle* h, int enable);
+/* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's
+ * candidates (:308-330, 362-367) run as ONE kernel, so the raw head tensors are neither written nor re-read (default on; needs
+ * the split-f16 family and A(5+C) <= 256, otherwise yn_infer runs head GEMM + decode kernel as before).  Outputs are bit-identical
+ * either way: a speed switch for A/B runs.  Env: YN_FUSE_DECODE=0/1. */
+int  yn_fuse_decode(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on
  * the handle's stream and caches the fastest.  All configurations of a family produce bit-identical results; disabling falls back

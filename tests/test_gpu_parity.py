@@ -781,3 +781,34 @@ def test_split_f16_conv_is_fp32_class(hvoc, golden):
     # and bit-for-bit reproducible
     y1 = hvoc.op_conv3x3(nhwc(x), dev(w), dev(b), 2).clone()
     assert torch.equal(hvoc.op_conv3x3(nhwc(x), dev(w), dev(b), 2), y1)
+
+
+@pytest.mark.parametrize("which,S,B", [("coco", 416, 5), ("coco", 320, 1), ("voc", 320, 2), ("voc", 224, 1)])
+def test_fused_head_decode_is_bit_identical(hcoco, hvoc, which, S, B):
+    """yn_fuse_decode: the last head conv + candidate decode as one kernel (head_decode_kernel) gives exactly the detections of
+    head GEMM -> raw heads -> decode_kernel, for 80 classes (256-column tile) and 20 classes (128-column tile), with row counts that
+    are not multiples of the 32-pixel tile (10x10 = 100, 7x7 = 49 cells at stride 32)."""
+    h = hcoco if which == "coco" else hvoc
+    old = h.S
+    h.set_grid(S)
+    h.set_thresholds(0.001, 0.5)
+    x = dev(weights.make_input(B, S, seed=21))
+    try:
+        h.fuse_decode(False)
+        ref = [t.clone() for t in h.infer(x)]
+        h.fuse_decode(True)
+        got = h.infer(x)
+        counts = ref[4].cpu().tolist()
+        assert got[4].cpu().tolist() == counts and sum(counts) > 0
+        for b in range(B):
+            k = counts[b]
+            for r, g_ in zip(ref[:4], got[:4]):
+                assert torch.equal(r[b, :k], g_[b, :k])
+        h.profile_enable(True)
+        h.infer(x)
+        kernels = [r[1] for r in h.profile_records()]
+        h.profile_enable(False)
+        assert sum(k.startswith("head_decode_kernel") for k in kernels) == 3 and not any(k.startswith("decode_kernel") for k in kernels)
+    finally:
+        h.fuse_decode(True)
+        h.set_grid(old)

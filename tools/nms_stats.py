@@ -22,3 +22,6 @@ for b in (0, 1):
     hist = torch.bincount(ci[b][ok], minlength=C).cpu().numpy()
     print("image %d: candidates above threshold %d of %d; per-class count: max %d, classes with >1024: %d, >256: %d, nonempty %d"
           % (b, int(ok.sum()), sc.shape[1], hist.max(), (hist > 1024).sum(), (hist > 256).sum(), (hist > 0).sum()))
+    srt = np.sort(hist)[::-1]
+    T = (srt + 63) // 64
+    print("   largest segments:", srt[:12].tolist(), " tiles total", int((T * (T + 1) // 2).sum()), " largest segment's tiles", int(T[0] * (T[0] + 1) // 2))

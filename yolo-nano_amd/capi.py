@@ -48,6 +48,7 @@ SIGNATURES = {
     "yn_unit_chain": (_i32, [_vp, _i32]),
     "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_exact_f32": (_i32, [_vp, _i32]),
+    "yn_fuse_decode": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -224,6 +225,10 @@ class Handle:
     def exact_f32(self, on=True):
         """Pin every GEMM-shaped conv to the f32 MFMA (default off: the MFMA-bound layers use split-f16 operands, fp32-class)."""
         self._ck(self.lib.yn_exact_f32(self.h, int(bool(on))), "yn_exact_f32")
+
+    def fuse_decode(self, on=True):
+        """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
+        self._ck(self.lib.yn_fuse_decode(self.h, int(bool(on))), "yn_fuse_decode")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

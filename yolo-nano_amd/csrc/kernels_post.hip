@@ -8,7 +8,7 @@
 //   score_full_kernel    same front end, writing the reference's all_bbox [N,4] / all_class [N,C]
 //   argmax_cand_kernel   :253-261 from caller-provided (all_local, all_conf)
 //   bucket / sort / matrix / resolve / compact : exact per-class greedy NMS (see the block comment below)
-#include "yn_internal.h"
+#include "yn_device.h"
 
 namespace ynk {
 
@@ -69,32 +69,134 @@ __device__ __forceinline__ unsigned f32_order_bits(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Reductions over a 16-lane DPP row.  Lane i combines with lane (i + r) % 16 for r = 8, 4, 2, 1 (row_ror): after each step
+// lanes i and i ^ r hold equal values, so this is the xor butterfly — the same combination tree, hence the same fp32 sum bit
+// for bit — as one DPP-modified VALU instruction per step; __shfl_xor compiles to ds_bpermute_b32, whose ~100-cycle LDS round
+// trip per step (14 dependent steps per candidate) made the decode latency-bound at 4 waves per SIMD.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#define YN_ROW_STEPS(OP) OP(0x128) OP(0x124) OP(0x122) OP(0x121)
 __device__ __forceinline__ float group16_max(float v)
 {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+#define OP(c) v = fmaxf(v, dpp_f<c>(v));
+    YN_ROW_STEPS(OP)
+#undef OP
     return v;
 }
 __device__ __forceinline__ float group16_sum(float v)
 {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+#define OP(c) v += dpp_f<c>(v);
+    YN_ROW_STEPS(OP)
+#undef OP
     return v;
 }
 __device__ __forceinline__ unsigned long long group16_max_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
+#define OP(c) { const unsigned lo = (unsigned)dpp_i<c>((int)(unsigned)(v & 0xffffffffu)), hi = (unsigned)dpp_i<c>((int)(unsigned)(v >> 32));          \
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo; v = o > v ? o : v; }
+    YN_ROW_STEPS(OP)
+#undef OP
+    return v;
+}
+__device__ __forceinline__ int group16_min_i(int v)
+{
+#define OP(c) { const int o = dpp_i<c>(v); v = o < v ? o : v; }
+    YN_ROW_STEPS(OP)
+#undef OP
     return v;
 }
 
 // 16 lanes per candidate (4 candidates per wavefront): lane j of a group owns classes j, j+16, ...; the softmax
 // max / sum / arg-max are 4-step reductions inside the 16-lane row (DPP row operations).  KMAX*16 >= C.
+// one coordinate (k = 0..3: x1, y1, x2, y2) of decode_one's normalised box: the same operations in the same order, so the four
+// lanes that each evaluate one coordinate reproduce decode_one bit for bit (tc = t[k & 1], ts = t[2 + (k & 1)])
+__device__ __forceinline__ float decode_coord(const GridInfo& g, int s, int gx, int gy, int a, float tc, float ts, float S, int k)
+{
+    const float stride = (float)(8 << s);
+    const float c = (sigmoid_f(tc) + (float)((k & 1) ? gy : gx)) * stride;
+    const float e = expf(ts) * g.anchors[(s * g.A + a) * 2 + (k & 1)];
+    const float v = ((k < 2) ? c - e / 2 : c + e / 2) / S;
+    return fminf(fmaxf(v, 0.0f), 1.0f);
+}
+
+// One candidate on 16 lanes (j = lane in the group): softmax over the classes x sigmoid(objectness), arg-max with numpy's
+// first-maximum rule, box decode (models/yolo_nano.py:253-261, 308-330, 362-367).  row = the pixel's raw head values
+// [A obj | A*C classes | A*4 box]; (gx, gy) = the cell.  The score of class c is p_c = e_c / sum * obj with e_c = exp(x_c - max):
+// p is monotone in e and the maximal e is exactly 1, so unless another class sits within 1e-5 of the maximum (or the product
+// underflows) the winner is the first class with e == 1 and its score 1 / sum * obj — ONE division per candidate; any wavefront
+// holding a near-tie takes the general path that evaluates every p_c (identical results, pinned by the parity suite).
+template <bool FULL, int KMAX>
+__device__ __forceinline__ void decode_candidate(const GridInfo& g, const float* row, int i, int s, int gx, int gy, int a, int j, float conf_thresh,
+                                                 float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
+                                                 float* __restrict__ all_class)
+{
+    const float* cl = row + g.A + a * g.C;
+    // every load of the candidate is issued before any is used: objectness, this lane's class slice (clamped index,
+    // -inf through an opaque mask for the slots past C) and one of the four box values
+    const float obj_raw = row[a];
+    const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = j + 16 * k;
+        unsigned mk = c < g.C ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(mk));
+        const unsigned bits = __float_as_uint(cl[c < g.C ? c : g.C - 1]);
+        v[k] = __uint_as_float((bits & mk) | (0xff800000u & ~mk));       // -inf
+    }
+    const float obj = sigmoid_f(obj_raw);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, v[k]);
+    mx = group16_max(mx);
+    float sum = 0.0f;
+    bool general = FULL;
+    int first = 0x7fffffff;
+#pragma unroll
+    for (int k = KMAX - 1; k >= 0; --k) {
+        const int c = j + 16 * k;
+        v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
+        if (v[k] == 1.0f) first = c;                                      // descending k: ends at this lane's lowest such class
+        general = general || (v[k] < 1.0f && v[k] > 0.99999f);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) sum += v[k];
+    sum = group16_sum(sum);
+    float sc = 1.0f / sum * obj;
+    general = general || !(sc > 1e-30f);
+    int cbest;
+    if (__any(general)) {
+        unsigned long long best = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = j + 16 * k;
+            if (c < g.C) {
+                const float p = v[k] / sum * obj;
+                if (FULL) all_class[(size_t)i * g.C + c] = p;
+                const unsigned long long key = ((unsigned long long)f32_order_bits(p) << 32) | (unsigned)(0x7fffffff - c);   // first max wins ties
+                best = key > best ? key : best;
+            }
+        }
+        if (!FULL) best = group16_max_u64(best);
+        const unsigned ub = (unsigned)(best >> 32);
+        sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
+        cbest = (int)(0x7fffffff - (unsigned)(best & 0xffffffffu));
+    } else {
+        cbest = group16_min_i(first);
+    }
+    // lane j evaluates coordinate j & 3 from box values (j & 1) and 2 + (j & 1) of its row (row_newbcast: lane n of the row to all)
+    const float tc = (j & 1) ? dpp_f<0x151>(tbox) : dpp_f<0x150>(tbox), ts = (j & 1) ? dpp_f<0x153>(tbox) : dpp_f<0x152>(tbox);
+    const float coord = decode_coord(g, s, gx, gy, a, tc, ts, (float)g.S, j & 3);
+    if (j < 4) boxes[(size_t)i * 4 + j] = coord;
+    if (!FULL && j == 0) {
+        scores[i] = sc;
+        cls[i] = (sc >= conf_thresh) ? cbest : -1;
+    }
+}
+
 template <bool FULL, int KMAX>
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
                                                       GridInfo g, int B, float conf_thresh,
@@ -109,60 +211,63 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
         int s, cell, a;
         cand_location(g, n, s, cell, a);                                  // candidate order of models/yolo_nano.py:308-330
         const float* head = s == 0 ? h0 : (s == 1 ? h1 : h2);
-        const float* row = head + ((size_t)b * g.hw[s] + cell) * HC;
-        const float* cl = row + g.A + a * g.C;
-        // every load of the candidate is issued before any is used: objectness, this lane's class slice (clamped index,
-        // -inf through an opaque mask for the slots past C) and one of the four box values (gathered by lane 0 below)
-        const float obj_raw = row[a];
-        const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
-        float v[KMAX];
+        const int gy = cell / g.w[s], gx = cell - gy * g.w[s];
+        decode_candidate<FULL, KMAX>(g, head + ((size_t)b * g.hw[s] + cell) * HC, i, s, gx, gy, a, j, conf_thresh, boxes, scores, cls, all_class);
+    }
+}
+
+// The last pointwise conv of a detection head (models/yolo_nano.py:299-301, K = 96 -> A(5+C) columns) and the candidate decode
+// of its scale (:308-330, 362-367) in one kernel: the raw head tile of 32 pixels never leaves the CU.  GEMM = gemm_split_tile as
+// one 32 x (128*NT) block (all columns of a pixel), bias added into an LDS tile [32][128*NT], then decode_candidate — the code
+// the standalone decode_kernel runs, 16 lanes per candidate — reads its row from LDS instead of HBM: results are bit-identical to
+// head GEMM + decode_kernel (the parity suite pins that), the 4*A(5+C) bytes per pixel of raw head are neither written nor re-read.
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g, int scale, float conf_thresh,
+                                                           float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls, int dbg)
+{
+    constexpr int BM = 32, BN = 128 * NT, LD = BN + 4;
+    constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2;
+    __shared__ __attribute__((aligned(16))) c3h16 smem[GEMM_HALVES > RAW_HALVES ? GEMM_HALVES : RAW_HALVES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = (int)(((blockIdx.x & 7u) * (gridDim.x >> 3)) + (blockIdx.x >> 3)) * BM;      // XCD x streams a contiguous run of rows
+    if (m0 >= a.M) return;
+    f32x16 acc[NT];
+    if (dbg & 1) {
+        for (int nt = 0; nt < NT; ++nt) for (int r = 0; r < 16; ++r) acc[nt][r] = 0.01f * (float)(r + lane);
+    } else
+    gemm_split_tile<1, 4, NT>(a, smem, m0, 0, acc);
+    __syncthreads();                                        // every wave is past its last operand read: the raw tile reuses the space
+    float* raw = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int c = j + 16 * k;
-            unsigned mk = c < g.C ? 0xffffffffu : 0u;
-            asm volatile("" : "+v"(mk));
-            const unsigned bits = __float_as_uint(cl[c < g.C ? c : g.C - 1]);
-            v[k] = __uint_as_float((bits & mk) | (0xff800000u & ~mk));       // -inf
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wave * NT * 32 + nt * 32 + l31;
+        const float bias = a.bias[n < a.Npad ? n : 0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + n] = acc[nt][r] + bias;
+    }
+    __syncthreads();
+    if (dbg & 2) return;
+    const int j = t & 15;
+    const int ncand = BM * g.A;
+    // candidate c = row * A + anchor, 16 per pass: (row, anchor) advance by 16 without dividing
+    int c = t >> 4, row = c / g.A, an = c - row * g.A;
+    const int drow = 16 / g.A, dan = 16 - drow * g.A;
+    int m = m0 + row;
+    int b = m / g.hw[scale], cell = m - b * g.hw[scale];
+    int gy = cell / g.w[scale], gx = cell - gy * g.w[scale];
+    for (; c < ncand; c += 16) {
+        if (m >= a.M) break;                                // uniform per 16-lane group; later passes only hold later rows
+        const int i = b * g.N + g.off[scale] + cell * g.A + an;
+        decode_candidate<false, KMAX>(g, raw + row * LD, i, scale, gx, gy, an, j, conf_thresh, boxes, scores, cls, nullptr);
+        an += dan;
+        int adv = drow;
+        if (an >= g.A) { an -= g.A; ++adv; }
+        row += adv; m += adv;
+        for (int q = 0; q < adv; ++q) {                     // adv <= 16 / A + 1 pixels forward in raster order, across image boundaries
+            if (++gx == g.w[scale]) { gx = 0; if (++gy == g.w[scale]) { gy = 0; ++b; } }
         }
-        const float obj = sigmoid_f(obj_raw);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, v[k]);
-        mx = group16_max(mx);
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int c = j + 16 * k;
-            v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
-            sum += v[k];
-        }
-        sum = group16_sum(sum);
-        unsigned long long best = 0;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int c = j + 16 * k;
-            if (c < g.C) {
-                const float p = v[k] / sum * obj;
-                if (FULL) all_class[(size_t)i * g.C + c] = p;
-                const unsigned long long key = ((unsigned long long)f32_order_bits(p) << 32) | (unsigned)(0x7fffffff - c);   // first max wins ties
-                best = key > best ? key : best;
-            }
-        }
-        if (!FULL) best = group16_max_u64(best);
-        float t4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t4[k] = __shfl(tbox, (threadIdx.x & 48) + k);      // lanes 0..3 of this 16-lane group
-        if (j == 0) {
-            float box[4];
-            decode_one(g, s, cell, a, t4, (float)g.S, box, true);
-            *reinterpret_cast<float4*>(boxes + (size_t)i * 4) = make_float4(box[0], box[1], box[2], box[3]);
-            if (!FULL) {
-                const unsigned ub = (unsigned)(best >> 32);
-                const float sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
-                scores[i] = sc;
-                cls[i] = (sc >= conf_thresh) ? (int)(0x7fffffff - (unsigned)(best & 0xffffffffu)) : -1;
-            }
-        }
+        cell = gy * g.w[scale] + gx;
     }
 }
 
@@ -191,6 +296,25 @@ void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, f
                         float* boxes, float* scores, int32_t* cls, hipStream_t s)
 {
     launch_decode<false>(heads, g, B, conf_thresh, boxes, scores, cls, nullptr, s);
+}
+
+bool head_decode_supported(const GemmArgs& a, const GridInfo& g)
+{
+    return a.Wsh && a.Wsl && !a.pass && a.act == 0 && a.Npad <= 256 && g.A * (5 + g.C) <= a.Npad && g.C <= 80 && a.M > 0;
+}
+
+void launch_head_decode(const GemmArgs& a, const GridInfo& g, int scale, float conf_thresh,
+                        float* boxes, float* scores, int32_t* cls, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)(((a.M + 31) / 32 + 7) & ~7);
+    const dim3 grid(blocks), blk(256);
+    static const int dbg = getenv("YN_HD_DBG") ? atoi(getenv("YN_HD_DBG")) : 0;
+#define YN_HD(nt, kmax) hipLaunchKernelGGL((head_decode_kernel<nt, kmax>), grid, blk, 0, s, a, g, scale, conf_thresh, boxes, scores, cls, dbg)
+    if (a.Npad > 128) YN_HD(2, 5);
+    else if (g.C <= 16) YN_HD(1, 1);
+    else if (g.C <= 32) YN_HD(1, 2);
+    else YN_HD(1, 5);
+#undef YN_HD
 }
 
 // YOLONano.decode_boxes: txtytwth [B, sumHW, A, 4] -> xyxy pixels [B, N, 4]
@@ -440,6 +564,11 @@ __device__ __forceinline__ bool plain_box(const float4 b)
     return fabsf(b.x) < 1e7f && fabsf(b.y) < 1e7f && fabsf(b.z) < 1e7f && fabsf(b.w) < 1e7f;
 }
 
+// min / max as plain v_min_f32 / v_max_f32: fminf / fmaxf on operands loaded from LDS cost a canonicalising v_max each (4.5 of the
+// 24 VALU instructions per pair in the tile loop below); NaN operands only reach the exact path (union is NaN, not > 0)
+__device__ __forceinline__ float vmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <bool DIOU>
 __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh,
                                             u64* __restrict__ M, float4* cbox, float* carea)
@@ -469,18 +598,15 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
             // t1 live columns): the reference's own arithmetic up to inter and union, then the division-free decision of
             // suppressed() — inter vs thresh*union with a 1e-5 guard band.  Pairs inside the band (or with union <= 0 / NaN)
             // are the only ones left for the exact path below.
-            const f32x2 ilo = {bx.x, bx.y}, ihi = {bx.z, bx.w};
-            const f32x2 tiny = {1e-28f, 1e-28f};
             u64 sure = 0, unsure = 0;
             for (int t8 = 0; t8 < t1; t8 += 8) {
                 unsigned s8 = 0, u8 = 0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float4 bt = cbox[t8 + u];
-                    const f32x2 jlo = {bt.x, bt.y}, jhi = {bt.z, bt.w};
-                    const f32x2 d = __builtin_elementwise_min(ihi, jhi) - __builtin_elementwise_max(ilo, jlo);
-                    const f32x2 wh = __builtin_elementwise_max(tiny, d);
-                    const float inter = wh.x * wh.y;
+                    const float w = vmax_raw(1e-28f, vmin_raw(bx.z, bt.z) - vmax_raw(bx.x, bt.x));
+                    const float h = vmax_raw(1e-28f, vmin_raw(bx.w, bt.w) - vmax_raw(bx.y, bt.y));
+                    const float inter = w * h;
                     const float un = (ar + carea[t8 + u]) - inter;
                     const float pth = thresh * un;
                     const bool dec = un > 0.0f && pth > 1e-30f;
@@ -515,7 +641,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
 {
     __shared__ float4 cbox_all[4][64];
     __shared__ float carea_all[4][64];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform for the compiler too: tile indices, masks and ballots stay in SGPRs
     float4* cbox = cbox_all[wave];
     float* carea = carea_all[wave];
     const int b = blockIdx.y;
@@ -763,12 +889,15 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     set_sort_attr();
     const int large_cap = wk.large_cap;
     auto mark = [&](const char* k) { if (hook && hook->fn) hook->fn(hook->ctx, k); };
+    // YN_DBG_NMS_SKIP (timing ablation only, outputs are wrong): bit0 sort, bit1 matrix, bit2 resolve
+    static const int skip = getenv("YN_DBG_NMS_SKIP") ? atoi(getenv("YN_DBG_NMS_SKIP")) : 0;
     mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
                        wk.large_list, large_cap, YN_SORT_SMALL);
     float4* sbox = reinterpret_cast<float4*>(wk.sbox);
     u64* M = reinterpret_cast<u64*>(wk.matrix);
     mark("sort_kernel");
+    if (!(skip & 1)) {
     hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                        N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0);
     if (N > YN_SORT_SMALL)                                  // only the (few) listed large segments get a 128 KB-LDS workgroup
@@ -777,14 +906,16 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap);
+    }
     int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
     if (G < 32) G = 32;
     if (G > 2048) G = 2048;
     mark(diou ? "matrix_kernel<true>" : "matrix_kernel<false>");
-    if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
+    if (skip & 2) {}
+    else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
     else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
     mark("resolve_kernel");
-    hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
+    if (!(skip & 4)) hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
     mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }

@@ -88,6 +88,10 @@ void launch_decode_boxes(const float* txtytwth, const GridInfo& g, int B, float*
 // candidates from raw heads: per candidate best score / class / box
 void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
                         float* boxes, float* scores, int32_t* cls, hipStream_t s);
+// the last pointwise conv of head `scale` + the decode of its candidates in one kernel (split-f16 packs, A(5+C) <= 256 columns)
+bool head_decode_supported(const GemmArgs& a, const GridInfo& g);
+void launch_head_decode(const GemmArgs& a, const GridInfo& g, int scale, float conf_thresh,
+                        float* boxes, float* scores, int32_t* cls, hipStream_t s);
 // candidates from (all_local, all_conf): argmax + threshold (models/yolo_nano.py:253-261)
 void launch_argmax_cand(const float* all_local, const float* all_conf, int B, int N, int C, float conf_thresh,
                         float* boxes, float* scores, int32_t* cls, hipStream_t s);
