@@ -128,32 +128,29 @@ __device__ __forceinline__ float decode_coord(const GridInfo& g, int s, int gx, 
 // p is monotone in e and the maximal e is exactly 1, so unless another class sits within 1e-5 of the maximum (or the product
 // underflows) the winner is the first class with e == 1 and its score 1 / sum * obj — ONE division per candidate; any wavefront
 // holding a near-tie takes the general path that evaluates every p_c (identical results, pinned by the parity suite).
+// Class part of one candidate on its 16 lanes.  Returns true when this WAVEFRONT took the general path — then `sc` / `cbest` are the
+// final score and class (needs the objectness) — else the caller finishes with score = 1 / sum * sigmoid(obj_raw), class = cbest.
+// The general path also covers obj_raw < -60: sigmoid below 1e-26, where score = obj / sum (sum <= C) may underflow to equal products.
 template <bool FULL, int KMAX>
-__device__ __forceinline__ void decode_candidate(const GridInfo& g, const float* row, int i, int s, int gx, int gy, int a, int j, float conf_thresh,
-                                                 float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
-                                                 float* __restrict__ all_class)
+__device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, int i, int a, int j, float obj_raw,
+                                           float& sum_out, float& sc, int& cbest, float* __restrict__ all_class)
 {
     const float* cl = row + g.A + a * g.C;
-    // every load of the candidate is issued before any is used: objectness, this lane's class slice (clamped index,
-    // -inf through an opaque mask for the slots past C) and one of the four box values
-    const float obj_raw = row[a];
-    const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
     float v[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int k = 0; k < KMAX; ++k) {                                      // clamped index, -inf through an opaque mask for the slots past C
         const int c = j + 16 * k;
         unsigned mk = c < g.C ? 0xffffffffu : 0u;
         asm volatile("" : "+v"(mk));
         const unsigned bits = __float_as_uint(cl[c < g.C ? c : g.C - 1]);
         v[k] = __uint_as_float((bits & mk) | (0xff800000u & ~mk));       // -inf
     }
-    const float obj = sigmoid_f(obj_raw);
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) mx = fmaxf(mx, v[k]);
     mx = group16_max(mx);
     float sum = 0.0f;
-    bool general = FULL;
+    bool general = FULL || !(obj_raw >= -60.0f);
     int first = 0x7fffffff;
 #pragma unroll
     for (int k = KMAX - 1; k >= 0; --k) {
@@ -165,10 +162,9 @@ __device__ __forceinline__ void decode_candidate(const GridInfo& g, const float*
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) sum += v[k];
     sum = group16_sum(sum);
-    float sc = 1.0f / sum * obj;
-    general = general || !(sc > 1e-30f);
-    int cbest;
+    sum_out = sum;
     if (__any(general)) {
+        const float obj = sigmoid_f(obj_raw);
         unsigned long long best = 0;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
@@ -184,9 +180,23 @@ __device__ __forceinline__ void decode_candidate(const GridInfo& g, const float*
         const unsigned ub = (unsigned)(best >> 32);
         sc = __uint_as_float((ub & 0x80000000u) ? (ub & 0x7fffffffu) : ~ub);
         cbest = (int)(0x7fffffff - (unsigned)(best & 0xffffffffu));
-    } else {
-        cbest = group16_min_i(first);
+        return true;
     }
+    cbest = group16_min_i(first);
+    return false;
+}
+
+template <bool FULL, int KMAX>
+__device__ __forceinline__ void decode_candidate(const GridInfo& g, const float* row, int i, int s, int gx, int gy, int a, int j, float conf_thresh,
+                                                 float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
+                                                 float* __restrict__ all_class)
+{
+    // the candidate's loads are issued before any is used: objectness, one of the four box values, the class slice (cand_class)
+    const float obj_raw = row[a];
+    const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
+    float sum, sc;
+    int cbest;
+    if (!cand_class<FULL, KMAX>(g, row, i, a, j, obj_raw, sum, sc, cbest, all_class)) sc = 1.0f / sum * sigmoid_f(obj_raw);
     // lane j evaluates coordinate j & 3 from box values (j & 1) and 2 + (j & 1) of its row (row_newbcast: lane n of the row to all)
     const float tc = (j & 1) ? dpp_f<0x151>(tbox) : dpp_f<0x150>(tbox), ts = (j & 1) ? dpp_f<0x153>(tbox) : dpp_f<0x152>(tbox);
     const float coord = decode_coord(g, s, gx, gy, a, tc, ts, (float)g.S, j & 3);
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g
                                                            float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls, int dbg)
 {
     constexpr int BM = 32, BN = 128 * NT, LD = BN + 4;
-    constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2;
+    constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2 + BM * 8 * 4;     // raw tile + [BM * A <= BM * 8] (sum, class)
     __shared__ __attribute__((aligned(16))) c3h16 smem[GEMM_HALVES > RAW_HALVES ? GEMM_HALVES : RAW_HALVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -248,26 +258,43 @@ __global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g
     }
     __syncthreads();
     if (dbg & 2) return;
+    // Decode in three passes so that no per-candidate scalar work is replicated over 16 lanes:
+    //   A  16 lanes per candidate, 16 candidates per pass: the class softmax statistics (cand_class) -> LDS
+    //   B  one thread per candidate: objectness sigmoid, score, threshold -> scores / cls
+    //   C  one thread per box coordinate (decode_coord) -> boxes
+    // the arithmetic per value is decode_candidate's, so the outputs equal head GEMM + decode_kernel bit for bit.
+    float* st_sum = reinterpret_cast<float*>(raw + BM * LD);              // [BM * A] sum of exponentials, or the final score (general path)
+    int* st_cls = reinterpret_cast<int*>(st_sum + BM * g.A);              // [BM * A] class, bit 31 = st_sum holds the final score
     const int j = t & 15;
-    const int ncand = BM * g.A;
-    // candidate c = row * A + anchor, 16 per pass: (row, anchor) advance by 16 without dividing
-    int c = t >> 4, row = c / g.A, an = c - row * g.A;
-    const int drow = 16 / g.A, dan = 16 - drow * g.A;
-    int m = m0 + row;
-    int b = m / g.hw[scale], cell = m - b * g.hw[scale];
-    int gy = cell / g.w[scale], gx = cell - gy * g.w[scale];
-    for (; c < ncand; c += 16) {
-        if (m >= a.M) break;                                // uniform per 16-lane group; later passes only hold later rows
+    const int ncand = min(BM, a.M - m0) * g.A;
+    for (int c = t >> 4; c < ncand; c += 16) {
+        const int row = c / g.A, an = c - row * g.A;
+        float sum, sc;
+        int cbest;
+        const float* rp = raw + row * LD;
+        const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
+        if (j == 0) { st_sum[c] = fin ? sc : sum; st_cls[c] = fin ? (cbest | (int)0x80000000) : cbest; }
+    }
+    __syncthreads();
+    for (int q = t; q < 5 * ncand; q += 256) {
+        // items [0, ncand): scores; [ncand, 5 ncand): coordinates
+        const bool is_score = q < ncand;
+        const int c = is_score ? q : (q - ncand) >> 2, k = (q - ncand) & 3;
+        const int row = c / g.A, an = c - row * g.A;
+        const int m = m0 + row;
+        const int b = m / g.hw[scale], cell = m - b * g.hw[scale];
         const int i = b * g.N + g.off[scale] + cell * g.A + an;
-        decode_candidate<false, KMAX>(g, raw + row * LD, i, scale, gx, gy, an, j, conf_thresh, boxes, scores, cls, nullptr);
-        an += dan;
-        int adv = drow;
-        if (an >= g.A) { an -= g.A; ++adv; }
-        row += adv; m += adv;
-        for (int q = 0; q < adv; ++q) {                     // adv <= 16 / A + 1 pixels forward in raster order, across image boundaries
-            if (++gx == g.w[scale]) { gx = 0; if (++gy == g.w[scale]) { gy = 0; ++b; } }
+        const float* rp = raw + row * LD;
+        if (is_score) {
+            const int cw = st_cls[c];
+            const float sc = (cw < 0) ? st_sum[c] : 1.0f / st_sum[c] * sigmoid_f(rp[an]);
+            scores[i] = sc;
+            cls[i] = (sc >= conf_thresh) ? (cw & 0x7fffffff) : -1;
+        } else {
+            const int gy = cell / g.w[scale], gx = cell - gy * g.w[scale];
+            const float* tb = rp + g.A * (1 + g.C) + an * 4;
+            boxes[(size_t)i * 4 + k] = decode_coord(g, scale, gx, gy, an, tb[k & 1], tb[2 + (k & 1)], (float)g.S, k);
         }
-        cell = gy * g.w[scale] + gx;
     }
 }
 
@@ -300,7 +327,7 @@ void launch_decode_cand(const float* const heads[3], const GridInfo& g, int B, f
 
 bool head_decode_supported(const GemmArgs& a, const GridInfo& g)
 {
-    return a.Wsh && a.Wsl && !a.pass && a.act == 0 && a.Npad <= 256 && g.A * (5 + g.C) <= a.Npad && g.C <= 80 && a.M > 0;
+    return a.Wsh && a.Wsl && !a.pass && a.act == 0 && a.Npad <= 256 && g.A * (5 + g.C) <= a.Npad && g.C <= 80 && g.A <= 8 && a.M > 0;
 }
 
 void launch_head_decode(const GemmArgs& a, const GridInfo& g, int scale, float conf_thresh,
@@ -596,11 +623,13 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
         if (!DIOU) {
             // Dense, branch-free pass over the chunk's columns (uniform loop, broadcast LDS reads, 8 columns per step, only the
             // t1 live columns): the reference's own arithmetic up to inter and union, then the division-free decision of
-            // suppressed() — inter vs thresh*union with a 1e-5 guard band.  Pairs inside the band (or with union <= 0 / NaN)
-            // are the only ones left for the exact path below.
+            // suppressed() — inter vs thresh*union with a 1e-5 guard band.  Groups of 8 columns holding a pair inside the band (or
+            // with union <= 0 / NaN) are re-evaluated by the exact path below (which agrees with the sure decisions by construction).
             u64 sure = 0, unsure = 0;
+            const bool tpos = thresh > 0.0f;               // then pth > 1e-30 already implies union > 0
             for (int t8 = 0; t8 < t1; t8 += 8) {
-                unsigned s8 = 0, u8 = 0;
+                unsigned s8 = 0;
+                bool open = false;                          // some pair of this group of 8 is undecided: the whole group goes to the exact path
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float4 bt = cbox[t8 + u];
@@ -609,14 +638,13 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
                     const float inter = w * h;
                     const float un = (ar + carea[t8 + u]) - inter;
                     const float pth = thresh * un;
-                    const bool dec = un > 0.0f && pth > 1e-30f;
-                    const bool st = dec && inter > pth * 1.00001f;
-                    const bool sf = dec && inter < pth * 0.99999f;
-                    s8 |= st ? (1u << u) : 0u;
-                    u8 |= (st || sf) ? 0u : (1u << u);
+                    const bool dec = tpos ? pth > 1e-30f : false;
+                    const bool over = inter > pth * 1.00001f, under = inter < pth * 0.99999f;
+                    s8 |= (dec && over) ? (1u << u) : 0u;
+                    open = open || !(dec && (over || under));
                 }
                 sure |= (u64)s8 << t8;
-                unsure |= (u64)u8 << t8;
+                unsure |= open ? (0xffull << t8) : 0ull;
             }
             mask = sure & valid;
             slow = unsure & valid;
