@@ -699,30 +699,116 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
 #define YN_RESOLVE_MAX_T 2048
 struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; int kidx[64]; int nk; };
 
-__device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
-                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+// Everything a band reads from memory — its diagonal word and candidate id (wave 0), its off-diagonal words (all threads:
+// thread -> row tid/4, columns 1 + (tid&3) + 4u) — is requested TWO bands ahead, into one of three register sets: a band's own work
+// is a few hundred cycles, a load of the freshly written matrix ~3 000 (it misses L2), and with a look-ahead of one band (the first
+// version) every band waited for its loads: 132 k cycles for the 39 bands of the benchmark's largest segment, 37 serial steps in all
+// (81 -> 66 us; issuing the loads unconditionally at clamped addresses to keep the vmcnt bookkeeping static was slower: 104 us).
+template <int NB>
+struct ResolvePre { u64 nb[NB]; u64 diag; int id; };
+
+template <int NB>
+__device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_t* __restrict__ ids, int n, const u64* __restrict__ M, int T, int ri,
+                                                 int lane, int wave, int pr, int pc)
 {
-    constexpr int NB = 16;                                  // prefetched band words per thread: covers T <= 64 (n <= 4096)
+    if (ri >= T) return;
+    const int W = T - ri;
+    if (wave == 0) {
+        p.diag = M[band_off(ri, T) + (size_t)lane * W];
+        p.id = (ri * 64 + lane < n) ? ids[ri * 64 + lane] : 0;
+    }
+    const size_t boff = band_off(ri, T) + (size_t)pr * W;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int w = 1 + pc + 4 * u;
+        p.nb[u] = (w < W) ? M[boff + w] : 0ull;
+    }
+}
+
+// wave 0: which boxes of chunk ri survive (-> L.keepm, L.kidx, L.nk; keep flags / pick list)
+__device__ __forceinline__ void resolve_diag(u64 diag, int id, int n, int ri, int lane, int picked,
+                                             int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+{
+    const int cnt = min(64, n - ri * 64);
+    const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    const u64 alive0 = validm & ~L.rem[ri];
+    u64 keepm = alive0;
+    // only the alive rows that suppress an alive column take a serial step (none in the common case): a row's word only holds
+    // later columns, so whatever is still alive once those rows are through is kept
+    u64 work = __ballot(((alive0 >> lane) & 1ull) && (diag & alive0));
+    if (work != 0ull) {
+        const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+        u64 alive = alive0;
+        while (work) {
+            const int i = __ffsll((long long)work) - 1;                                  // alive at its turn: kept
+            const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
+            const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+            alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+            work &= alive & ~(1ull << i);                                                // bits <= i of later words are zero
+        }
+        keepm = alive;
+    }
+    if ((keepm >> lane) & 1ull) {
+        const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
+        L.kidx[rank] = lane;
+        if (keep_flags) keep_flags[id] = 1;
+        if (pick_list) pick_list[picked + rank] = id;
+    }
+    if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; }
+}
+
+template <int NB>
+__device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                             int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = (n + 63) >> 6;
+    const int pr = tid >> 2, pc = tid & 3;
+    ResolvePre<NB> P0, P1, P2;
+    resolve_prefetch<NB>(P0, ids, n, M, T, 0, lane, wave, pr, pc);
+    resolve_prefetch<NB>(P1, ids, n, M, T, 1, lane, wave, pr, pc);
+    __syncthreads();
+    int picked = 0;
+#define YN_BAND(P, PNEXT2, ri_)                                                                              \
+    {                                                                                                        \
+        const int ri = (ri_);                                                                                \
+        resolve_prefetch<NB>(PNEXT2, ids, n, M, T, ri + 2, lane, wave, pr, pc);                              \
+        if (wave == 0) resolve_diag(P.diag, P.id, n, ri, lane, picked, keep_flags, pick_list, L);            \
+        __syncthreads();                                                                                     \
+        picked += L.nk;                                                                                      \
+        if ((L.keepm >> pr) & 1ull) {                                                                        \
+            _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                   \
+                if (P.nb[u]) atomicOr(&L.rem[ri + 1 + pc + 4 * u], P.nb[u]);                                 \
+        }                                                                                                    \
+        __syncthreads();                                                                                     \
+    }
+    for (int r0 = 0; r0 < T; r0 += 3) {
+        YN_BAND(P0, P2, r0)
+        if (r0 + 1 < T) YN_BAND(P1, P0, r0 + 1)
+        if (r0 + 2 < T) YN_BAND(P2, P1, r0 + 2)
+    }
+#undef YN_BAND
+    return picked;
+}
+
+__device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int T = (n + 63) >> 6;
     for (int w = tid; w < T; w += nthr) L.rem[w] = 0;
+    if (nthr == 256) {                                      // the band words of a row fit four threads' register sets
+        if (T <= 17) return resolve_bands<4>(ids, n, M, keep_flags, pick_list, L);
+        if (T <= 33) return resolve_bands<8>(ids, n, M, keep_flags, pick_list, L);
+        if (T <= 65) return resolve_bands<16>(ids, n, M, keep_flags, pick_list, L);
+    }
+    // very large segments (n > 4160): no register staging, the kept rows' words are read when they are needed
     u64 diag_next = 0;
-    if (wave == 0) diag_next = M[(size_t)lane * T];
-    // band words of chunk 0 (row = p / Wr, col = 1 + p % Wr), issued now, consumed after the diagonal is resolved
-    u64 nb[NB];
-    // thread -> row r = tid/4, columns w = 1 + (tid&3) + 4u  (no integer divisions on the serial path)
-    const int pr = tid >> 2, pc = tid & 3;
-    auto prefetch_band = [&](int ri) {
-        const int W = T - ri;
-        const size_t boff = band_off(ri, T) + (size_t)pr * W;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int w = 1 + pc + 4 * u;
-            nb[u] = (w < W) ? M[boff + w] : 0ull;
-        }
-    };
-    const bool fits = (T - 1) <= NB * 4 && nthr == 256;
-    if (fits) prefetch_band(0);
+    int id_next = 0;
+    if (wave == 0) {
+        diag_next = M[(size_t)lane * T];
+        id_next = lane < n ? ids[lane] : 0;
+    }
     __syncthreads();
     int picked = 0;
     for (int ri = 0; ri < T; ++ri) {
@@ -730,51 +816,22 @@ __device__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64
         const int W = T - ri;
         if (wave == 0) {
             const u64 diag = diag_next;
-            if (ri + 1 < T) diag_next = M[band_off(ri + 1, T) + (size_t)lane * (W - 1)];
-            const int cnt = min(64, n - ri * 64);
-            const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-            const u64 alive0 = validm & ~L.rem[ri];
-            u64 keepm = alive0;
-            // rows that are alive and suppress an alive column; none (the common case) => everything alive is kept
-            if (__ballot(((alive0 >> lane) & 1ull) && (diag & alive0)) != 0ull) {
-                const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
-                u64 alive = alive0;
-                keepm = 0;
-                while (alive) {
-                    const int i = __ffsll((long long)alive) - 1;
-                    keepm |= 1ull << i;
-                    const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);     // (unsigned): no sign extension
-                    const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-                    alive &= ~((((u64)hi_i << 32) | (u64)lo_i) | (1ull << i));
-                }
+            const int id = id_next;
+            if (ri + 1 < T) {
+                diag_next = M[band_off(ri + 1, T) + (size_t)lane * (W - 1)];
+                id_next = ((ri + 1) * 64 + lane < n) ? ids[(ri + 1) * 64 + lane] : 0;
             }
-            if ((keepm >> lane) & 1ull) {
-                const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
-                const int id = ids[ri * 64 + lane];
-                L.kidx[rank] = lane;
-                if (keep_flags) keep_flags[id] = 1;
-                if (pick_list) pick_list[picked + rank] = id;
-            }
-            if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; }
+            resolve_diag(diag, id, n, ri, lane, picked, keep_flags, pick_list, L);
         }
         __syncthreads();
         const int nk = L.nk;
         picked += nk;
         const int Wr = W - 1;                               // later chunks of this band
-        if (fits) {
-            if ((L.keepm >> pr) & 1ull) {
-#pragma unroll
-                for (int u = 0; u < NB; ++u)
-                    if (nb[u]) atomicOr(&L.rem[ri + 1 + pc + 4 * u], nb[u]);
-            }
-            if (ri + 1 < T) prefetch_band(ri + 1);
-        } else {
-            const int total = nk * Wr;
-            for (int p = tid; p < total; p += nthr) {
-                const int k = p / Wr, w = 1 + (p - k * Wr);
-                const u64 v = M[boff + (size_t)L.kidx[k] * W + w];
-                if (v) atomicOr(&L.rem[ri + w], v);
-            }
+        const int total = nk * Wr;
+        for (int q = tid; q < total; q += nthr) {
+            const int k = q / Wr, w = 1 + (q - k * Wr);
+            const u64 v = M[boff + (size_t)L.kidx[k] * W + w];
+            if (v) atomicOr(&L.rem[ri + w], v);
         }
         __syncthreads();
     }
