@@ -626,10 +626,13 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
             // suppressed() — inter vs thresh*union with a 1e-5 guard band.  Groups of 8 columns holding a pair inside the band (or
             // with union <= 0 / NaN) are re-evaluated by the exact path below (which agrees with the sure decisions by construction).
             u64 sure = 0, unsure = 0;
-            const bool tpos = thresh > 0.0f;               // then pth > 1e-30 already implies union > 0
+            // guard band folded into the threshold: hi = fl(u * fl(thr * 1.00001)) >= thr * u * (1 + 0.9e-5), lo likewise below; lo > 1e-30
+            // (thr > 0) also says union > 0.  thr <= 0: nothing is decided here, every group goes to the exact path.
+            const u64 tmask = thresh > 0.0f ? ~0ull : 0ull;
+            const float c_hi = thresh * 1.00001f, c_lo = thresh * 0.99999f;
             for (int t8 = 0; t8 < t1; t8 += 8) {
-                unsigned s8 = 0;
-                bool open = false;                          // some pair of this group of 8 is undecided: the whole group goes to the exact path
+                unsigned s8 = 0;                            // bit 7-u = column t8+u surely suppressed (built by shift-in, reversed below)
+                unsigned nd = 0;                            // decided pairs of this lane in the group of 8
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float4 bt = cbox[t8 + u];
@@ -637,14 +640,24 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
                     const float h = vmax_raw(1e-28f, vmin_raw(bx.w, bt.w) - vmax_raw(bx.y, bt.y));
                     const float inter = w * h;
                     const float un = (ar + carea[t8 + u]) - inter;
-                    const float pth = thresh * un;
-                    const bool dec = tpos ? pth > 1e-30f : false;
-                    const bool over = inter > pth * 1.00001f, under = inter < pth * 0.99999f;
-                    s8 |= (dec && over) ? (1u << u) : 0u;
-                    open = open || !(dec && (over || under));
+                    const float hi = un * c_hi, lo = un * c_lo;
+                    const u64 dec = __ballot(lo > 1e-30f) & tmask;
+                    const u64 under = __ballot(inter < lo);
+                    // over = inter > hi.  s8 = 2 s8 + (over && dec): the compare lands in VCC, the wave masks combine on the scalar unit and
+                    // an add-with-carry shifts the bit in; nd += (over || under) && dec the same way — two VALU instructions per pair
+                    // where select + or per mask took five.
+                    u64 tmp;
+                    asm("v_cmp_gt_f32 vcc, %3, %4\n\t"
+                        "s_and_b64 %2, vcc, %5\n\t"
+                        "s_mov_b64 vcc, %2\n\t"
+                        "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                        "s_and_b64 vcc, %6, %5\n\t"
+                        "s_or_b64 vcc, vcc, %2\n\t"
+                        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+                        : "+v"(s8), "+v"(nd), "=&s"(tmp) : "v"(inter), "v"(hi), "s"(dec), "s"(under) : "vcc");
                 }
-                sure |= (u64)s8 << t8;
-                unsure |= open ? (0xffull << t8) : 0ull;
+                sure |= (u64)(__builtin_bitreverse32(s8) >> 24) << t8;
+                unsure |= (nd != 8u) ? (0xffull << t8) : 0ull;          // an undecided pair: the whole group goes to the exact path
             }
             mask = sure & valid;
             slow = unsure & valid;
