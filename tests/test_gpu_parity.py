@@ -812,3 +812,48 @@ def test_fused_head_decode_is_bit_identical(hcoco, hvoc, which, S, B):
     finally:
         h.fuse_decode(True)
         h.set_grid(old)
+
+
+@pytest.mark.parametrize("thresh", [0.5, 0.3, 0.75, 1e-6, 0.0])
+def test_nms_guard_band_stress_vs_oracle(hvoc, thresh):
+    """The matrix kernel decides most pairs without dividing (inter vs thresh*union with a 1e-5 guard band) and sends the rest through
+    the reference's own arithmetic.  Boxes built so that many pairs sit within 1e-7 ... 1e-3 of the threshold on either side, plus
+    degenerate (zero / negative extent), huge, denormal-sized and NaN boxes, must give the oracle's kept indices exactly."""
+    from oracle import oracle
+    rs = np.random.RandomState(11)
+    n = 900
+    base = rs.uniform(0.1, 0.6, (n, 2)).astype(np.float32)
+    wh = rs.uniform(0.05, 0.3, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([base, base + wh], 1).astype(np.float32)
+    t = max(thresh, 0.05)
+    # partners: box j = box i stretched in x so that IoU(i, j) = t * (1 + eps): same y extent, same x1, x2' = x1 + w / iou
+    for k in range(0, n - 1, 2):
+        eps = rs.choice([0.0, 1e-7, -1e-7, 3e-6, -3e-6, 2e-5, -2e-5, 1e-3, -1e-3])
+        iou = min(t * (1.0 + eps), 0.999)
+        boxes[k + 1] = boxes[k]
+        boxes[k + 1, 2] = np.float32(boxes[k, 0] + (boxes[k, 2] - boxes[k, 0]) / iou)
+    boxes[5] = [0.3, 0.3, 0.3, 0.3]                      # zero area
+    boxes[6] = [0.5, 0.5, 0.4, 0.4]                      # negative extent
+    boxes[7] = [-1e30, -1e30, 1e30, 1e30]                # area overflows to inf
+    boxes[8] = [0.2, 0.2, 0.2 + 1e-20, 0.2 + 1e-20]      # denormal area
+    boxes[9] = [np.nan, 0.1, 0.5, 0.5]
+    boxes[10] = [0.1, 0.1, np.inf, 0.5]
+    scores = rs.uniform(0.01, 1.0, n).astype(np.float32)
+    scores[::7] = scores[3]                              # ties
+    ref = oracle.nms(boxes, scores, thresh)
+    got = hvoc.nms(dev(boxes), dev(scores), thresh).cpu().numpy()
+    assert got.tolist() == list(ref)
+    # the same boxes through the batched per-class pipeline (matrix_kernel): one class per third of the boxes
+    C = hvoc.C if hasattr(hvoc, "C") else 20
+    conf = np.zeros((n, C), np.float32)
+    conf[np.arange(n), np.arange(n) % 3] = scores
+    hvoc.set_thresholds(0.001, thresh)
+    try:
+        rb, rsc, rc = oracle.postprocess(boxes, conf, 0.001, thresh)
+        out = hvoc.postprocess(dev(boxes)[None], dev(conf)[None])
+        k = int(out[4][0].item())
+        assert k == len(rsc)
+        assert np.array_equal(out[0][0, :k].cpu().numpy(), rb, equal_nan=True) and np.array_equal(out[1][0, :k].cpu().numpy(), rsc)
+        assert np.array_equal(out[2][0, :k].cpu().numpy().astype(np.int64), np.asarray(rc).astype(np.int64))
+    finally:
+        hvoc.set_thresholds(0.001, 0.5)
