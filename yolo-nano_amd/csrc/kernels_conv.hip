@@ -699,12 +699,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 // per tap through one LDS buffer with register prefetch.
 // -------------------------------------------------------------------------------------------------
 
+// The 96 input channels go through LDS in two HALVES of 48 (halo planes of 48 channels, then the nine taps on them, twice): 71 KB
+// per workgroup instead of 134 KB, so TWO workgroups share a CU and one's halo phase (HBM-bound) and epilogue overlap the other's tap
+// phase (LDS / MFMA-bound) — with one resident workgroup the three phases ran strictly one after the other.
 template <int NT>
-__global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
 {
-    constexpr int CIN = 96, KQ = CIN / 8, BM = 128, BN = 32 * NT, CSH = CIN + 8;      // halo row stride (halves): 208 bytes, conflict-free b128 reads
-    constexpr int WCH = KQ * BN * 8;                                                  // halves per weight plane per tap
-    constexpr int B_PER = (2 * KQ * BN + 255) / 256;                                  // 16-byte granules per thread per tap (hi and lo planes)
+    constexpr int CIN = 96, CH = 48, NH = CIN / CH, KQ = CH / 8, KQT = CIN / 8, BM = 128, BN = 32 * NT, CSH = CH + 8;   // halo row stride (halves): 112 bytes
+    constexpr int WCH = KQ * BN * 8;                                                  // halves per weight plane per (tap, half)
+    constexpr int B_PER = (2 * KQ * BN + 255) / 256;                                  // 16-byte granules per thread per (tap, half) (hi and lo planes)
     extern __shared__ __attribute__((aligned(16))) float c3s_smem[];
     const int W = a.W, H = a.H, HW = H * W;
     const int npix = BM + 2 * W + 2;
@@ -730,7 +733,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
 #endif
     YN_TS();
     c3h16x8 b_reg[B_PER];
-    auto prefetch_b = [&](int tap) {
+    auto prefetch_b = [&](int step) {                                                 // step = half * 9 + tap
+        const int half = step / 9, tap = step - half * 9;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int g = t + 256 * i;                                                // granule: plane (hi / lo), octet o, column n
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
             c3h16x8 v;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
-            if (g < 2 * KQ * BN) v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + (((size_t)tap * KQ + o) * a.Npad + n0 + n) * 8);
+            if (g < 2 * KQ * BN) v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + (((size_t)tap * KQT + half * KQ + o) * a.Npad + n0 + n) * 8);
             b_reg[i] = v;
         }
     };
@@ -756,9 +760,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
     //      smooth_1: W = 52, one block per CU): halo 19 k cycles, nine taps 31.7 k (486 MFMAs = 15.5 k), epilogue 9 k per 128-pixel tile.
     //      The halo phase is BANDWIDTH-bound, not latency-bound: 180 KB per tile (halo factor 1.83 at W = 52 + the up2 source) at the
     //      ~10 B/clk/CU every CU gets when all of them stream at once; 24 loads in flight per thread instead of 8 changed nothing ----
-    {
-        constexpr int U = 8, CQ = CIN / 4, PPL = 256 / CQ;
+    auto load_halo = [&](int half) {
+        constexpr int U = 8, CQ = CH / 4, PPL = 256 / CQ;
         const int cq = t % CQ, pl = t / CQ;
+        const int c0 = half * CH + 4 * cq;
         if (pl < PPL) {
             for (int i0 = pl; i0 < npix; i0 += PPL * U) {
                 float4 v[U], u2[U];
@@ -769,14 +774,14 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
                     v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     u2[u] = v[u];
                     if (i < npix && q >= 0 && q < a.M) {
-                        v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)q * CIN + 4 * cq);
+                        v[u] = *reinterpret_cast<const float4*>(a.in + (size_t)q * CIN + c0);
                         if (a.resample) {
                             const int b = q / HW, rem = q - b * HW;
                             const int y = rem / W, x = rem - y * W;
                             size_t p2;
                             if (a.resample == 1) p2 = ((size_t)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
                             else                 p2 = ((size_t)b * (H << 1) + (y << 1)) * (W << 1) + (x << 1);
-                            u2[u] = *reinterpret_cast<const float4*>(a.in2 + p2 * CIN + 4 * cq);
+                            u2[u] = *reinterpret_cast<const float4*>(a.in2 + p2 * CIN + c0);
                         }
                     }
                 }
@@ -794,7 +799,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
                 }
             }
         }
-    }
+    };
+    load_halo(0);
     YN_TS();
     stage_b();
 
@@ -819,8 +825,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
 
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) prefetch_b(tap + 1);
+    for (int step = 0; step < 9 * NH; ++step) {
+        const int tap = step % 9;
+        if (step + 1 < 9 * NH) prefetch_b(step + 1);
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const bool ok = (tapmask >> tap) & 1u;
         const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8;
@@ -843,8 +850,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (tap + 1 < 9) {
-            __syncthreads();                                 // everyone is done with this tap's weights
+        if (step + 1 < 9 * NH) {
+            __syncthreads();                                 // everyone is done with this step's weights (and, after tap 8, with the halo planes)
+            if (tap == 8) load_halo(step / 9 + 1);
             stage_b();
             __syncthreads();
         }
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(GemmArgs a)
 #endif
 #undef YN_TS
 }
-static size_t conv3x3_split_lds(int W, int NT) { return ((size_t)2 * (128 + 2 * W + 2) * (96 + 8) + (size_t)2 * 12 * (32 * NT) * 8) * 2; }
+static size_t conv3x3_split_lds(int W, int NT) { return ((size_t)2 * (128 + 2 * W + 2) * (48 + 8) + (size_t)2 * 6 * (32 * NT) * 8) * 2; }
 
 static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
 {
