@@ -71,7 +71,8 @@ int  yn_exact_f32(yn_handle* h, int enable);
 /* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's
  * candidates (:308-330, 362-367) run as ONE kernel, so the raw head tensors are neither written nor re-read (default on; needs
  * the split-f16 family and A(5+C) <= 256, otherwise yn_infer runs head GEMM + decode kernel as before).  Outputs are bit-identical
- * either way: a speed switch for A/B runs.  Env: YN_FUSE_DECODE=0/1. */
+ * either way: a speed switch for A/B runs.  enable = 1: when the stride-8 head has >= 8192 pixels (below that three GEMMs + one decode
+ * launch are faster), 2: always.  Env: YN_FUSE_DECODE=0/1/2. */
 int  yn_fuse_decode(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on

@@ -228,7 +228,7 @@ class Handle:
 
     def fuse_decode(self, on=True):
         """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
-        self._ck(self.lib.yn_fuse_decode(self.h, int(bool(on))), "yn_fuse_decode")
+        self._ck(self.lib.yn_fuse_decode(self.h, int(on)), "yn_fuse_decode")      # 0 off, 1 when the heads are large enough, 2 always
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

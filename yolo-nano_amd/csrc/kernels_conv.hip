@@ -702,10 +702,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 // The 96 input channels go through LDS in two HALVES of 48 (halo planes of 48 channels, then the nine taps on them, twice): 71 KB
 // per workgroup instead of 134 KB, so TWO workgroups share a CU and one's halo phase (HBM-bound) and epilogue overlap the other's tap
 // phase (LDS / MFMA-bound) — with one resident workgroup the three phases ran strictly one after the other.
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
+// NH = 1 (all 96 channels staged at once) is kept for launches of fewer than 256 workgroups (13x13 maps, bs = 1): nothing to overlap
+// with there, and a second halo phase costs 3 us.  Both forms walk K in the same order — channel half, tap, 16-deep step — so a
+// layer's bits do not depend on which one its size selects (an image's detections are independent of its batch:
+// test_infer_config2_bs32).
+template <int NT, int NH>
+__global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
 {
-    constexpr int CIN = 96, CH = 48, NH = CIN / CH, KQ = CH / 8, KQT = CIN / 8, BM = 128, BN = 32 * NT, CSH = CH + 8;   // halo row stride (halves): 112 bytes
+    constexpr int CIN = 96, CH = 48, HC = CIN / NH, KQ = CH / 8, KQT = CIN / 8, BM = 128, BN = 32 * NT, CSH = HC + 8;   // halo row stride (halves): 112 / 208 bytes
     constexpr int WCH = KQ * BN * 8;                                                  // halves per weight plane per (tap, half)
     constexpr int B_PER = (2 * KQ * BN + 255) / 256;                                  // 16-byte granules per thread per (tap, half) (hi and lo planes)
     extern __shared__ __attribute__((aligned(16))) float c3s_smem[];
@@ -761,9 +765,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
     //      The halo phase is BANDWIDTH-bound, not latency-bound: 180 KB per tile (halo factor 1.83 at W = 52 + the up2 source) at the
     //      ~10 B/clk/CU every CU gets when all of them stream at once; 24 loads in flight per thread instead of 8 changed nothing ----
     auto load_halo = [&](int half) {
-        constexpr int U = 8, CQ = CH / 4, PPL = 256 / CQ;
+        constexpr int U = 8, CQ = HC / 4, PPL = 256 / CQ;
         const int cq = t % CQ, pl = t / CQ;
-        const int c0 = half * CH + 4 * cq;
+        const int c0 = half * HC + 4 * cq;
         if (pl < PPL) {
             for (int i0 = pl; i0 < npix; i0 += PPL * U) {
                 float4 v[U], u2[U];
@@ -825,12 +829,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
 
-    for (int step = 0; step < 9 * NH; ++step) {
+    for (int step = 0; step < 18; ++step) {                 // (channel half, tap): K = 2 x 9 x 48
         const int tap = step % 9;
-        if (step + 1 < 9 * NH) prefetch_b(step + 1);
+        if (step + 1 < 18) prefetch_b(step + 1);
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const bool ok = (tapmask >> tap) & 1u;
-        const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8;
+        const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8 + (NH == 1 ? (step / 9) * CH : 0);
         const c3h16* Bhb = Bh + (size_t)(h * BN + l31) * 8;
         const c3h16* Blb = Bl + (size_t)(h * BN + l31) * 8;
 #pragma unroll
@@ -850,9 +854,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (step + 1 < 9 * NH) {
+        if (step + 1 < 18) {
             __syncthreads();                                 // everyone is done with this step's weights (and, after tap 8, with the halo planes)
-            if (tap == 8) load_halo(step / 9 + 1);
+            if (NH == 2 && tap == 8) load_halo(1);
             stage_b();
             __syncthreads();
         }
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(GemmArgs a)
 #endif
 #undef YN_TS
 }
-static size_t conv3x3_split_lds(int W, int NT) { return ((size_t)2 * (128 + 2 * W + 2) * (48 + 8) + (size_t)2 * 6 * (32 * NT) * 8) * 2; }
+static size_t conv3x3_split_lds(int W, int NT, int NH) { return ((size_t)2 * (128 + 2 * W + 2) * (96 / NH + 8) + (size_t)2 * 6 * (32 * NT) * 8) * 2; }
 
 static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
 {
@@ -1123,19 +1127,23 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
     // the network's 96->96 neck convs: per-tap weight chunks + 16-byte halo staging.  Small maps (few 128-pixel
     // tiles) split N over three block columns instead: the kernel is then latency- not MFMA-bound.
     if (a.Wsh && a.Wsl && a.K == 96 && a.Npad == 96 && a.in_off == 0 && a.in_ld == 96 && (a.N & 3) == 0 && (a.out_ld & 3) == 0 && (a.out_off & 3) == 0 &&
-        conv3x3_split_lds(a.W, 1) <= 160 * 1024) {
+        conv3x3_split_lds(a.W, 1, 1) <= 160 * 1024) {
         static unsigned long long attr_s = 0;
         if (attr_pending(attr_s)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const int tiles = (a.M + 127) / 128;
-        if (tiles >= 256 && conv3x3_split_lds(a.W, 3) <= 160 * 1024) {
-            g_last_kernel = "conv3x3_split_kernel<3>";
-            hipLaunchKernelGGL(conv3x3_split_kernel<3>, dim3(xcd_grid(tiles), 1), dim3(256), conv3x3_split_lds(a.W, 3), s, a);
-        } else {                                           // small maps: N over three block columns (latency-bound, more blocks)
-            g_last_kernel = "conv3x3_split_kernel<1>";
-            hipLaunchKernelGGL(conv3x3_split_kernel<1>, dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1), s, a);
+        if (tiles >= 256) {                                // N in one block column; channel halves, two workgroups per CU
+            g_last_kernel = "conv3x3_split_kernel<3,2>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<3, 2>), dim3(xcd_grid(tiles), 1), dim3(256), conv3x3_split_lds(a.W, 3, 2), s, a);
+        } else if (tiles * 3 >= 256) {                     // N over three block columns (more, shorter workgroups)
+            g_last_kernel = "conv3x3_split_kernel<1,2>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 2>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 2), s, a);
+        } else {                                           // less than one workgroup per CU: latency-bound, all channels staged at once
+            g_last_kernel = "conv3x3_split_kernel<1,1>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 1>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 1), s, a);
         }
         return;
     }

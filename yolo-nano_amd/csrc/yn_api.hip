@@ -120,6 +120,7 @@ struct yn_handle {
     // graphs / profiling
     bool use_graph = false;
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
+    int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
     bool exact_f32 = false;                // yn_exact_f32 / YN_EXACT_F32=1: GEMM-shaped convs on the f32 MFMA only (no split-f16 operands)
     bool autotune = true;
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
@@ -715,6 +716,9 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         snprintf(nm, sizeof nm, "head_det_%d.4", hd + 1);
         fuse_all = head_decode_supported(head_final_args(h, L(h, nm), nullptr, (long)B * Ws[hd] * Ws[hd]), h->grid);
     }
+    // small batches: three 16 us fused launches against three 10 us GEMMs + one 7 us decode (bs = 1) - the fusion pays from the
+    // traffic it removes, i.e. when the stride-8 head is large (bs >= 4 at 416x416); yn_fuse_decode(2) forces it (tests)
+    if (h->fuse_decode_mode != 2 && (long)B * W3 * W3 < 8192) fuse_all = false;
     if (fused) *fused = fuse_all;
     auto run_head = [&](int hd) {
         const long M = (long)B * Ws[hd] * Ws[hd];
@@ -816,7 +820,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
-    if (const char* e8 = getenv("YN_FUSE_DECODE")) h->fuse_decode = atoi(e8) != 0;
+    if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     build_layers(h);
@@ -911,8 +915,9 @@ int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
 int yn_fuse_decode(yn_handle* h, int enable)
 {
     if (!h) return 1;
-    if ((enable != 0) != h->fuse_decode) drop_graphs(h);
+    if ((enable != 0) != h->fuse_decode || enable != h->fuse_decode_mode) drop_graphs(h);
     h->fuse_decode = enable != 0;
+    h->fuse_decode_mode = enable;
     return 0;
 }
 
