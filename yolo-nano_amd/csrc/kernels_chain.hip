@@ -358,6 +358,13 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
     const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
     if (m0 >= a.M) return;
 
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
     uch16x8 b_reg[B_PER];
     auto prefetch_b = [&](const void* Wh, const void* Wl, int c) {
 #pragma unroll
@@ -484,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
         for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (uch16)0.0f; Pl[r * PS + c2] = (uch16)0.0f; }
     }
     __syncthreads();
+    YN_TS();
 
     f32x16 acc0[NT], acc1[NT];
     // entry state: chunk 0 staged (visible), chunk 1 requested into b_reg
@@ -524,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
             for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
     };
     gemm(a.Ws2h, a.Ws2l);
+    YN_TS();
     if (a.Wp1n) prefetch_b(a.Ws1h, a.Ws1l, 0);
     __syncthreads();                                                    // all waves are done reading the planes and the weights
 
@@ -566,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
             }
         }
     }
+    YN_TS();
     if (!a.Wp1n) return;
     // x2' = interleave(x1[bf/2:], y[bf/2:]) -> the planes (free since the first GEMM; their pad columns are still zero)
 #pragma unroll
@@ -580,10 +590,19 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
     __syncthreads();
 
     // ---- 4. the next unit's pw1 on x2' -> global ------------------------------------------------------------------------------
+    YN_TS();
     gemm(a.Ws1h, a.Ws1l);
+    YN_TS();
     GemmArgs e{};
     e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = a.M; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
     gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && (blockIdx.x % 97) == 5)
+        printf("chains bf %d blk %d dw %lld gemm1 %lld y+interleave %lld x2split %lld gemm2 %lld epi %lld total %lld\n", bf, (int)blockIdx.x, TS[1] - TS[0], TS[2] - TS[1],
+               TS[3] - TS[2], TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5], TS[6] - TS[0]);
+#endif
+#undef YN_TS
 }
 
 static size_t unit_chain_split_lds(int bf, int BM, int BN)
