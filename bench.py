@@ -586,9 +586,9 @@ def main():
     if not args.no_extras:
         extras = {}
         if (S, B, args.backbone) != (608, 32, "1.0x"):
-            extras["infer_608_bs32"] = side_workload(args, dev, rank, world, dist, 608, 32, "1.0x", 40, 8, ns)                 # north_star: "416x416 and 608x608"
+            extras["infer_608_bs32"] = side_workload(args, dev, rank, world, dist, 608, 32, "1.0x", 60, 24, ns)                 # north_star: "416x416 and 608x608"
         if (S, B, args.backbone) != (416, 128, "0.5x"):
-            extras["infer_0.5x_416_bs128"] = side_workload(args, dev, rank, world, dist, 416, 128, "0.5x", 30, 6, ns)          # BASELINE configs[3]
+            extras["infer_0.5x_416_bs128"] = side_workload(args, dev, rank, world, dist, 416, 128, "0.5x", 60, 24, ns)          # BASELINE configs[3]
         targs = argparse.Namespace(**vars(args))
         targs.size, targs.batch, targs.steps, targs.warmup, targs.backbone = 608, 32, 12, 3, "1.0x"
         for dt in ("f16", "f32"):                                                                                               # BASELINE configs[2]

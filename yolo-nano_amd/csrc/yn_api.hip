@@ -419,14 +419,29 @@ int tune_pw(yn_handle* h, GemmArgs a)
     if (!h->tune_e0) { (void)hipEventCreate(&h->tune_e0); (void)hipEventCreate(&h->tune_e1); }
     int best = -1;
     float best_ms = 1e30f;
-    // two rounds over all candidates, five timed launches each, minimum per candidate: a single short bracket is noisy enough
-    // (clock ramp, a neighbour stream's kernel) to pick a tile 1.5x slower than the best one
+    // two rounds over all candidates, minimum per candidate; every bracket spans >= ~300 us of launches (5...40 of them): a single
+    // short bracket is noisy enough (clock ramp, a neighbour stream's kernel) to pick a tile 1.5x slower than the best one, and the
+    // named workloads then moved by +-10 % from run to run
+    int reps = 5;
+    {
+        a.cfg = c_lo;
+        launch_pw(a, h->cur);
+        (void)hipEventRecord(h->tune_e0, h->cur);
+        launch_pw(a, h->cur); launch_pw(a, h->cur);
+        (void)hipEventRecord(h->tune_e1, h->cur);
+        float ms2 = 0.0f;
+        if (hipEventSynchronize(h->tune_e1) != hipSuccess) return -1;
+        (void)hipEventElapsedTime(&ms2, h->tune_e0, h->tune_e1);
+        const float per = ms2 > 0.0f ? ms2 * 0.5f : 0.02f;
+        reps = (int)(0.3f / per);
+        reps = reps < 5 ? 5 : (reps > 40 ? 40 : reps);
+    }
     for (int round = 0; round < 2; ++round) {
         for (int c = c_lo; c < c_hi; ++c) {
             a.cfg = c;
             launch_pw(a, h->cur);                           // warm-up
             (void)hipEventRecord(h->tune_e0, h->cur);
-            for (int r = 0; r < 5; ++r) launch_pw(a, h->cur);
+            for (int r = 0; r < reps; ++r) launch_pw(a, h->cur);
             (void)hipEventRecord(h->tune_e1, h->cur);
             if (hipEventSynchronize(h->tune_e1) != hipSuccess) return -1;
             float ms = 0.0f;
