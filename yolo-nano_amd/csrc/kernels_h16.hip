@@ -531,31 +531,52 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
         if (MODE == 2 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
     }
     if (live) {
+        // Software pipeline: the next batch of U rows is requested before the current one is reduced.  One workgroup per CU means one
+        // wavefront per SIMD, so nothing else hides a batch's load latency behind the ~2.5 k cycles of fp64 accumulation of the
+        // previous one (the reductions ran at 1.3-2 TB/s with the loads and the arithmetic strictly alternating).
         constexpr int U = 4;
         const long step = (long)gridDim.x * rowsPer;
-        for (long r = (long)blockIdx.x * rowsPer + rl; r < a.M; r += U * step) {
-            h16x8 v[U];
-            float g[U][8];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { ok[u] = r + u * step < a.M; v[u] = ldh8(a.y + (size_t)(ok[u] ? r + u * step : r) * a.y_ld + a.y_off + p0); }
-            if (MODE == 2) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) load_dz8(a, (size_t)(ok[u] ? r + u * step : r), p0, g[u]);
-            }
+        const bool fastdz = MODE == 2 && a.dz_odd && p0 + 8 <= a.C && (2 * p0 + 16 <= a.dz_half || 2 * p0 >= a.dz_half);
+        const bool slowdz = MODE == 2 && a.dz_odd && !fastdz;
+        const size_t dzo = (MODE == 2 && a.dz_odd) ? (size_t)(2 * p0 + (2 * p0 >= a.dz_half ? a.dz_gap : 0)) : (size_t)(a.dz_off + p0);
+        struct Batch { h16x8 v[U], d0[U], d1[U]; bool ok[U]; };            // two of them, indexed statically (a run-time index spills to scratch)
+        auto issue = [&](Batch& q, long r) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                q.ok[u] = r + u * step < a.M;
+                const size_t row = (size_t)(q.ok[u] ? r + u * step : (r < a.M ? r : a.M - 1));
+                q.v[u] = ldh8(a.y + row * a.y_ld + a.y_off + p0);
+                if (MODE == 2 && !slowdz) {
+                    q.d0[u] = ldh8(a.dz + row * a.dz_ld + dzo);
+                    if (a.dz_odd) q.d1[u] = ldh8(a.dz + row * a.dz_ld + dzo + 8);
+                }
+            }
+        };
+        auto reduce = [&](const Batch& q, long r) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g[8];
+                if (MODE == 2) {
+                    if (slowdz) load_dz8(a, (size_t)(q.ok[u] ? r + u * step : r), p0, g);
+                    else if (a.dz_odd) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { g[j] = (float)q.d0[u][2 * j + 1]; g[4 + j] = (float)q.d1[u][2 * j + 1]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[j] = (float)q.d0[u][j];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float yv = (float)v[u][j];
+                    const float yv = (float)q.v[u][j];
                     if (MODE == 0) {
-                        const float y0 = ok[u] ? yv : 0.0f;
+                        const float y0 = q.ok[u] ? yv : 0.0f;
                         s0[j] += (double)y0;
                         s1[j] += (double)y0 * (double)y0;
                     } else if (MODE == 3) {
-                        s0[j] += ok[u] ? (double)yv : 0.0;
+                        s0[j] += q.ok[u] ? (double)yv : 0.0;
                     } else {
-                        float d = ok[u] ? g[u][j] : 0.0f;
+                        float d = q.ok[u] ? g[j] : 0.0f;
                         if (a.act) d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
                         const float xh = (yv - mu[j]) * is[j];
                         s0[j] += (double)d;
@@ -563,6 +584,19 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
                     }
                 }
             }
+        };
+        Batch A, B;
+        const long bstep = U * step;
+        long r = (long)blockIdx.x * rowsPer + rl;
+        if (r < a.M) issue(A, r);
+        while (r < a.M) {
+            if (r + bstep < a.M) issue(B, r + bstep);
+            reduce(A, r);
+            r += bstep;
+            if (r >= a.M) break;
+            if (r + bstep < a.M) issue(A, r + bstep);
+            reduce(B, r);
+            r += bstep;
         }
     }
     // combine the row-lanes: inside a wave by xor-shuffles over the lane bits above the octet-lane bits (the row-lanes of one octet
