@@ -1,4 +1,4 @@
 # phase cycle counts of the unit-chain kernels (debug build with printf); cycle-counter ticks
 YN_EXTRA_FLAGS=-DYN_EXP_TIMING python3 -c "from yolo_nano_amd import build; build.build(force=True)" > /dev/null 2>&1
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extras --streams 1 --launch eager --profile-steps 0 2>/dev/null | grep "^chain" | sort -k3,3n -k5,5n | awk 'NR%12==1' | tail -14
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extras --streams 1 --launch eager --profile-steps 0 2>/dev/null | grep "^chain" | sort -k1,1 -k3,3n | awk "NR%10==1" | tail -16
 python3 -c "from yolo_nano_amd import build; build.build(force=True)" > /dev/null 2>&1

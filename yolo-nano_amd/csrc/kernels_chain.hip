@@ -479,13 +479,22 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
         prefetch_b(a.Ws2h, a.Ws2l, 0);
         x1_prefetch();
         stage_b();
+#ifdef YN_EXP_TIMING
+        long long td[6]; int tdn = 0; td[tdn++] = __builtin_readcyclecounter();
+#endif
         if (nchunks > 1) prefetch_b(a.Ws2h, a.Ws2l, 1);
         if (worker) {
             for (int run = pl; run < BM / R; run += ppl) {
                 finish(run, win);
+#ifdef YN_EXP_TIMING
+                if (tdn < 5) td[tdn++] = __builtin_readcyclecounter();
+#endif
                 if (run + ppl < BM / R) issue(run + ppl, win);
             }
         }
+#ifdef YN_EXP_TIMING
+        if (t == 0 && (blockIdx.x % 97) == 5) printf("chaindw bf %d blk %d start->stage_b %lld run0 %lld run1 %lld\n", bf, (int)blockIdx.x, td[0] - TS[0], td[1] - td[0], tdn > 2 ? td[2] - td[1] : 0LL);
+#endif
         // K tail: the columns [bf, PS) of both planes are zero (they meet zero weight rows, but must not be NaN bit patterns)
         const int padn = PS - bf;
         for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (uch16)0.0f; Pl[r * PS + c2] = (uch16)0.0f; }

@@ -40,29 +40,6 @@ __device__ __forceinline__ void decode_one(const GridInfo& g, int s, int cell, i
     }
 }
 
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_sum_f(float v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), off);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), off);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o > v ? o : v;
-    }
-    return v;
-}
 __device__ __forceinline__ unsigned f32_order_bits(float f)
 {
     const unsigned u = __float_as_uint(f);
@@ -109,8 +86,6 @@ __device__ __forceinline__ int group16_min_i(int v)
     return v;
 }
 
-// 16 lanes per candidate (4 candidates per wavefront): lane j of a group owns classes j, j+16, ...; the softmax
-// max / sum / arg-max are 4-step reductions inside the 16-lane row (DPP row operations).  KMAX*16 >= C.
 // one coordinate (k = 0..3: x1, y1, x2, y2) of decode_one's normalised box: the same operations in the same order, so the four
 // lanes that each evaluate one coordinate reproduce decode_one bit for bit (tc = t[k & 1], ts = t[2 + (k & 1)])
 __device__ __forceinline__ float decode_coord(const GridInfo& g, int s, int gx, int gy, int a, float tc, float ts, float S, int k)
@@ -128,7 +103,8 @@ __device__ __forceinline__ float decode_coord(const GridInfo& g, int s, int gx, 
 // p is monotone in e and the maximal e is exactly 1, so unless another class sits within 1e-5 of the maximum (or the product
 // underflows) the winner is the first class with e == 1 and its score 1 / sum * obj — ONE division per candidate; any wavefront
 // holding a near-tie takes the general path that evaluates every p_c (identical results, pinned by the parity suite).
-// Class part of one candidate on its 16 lanes.  Returns true when this WAVEFRONT took the general path — then `sc` / `cbest` are the
+// Class part of one candidate on its 16 lanes (4 candidates per wavefront): lane j of a group owns classes j, j+16, ...; the softmax
+// max / sum / arg-max are 4-step reductions inside the 16-lane DPP row.  KMAX*16 >= C.  Returns true when this WAVEFRONT took the general path — then `sc` / `cbest` are the
 // final score and class (needs the objectness) — else the caller finishes with score = 1 / sum * sigmoid(obj_raw), class = cbest.
 // The general path also covers obj_raw < -60: sigmoid below 1e-26, where score = obj / sum (sum <= C) may underflow to equal products.
 template <bool FULL, int KMAX>
@@ -580,17 +556,6 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
 // word (row, ci-ri) at  band_off(ri) + row*(T-ri) + (ci-ri),  band_off(ri) = 64*(ri*T - ri*(ri-1)/2).
 __device__ __forceinline__ size_t band_off(int ri, int T) { return (size_t)64 * ((size_t)ri * T - (size_t)ri * (ri - 1) / 2); }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// "plain" box: finite-ish coordinates and a non-negative area, so that for a DISJOINT pair with a plain row box of
-// area > 1e-10 the reference's arithmetic is decided without evaluating it: one clamped side is 1e-28, the other
-// at most 2e7, hence inter <= 2e-21, union >= 1e-10 - 2e-21 > 0 and inter/union <= 2e-11 <= thresh (thresh >= 1e-9):
-// `ovr <= thresh` holds, the pair is NOT suppressed.  Everything else takes the exact path (suppressed()).
-__device__ __forceinline__ bool plain_box(const float4 b)
-{
-    return fabsf(b.x) < 1e7f && fabsf(b.y) < 1e7f && fabsf(b.z) < 1e7f && fabsf(b.w) < 1e7f;
-}
-
 // min / max as plain v_min_f32 / v_max_f32: fminf / fmaxf on operands loaded from LDS cost a canonicalising v_max each (4.5 of the
 // 24 VALU instructions per pair in the tile loop below); NaN operands only reach the exact path (union is NaN, not > 0)
 __device__ __forceinline__ float vmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -607,7 +572,6 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
     const float ca = (cb.z - cb.x) * (cb.w - cb.y);
     cbox[lane] = cb;
     carea[lane] = ca;
-    const u64 col_plain = __ballot(plain_box(cb) && ca >= 0.0f);       // wave-uniform
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // cbox/carea are private to this wavefront:
     __builtin_amdgcn_wave_barrier();                                   // its LDS accesses execute in order
     const int jr = ri * 64 + lane;
