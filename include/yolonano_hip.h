@@ -74,6 +74,10 @@ int  yn_exact_f32(yn_handle* h, int enable);
  * either way: a speed switch for A/B runs.  enable = 1: when the stride-8 head has >= 8192 pixels (below that three GEMMs + one decode
  * launch are faster), 2: always.  Env: YN_FUSE_DECODE=0/1/2. */
 int  yn_fuse_decode(yn_handle* h, int enable);
+/* Layer k of the three detection heads (models/yolo_nano.py:299-301: same operator, three pyramid levels) and the three FPN
+ * laterals (:286-288) run as ONE grouped launch each instead of three (default on; split-f16 family only).  Bit-identical outputs:
+ * a speed switch for A/B runs.  Env: YN_GROUP=0/1. */
+int  yn_group_launch(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on
  * the handle's stream and caches the fastest.  All configurations of a family produce bit-identical results; disabling falls back

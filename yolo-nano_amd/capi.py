@@ -49,6 +49,7 @@ SIGNATURES = {
     "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_exact_f32": (_i32, [_vp, _i32]),
     "yn_fuse_decode": (_i32, [_vp, _i32]),
+    "yn_group_launch": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -229,6 +230,10 @@ class Handle:
     def fuse_decode(self, on=True):
         """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
         self._ck(self.lib.yn_fuse_decode(self.h, int(on)), "yn_fuse_decode")      # 0 off, 1 when the heads are large enough, 2 always
+
+    def group_launch(self, on=True):
+        """The three heads' layer k / the three laterals as one grouped launch each (default on; bit-identical outputs either way)."""
+        self._ck(self.lib.yn_group_launch(self.h, int(bool(on))), "yn_group_launch")
 
     def pw_config_count(self):
         return int(self.lib.yn_pw_config_count())

@@ -923,21 +923,36 @@ static size_t conv3x3_halo_lds(int W, int Cin, int NT)
 // to the f32-MFMA family, which rounds once per product-add; against float64 the split form is the more accurate of the two).
 // -------------------------------------------------------------------------------------------------
 template <int WM, int WN, int NT>
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a)
+__device__ __forceinline__ void gemm_split_block(const GemmArgs& a, c3h16* smem, unsigned bid, unsigned nblocks)
 {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
-    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(BM, BN)];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    const unsigned gy = (unsigned)(a.Npad + BN - 1) / BN, gx8 = gridDim.x / gy;     // XCD-aware decode (see gemm_conv_kernel)
-    const unsigned slot = blockIdx.x >> 3;
-    const int m0 = (int)((blockIdx.x & 7u) * (gx8 >> 3) + slot / gy) * BM;
+    const unsigned gy = (unsigned)(a.Npad + BN - 1) / BN, gx8 = nblocks / gy;     // XCD-aware decode (see gemm_conv_kernel)
+    const unsigned slot = bid >> 3;
+    const int m0 = (int)((bid & 7u) * (gx8 >> 3) + slot / gy) * BM;
     const int n0 = (int)(slot % gy) * BN;
     if (m0 >= a.M) return;
     const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
     f32x16 acc0[NT];
     gemm_split_tile<WM, WN, NT>(a, smem, m0, n0, acc0);
     gemm_epilogue<NT>(a, acc0, m0 + wm * 32, n0 + wn * NT * 32, vecO, lane);
+}
+
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN)];
+    gemm_split_block<WM, WN, NT>(a, smem, blockIdx.x, gridDim.x);
+}
+
+template <int WM, int WN, int NT>
+__global__ __launch_bounds__(256) void gemm_split_group_kernel(Group<GemmArgs> g)
+{
+    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN)];
+    unsigned local, nb;
+    const int p = group_problem(g.first, blockIdx.x, local, nb);
+    gemm_split_block<WM, WN, NT>(g.a[p], smem, local, nb);
 }
 
 struct TileCfg { int WM, WN, NT, KP, NBUF; };
@@ -1026,6 +1041,46 @@ static bool launch_pw_split(const GemmArgs& a, int idx, hipStream_t s)
     if (i++ == idx) { hipLaunchKernelGGL((gemm_split_kernel<wm, wn, nt>), grid, dim3(256), 0, s, a); return true; }
     YN_PWS_CONFIGS(X)
 #undef X
+    return false;
+}
+
+bool launch_pw_group(const GemmArgs* a, int n, int cfg, hipStream_t s)
+{
+    if (n < 1 || n > YN_GROUP_MAX) return false;
+    for (int p = 0; p < n; ++p)
+        if (!a[p].Wsh || !a[p].Wsl || (a[p].K & 1) || (a[p].in_ld & 1) || (a[p].in_off & 1) || a[p].Npad != a[0].Npad) return false;
+    int idx = cfg - N_PW_CFGS - N_PWD_CFGS;
+    if (idx < 0 || idx >= N_PWS_CFGS) {                     // untuned: the tile gemm_split would pick for the first (largest) problem
+        const int nt32 = a[0].Npad / 32;
+        idx = 0;
+        long best = -1;
+        for (int i = 0; i < N_PWS_CFGS; ++i) {
+            const SplitCfg& c = g_pws_cfgs[i];
+            const long BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+            if (BN > 32 * nt32 + 31 && BN != 32) continue;
+            const long blocks = ((a[0].M + BM - 1) / BM) * ((a[0].Npad + BN - 1) / BN);
+            const long waste = ((a[0].Npad + BN - 1) / BN) * BN - a[0].Npad;
+            const long score = (blocks >= 512 ? 1000000 : blocks * 1000) + BM * BN / 64 - waste * 50;
+            if (score > best) { best = score; idx = i; }
+        }
+    }
+    const SplitCfg& c = g_pws_cfgs[idx];
+    const int BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
+    Group<GemmArgs> g{};
+    unsigned tot = 0;
+    for (int p = 0; p < YN_GROUP_MAX; ++p) {
+        g.first[p] = tot;
+        if (p < n) { g.a[p] = a[p]; tot += xcd_grid((a[p].M + BM - 1) / BM) * ((a[p].Npad + BN - 1) / BN); }
+    }
+    g.first[YN_GROUP_MAX] = tot;
+    static char name[64];
+    int i = 0;
+#define X(wm, wn, nt)                                                                                      \
+    if (i++ == idx) { g_last_kernel = "gemm_split_group_kernel<" #wm "," #wn "," #nt ">";                   \
+                      hipLaunchKernelGGL((gemm_split_group_kernel<wm, wn, nt>), dim3(tot), dim3(256), 0, s, g); return true; }
+    YN_PWS_CONFIGS(X)
+#undef X
+    (void)name;
     return false;
 }
 
@@ -1198,14 +1253,14 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
 // a third of the HBM rate — and out-of-image taps are zeroed with an opaque bit mask (a select would be sunk back into
 // a branch).  VEC = 4 (16-byte accesses) whenever C, the row strides and the channel offsets allow it, else 2.
 template <int STRIDE, int VEC, int R>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
+__device__ __forceinline__ void dwconv3x3_block(const DwArgs& a, unsigned bid, unsigned nblocks)
 {
     typedef typename VecT<VEC>::type vec;
     constexpr int NCOL = STRIDE == 1 ? R + 2 : 2 * R + 1;
     const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
     const int cv_n = a.C / VEC, segs = (Wo + R - 1) / R;
     const int total = a.B * Ho * segs * cv_n;
-    const int i = xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int i = xcd_block(bid, nblocks) * 256 + threadIdx.x;
     if (i >= total) return;
     const int cv = i % cv_n;
     int q = i / cv_n;
@@ -1240,6 +1295,42 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a)
             for (int kx = 0; kx < 3; ++kx) vfma(acc, col[ky][o * STRIDE + kx], w[ky * 3 + kx]);
         *reinterpret_cast<vec*>(orow + (size_t)(ox0 + o) * a.out_ld) = vact(acc, a.act);
     }
+}
+
+template <int STRIDE, int VEC, int R>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs a) { dwconv3x3_block<STRIDE, VEC, R>(a, blockIdx.x, gridDim.x); }
+
+template <int R>
+__global__ __launch_bounds__(256) void dwconv3x3_group_kernel(Group<DwArgs> g)
+{
+    unsigned local, nb;
+    const int p = group_problem(g.first, blockIdx.x, local, nb);
+    dwconv3x3_block<1, 4, R>(g.a[p], local, nb);
+}
+
+bool dw_group_ok(const DwArgs* a, int n)
+{
+    if (n < 1 || n > YN_GROUP_MAX) return false;
+    for (int p = 0; p < n; ++p)
+        if (a[p].stride != 1 || (a[p].C % 4) || (a[p].in_ld % 4) || (a[p].in_off % 4) || (a[p].out_ld % 4) || (a[p].out_off % 4)) return false;
+    return true;
+}
+
+void launch_dw_group(const DwArgs* a, int n, hipStream_t s)
+{
+    auto blocks_for = [&](const DwArgs& q, int r) { return (unsigned)(((long)q.B * q.H * ((q.W + r - 1) / r) * (q.C / 4) + 255) / 256); };
+    unsigned all4 = 0;
+    for (int p = 0; p < n; ++p) all4 += blocks_for(a[p], 4);
+    const int R = all4 >= 1024 ? 4 : 2;                     // run length as launch_dw picks it, for the group as a whole
+    Group<DwArgs> g{};
+    unsigned tot = 0;
+    for (int p = 0; p < YN_GROUP_MAX; ++p) {
+        g.first[p] = tot;
+        if (p < n) { g.a[p] = a[p]; tot += xcd_grid(blocks_for(a[p], R)); }
+    }
+    g.first[YN_GROUP_MAX] = tot;
+    if (R == 4) { g_last_kernel = "dwconv3x3_group_kernel<4>"; hipLaunchKernelGGL(dwconv3x3_group_kernel<4>, dim3(tot), dim3(256), 0, s, g); }
+    else        { g_last_kernel = "dwconv3x3_group_kernel<2>"; hipLaunchKernelGGL(dwconv3x3_group_kernel<2>, dim3(tot), dim3(256), 0, s, g); }
 }
 
 void launch_dw(const DwArgs& a, hipStream_t s)

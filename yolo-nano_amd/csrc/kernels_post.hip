@@ -207,16 +207,21 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
 // one 32 x (128*NT) block (all columns of a pixel), bias added into an LDS tile [32][128*NT], then decode_candidate — the code
 // the standalone decode_kernel runs, 16 lanes per candidate — reads its row from LDS instead of HBM: results are bit-identical to
 // head GEMM + decode_kernel (the parity suite pins that), the 4*A(5+C) bytes per pixel of raw head are neither written nor re-read.
+template <int NT> struct HeadDecodeLds {
+    static constexpr int BM = 32, BN = 128 * NT, LD = BN + 4;
+    static constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2 + BM * 8 * 4;     // raw tile + [BM * A <= BM * 8] (sum, class)
+    static constexpr int HALVES = GEMM_HALVES > RAW_HALVES ? GEMM_HALVES : RAW_HALVES;
+};
+
 template <int NT, int KMAX>
-__global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g, int scale, float conf_thresh,
-                                                           float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls, int dbg)
+__device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridInfo& g, int scale, float conf_thresh,
+                                                  float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls, int dbg,
+                                                  c3h16* smem, unsigned bid, unsigned nblocks)
 {
     constexpr int BM = 32, BN = 128 * NT, LD = BN + 4;
-    constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2 + BM * 8 * 4;     // raw tile + [BM * A <= BM * 8] (sum, class)
-    __shared__ __attribute__((aligned(16))) c3h16 smem[GEMM_HALVES > RAW_HALVES ? GEMM_HALVES : RAW_HALVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = (int)(((blockIdx.x & 7u) * (gridDim.x >> 3)) + (blockIdx.x >> 3)) * BM;      // XCD x streams a contiguous run of rows
+    const int m0 = (int)(((bid & 7u) * (nblocks >> 3)) + (bid >> 3)) * BM;      // XCD x streams a contiguous run of rows
     if (m0 >= a.M) return;
     f32x16 acc[NT];
     if (dbg & 1) {
@@ -274,6 +279,25 @@ __global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g
     }
 }
 
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256) void head_decode_kernel(GemmArgs a, GridInfo g, int scale, float conf_thresh,
+                                                           float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls, int dbg)
+{
+    __shared__ __attribute__((aligned(16))) c3h16 smem[HeadDecodeLds<NT>::HALVES];
+    head_decode_block<NT, KMAX>(a, g, scale, conf_thresh, boxes, scores, cls, dbg, smem, blockIdx.x, gridDim.x);
+}
+
+// the three scales' last conv + decode as one launch (problem p = scale p)
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256) void head_decode_group_kernel(Group<GemmArgs> q, GridInfo g, float conf_thresh,
+                                                                 float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls)
+{
+    __shared__ __attribute__((aligned(16))) c3h16 smem[HeadDecodeLds<NT>::HALVES];
+    unsigned local, nb;
+    const int p = group_problem(q.first, blockIdx.x, local, nb);
+    head_decode_block<NT, KMAX>(q.a[p], g, p, conf_thresh, boxes, scores, cls, 0, smem, local, nb);
+}
+
 template <bool FULL>
 static void launch_decode(const float* const heads[3], const GridInfo& g, int B, float conf_thresh,
                           float* boxes, float* scores, int32_t* cls, float* all_class, hipStream_t s)
@@ -318,6 +342,24 @@ void launch_head_decode(const GemmArgs& a, const GridInfo& g, int scale, float c
     else if (g.C <= 32) YN_HD(1, 2);
     else YN_HD(1, 5);
 #undef YN_HD
+}
+
+void launch_head_decode_group(const GemmArgs* a, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s)
+{
+    Group<GemmArgs> q{};
+    unsigned tot = 0;
+    for (int p = 0; p < YN_GROUP_MAX; ++p) {
+        q.first[p] = tot;
+        if (p < n) { q.a[p] = a[p]; tot += (unsigned)(((a[p].M + 31) / 32 + 7) & ~7); }
+    }
+    q.first[YN_GROUP_MAX] = tot;
+    const dim3 grid(tot), blk(256);
+#define YN_HDG(nt, kmax) hipLaunchKernelGGL((head_decode_group_kernel<nt, kmax>), grid, blk, 0, s, q, g, conf_thresh, boxes, scores, cls)
+    if (a[0].Npad > 128) YN_HDG(2, 5);
+    else if (g.C <= 16) YN_HDG(1, 1);
+    else if (g.C <= 32) YN_HDG(1, 2);
+    else YN_HDG(1, 5);
+#undef YN_HDG
 }
 
 // YOLONano.decode_boxes: txtytwth [B, sumHW, A, 4] -> xyxy pixels [B, N, 4]

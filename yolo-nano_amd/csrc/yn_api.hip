@@ -119,6 +119,7 @@ struct yn_handle {
     size_t train_arena_bytes = 0;
     // graphs / profiling
     bool use_graph = false;
+    bool group_launch = true;              // yn_group_launch / YN_GROUP=0: the three heads' layers (and the laterals) as grouped launches
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
     int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
     bool exact_f32 = false;                // yn_exact_f32 / YN_EXACT_F32=1: GEMM-shaped convs on the f32 MFMA only (no split-f16 operands)
@@ -457,8 +458,8 @@ int tune_pw(yn_handle* h, GemmArgs a)
     return best;
 }
 
-void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
-            float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off, int n_store = 0)
+GemmArgs pw_args(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
+                 float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off, int n_store = 0)
 {
     GemmArgs a{};
     a.in = in; a.in_ld = in_ld; a.in_off = in_off;
@@ -469,6 +470,13 @@ void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     if (n_store > l.cout && n_store <= l.Npad) a.N = n_store;     // padded output row: the extra (zero-weight) columns are stored too
     if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }      // split-f16 MFMA family (fp32-class); exact_f32: the f32-MFMA kernels
     a.cfg = -1;
+    return a;
+}
+
+void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
+            float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off, int n_store = 0)
+{
+    GemmArgs a = pw_args(h, l, in, in_ld, in_off, M, out, out_ld, out_off, pass, pass_ld, pass_off, n_store);
     a.cfg = tune_pw(h, a);
     Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
                4.0 * (M * (double)(l.cin + l.cout + (pass ? 2 * l.cout : 0)) + (double)l.cin * l.cout));
@@ -594,6 +602,33 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
     launch_conv3x3(a, h->cur);
 }
 
+// ---- grouped launches (Group<>, yn_internal.h): the same layer of the three detection heads / the three laterals as ONE launch ----
+bool run_pw_group(yn_handle* h, const Layer* const l[], GemmArgs a[], int n, const char* name)
+{
+    a[0].cfg = tune_pw(h, a[0]);                            // the tile of the largest problem; every split configuration gives the same bits
+    double fl = 0, by = 0;
+    for (int p = 0; p < n; ++p) {
+        fl += 2.0 * a[p].M * l[p]->cin * l[p]->cout;
+        by += 4.0 * (a[p].M * (double)(l[p]->cin + l[p]->cout) + (double)l[p]->cin * l[p]->cout);
+    }
+    Bracket br(h, name, fl, by);
+    if (launch_pw_group(a, n, a[0].cfg, h->cur)) return true;
+    br.cancel();
+    return false;
+}
+
+void run_dw_group(yn_handle* h, const Layer* const l[], DwArgs a[], int n, const char* name)
+{
+    double fl = 0, by = 0;
+    for (int p = 0; p < n; ++p) {
+        const double M = (double)a[p].B * a[p].H * a[p].W;
+        fl += 2.0 * M * 9 * l[p]->cout;
+        by += 4.0 * 2 * M * l[p]->cout;
+    }
+    Bracket br(h, name, fl, by);
+    launch_dw_group(a, n, h->cur);
+}
+
 // ---- fork / join of independent kernel chains onto side streams (also legal inside stream capture) ----
 hipEvent_t fj_event(yn_handle* h)
 {
@@ -712,12 +747,25 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     const int W3 = S / 8, W4 = S / 16, W5 = S / 32;
     const long M3 = (long)B * W3 * W3, M4 = (long)B * W4 * W4, M5 = (long)B * W5 * W5;
     TAKE(p3, M3 * NECK); TAKE(p4, M4 * NECK); TAKE(p5, M5 * NECK);
-    // the three laterals are independent; p3 is only needed by smooth_1
-    fork_to(h, 0);
-    run_pw(h, L(h, "conv1x1_0"), cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0);
-    back_to_main(h);
-    run_pw(h, L(h, "conv1x1_1"), cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0);
-    run_pw(h, L(h, "conv1x1_2"), cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0);
+    // the three laterals are independent (p3 is only needed by smooth_1): one grouped launch, or three launches with the large one
+    // forked onto a side stream
+    bool lat_grouped = false;
+    if (h->group_launch && !h->exact_f32) {
+        const Layer* ll[3] = {&L(h, "conv1x1_0"), &L(h, "conv1x1_1"), &L(h, "conv1x1_2")};
+        if (ll[0]->ws_hi && ll[1]->ws_hi && ll[2]->ws_hi) {
+            GemmArgs g3[3] = {pw_args(h, *ll[0], cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0),
+                              pw_args(h, *ll[1], cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0),
+                              pw_args(h, *ll[2], cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0)};
+            lat_grouped = run_pw_group(h, ll, g3, 3, "conv1x1_*");
+        }
+    }
+    if (!lat_grouped) {
+        fork_to(h, 0);
+        run_pw(h, L(h, "conv1x1_0"), cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0);
+        back_to_main(h);
+        run_pw(h, L(h, "conv1x1_1"), cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0);
+        run_pw(h, L(h, "conv1x1_2"), cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0);
+    }
     TAKE(p4a, M4 * NECK); TAKE(p3a, M3 * NECK); TAKE(p4b, M4 * NECK); TAKE(p5a, M5 * NECK);
     run_c3(h, L(h, "smooth_0"), p4, p5, 1, B, W4, W4, p4a);        // p4 + up2(p5)
     join_from(h, 0);
@@ -756,6 +804,66 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         }
         return 0;
     };
+    // All three heads layer by layer, each layer ONE grouped launch (5 launches instead of 15): the stride-16 / 32 heads ride along with
+    // the stride-8 one instead of paying ten launches of 7-20 us for a few microseconds of work.  Needs the split-f16 family.
+    bool grouped = h->group_launch && !h->exact_f32;
+    const Layer* hl[5][3];
+    for (int k = 0; k < 5 && grouped; ++k)
+        for (int hd = 0; hd < 3; ++hd) {
+            snprintf(nm, sizeof nm, "head_det_%d.%d", hd + 1, k);
+            hl[k][hd] = &L(h, nm);
+            if ((k == 1 || k == 3 || k == 4) && !hl[k][hd]->ws_hi) grouped = false;
+        }
+    if (grouped) {
+        run_c3(h, L(h, "smooth_2"), p4a, p3a, 2, B, W4, W4, p4b);      // p4 + down(p3)
+        run_c3(h, L(h, "smooth_3"), p5, p4b, 2, B, W5, W5, p5a);       // p5 + down(p4)
+        float *hA[3], *hB[3], *hC[3];
+        for (int hd = 0; hd < 3; ++hd) {
+            const size_t M = (size_t)B * Ws[hd] * Ws[hd];
+            hA[hd] = arena_take(h, M * NECK); hB[hd] = arena_take(h, M * NECK); hC[hd] = arena_take(h, M * NECK);
+            if (!hA[hd] || !hB[hd] || !hC[hd]) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
+        }
+        auto dw_layer = [&](int k, float* const src_own[3], const float* const src_feat[3], float* const dst[3], const char* name) {
+            DwArgs d[3];
+            for (int hd = 0; hd < 3; ++hd) {
+                const Layer& l = *hl[k][hd];
+                d[hd] = DwArgs{};
+                d[hd].in = src_feat ? src_feat[hd] : src_own[hd]; d[hd].in_ld = NECK; d[hd].in_off = 0; d[hd].w = l.w_packed; d[hd].bias = l.b_packed;
+                d[hd].out = dst[hd]; d[hd].out_ld = NECK; d[hd].out_off = 0;
+                d[hd].B = B; d[hd].H = Ws[hd]; d[hd].W = Ws[hd]; d[hd].C = l.cout; d[hd].stride = l.stride; d[hd].act = l.act;
+            }
+            if (!dw_group_ok(d, 3)) return false;
+            run_dw_group(h, hl[k], d, 3, name);
+            return true;
+        };
+        auto pw_layer = [&](int k, float* const src[3], float* const dst[3], int dst_ld, int n_store, const char* name) {
+            GemmArgs g3[3];
+            for (int hd = 0; hd < 3; ++hd)
+                g3[hd] = pw_args(h, *hl[k][hd], src[hd], NECK, 0, (long)B * Ws[hd] * Ws[hd], dst[hd], dst_ld, 0, nullptr, 0, 0, n_store);
+            return run_pw_group(h, hl[k], g3, 3, name);
+        };
+        bool ok = dw_layer(0, nullptr, feats, hA, "head_det_*.0") && pw_layer(1, hA, hB, NECK, 0, "head_det_*.1") &&
+                  dw_layer(2, hB, nullptr, hA, "head_det_*.2") && pw_layer(3, hA, hC, NECK, 0, "head_det_*.3");
+        if (ok) {
+            if (fuse_all) {
+                GemmArgs g3[3];
+                double fl = 0, by = 0;
+                for (int hd = 0; hd < 3; ++hd) {
+                    const long M = (long)B * Ws[hd] * Ws[hd];
+                    g3[hd] = head_final_args(h, *hl[4][hd], hC[hd], M);
+                    fl += 2.0 * M * hl[4][hd]->cin * hl[4][hd]->cout;
+                    by += 4.0 * (M * (double)hl[4][hd]->cin + (double)hl[4][hd]->cin * hl[4][hd]->cout + 6.0 * M * h->grid.A);
+                }
+                set_last_kernel_name("head_decode_group_kernel");
+                Bracket br(h, "head_det_*.4+decode", fl, by);
+                launch_head_decode_group(g3, 3, h->grid, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->cur);
+            } else {
+                float* outs[3] = {heads[0], heads[1], heads[2]};
+                ok = pw_layer(4, hC, outs, head_ld, head_ld, "head_det_*.4");
+            }
+        }
+        if (!ok) return fail(h, "grouped head launch: unsupported layer layout");
+    } else {
     fork_to(h, 0);
     if (run_head(0)) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
     back_to_main(h);
@@ -767,6 +875,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     if (run_head(2)) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes);
     join_from(h, 0);
     join_from(h, 1);
+    }
 #undef TAKE
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -835,6 +944,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
+    if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
     if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
@@ -927,6 +1037,14 @@ int yn_set_pw_config(yn_handle* h, int index)
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
 int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
+int yn_group_launch(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != h->group_launch) drop_graphs(h);
+    h->group_launch = enable != 0;
+    return 0;
+}
+
 int yn_fuse_decode(yn_handle* h, int enable)
 {
     if (!h) return 1;

@@ -189,6 +189,24 @@ void launch_sgd(float* p, const float* g, float* buf, long n, float lr, float mo
 __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) { return (b & 7u) * (nb >> 3) + (b >> 3); }
 inline unsigned xcd_grid(unsigned blocks) { return (blocks + 7u) & ~7u; }
 
+// ---- grouped launches: up to three problems of one kernel type (the three detection heads' layer k, the three FPN laterals) as ONE
+//      launch.  Workgroup ids [first[p], first[p+1]) belong to problem p; every range starts at a multiple of 8, so a problem's local
+//      ids keep the id % 8 -> XCD relation the tile decode relies on.  The small problems ride along with the large one instead of
+//      paying a launch each (a launch of this network's small layers costs 7-15 us whatever it computes).
+#define YN_GROUP_MAX 3
+template <typename Args> struct Group { Args a[YN_GROUP_MAX]; unsigned first[YN_GROUP_MAX + 1]; };
+__device__ __forceinline__ int group_problem(const unsigned (&first)[YN_GROUP_MAX + 1], unsigned bid, unsigned& local, unsigned& nb)
+{
+    const int p = (bid >= first[1] ? 1 : 0) + (bid >= first[2] ? 1 : 0);
+    local = bid - first[p];
+    nb = first[p + 1] - first[p];
+    return p;
+}
+void launch_dw_group(const DwArgs* a, int n, hipStream_t s);                    // stride 1, 4-channel vectors (checked by the caller through dw_group_ok)
+bool dw_group_ok(const DwArgs* a, int n);
+bool launch_pw_group(const GemmArgs* a, int n, int cfg, hipStream_t s);          // split-f16 family only; cfg = pointwise configuration index or -1
+void launch_head_decode_group(const GemmArgs* a, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s);
+
 // hipFuncSetAttribute acts on the CURRENT device: every call site keeps a bit mask of the devices it has configured
 inline bool attr_pending(unsigned long long& mask)
 {
