@@ -119,6 +119,7 @@ struct yn_handle {
     size_t train_arena_bytes = 0;
     // graphs / profiling
     bool use_graph = false;
+    long net_passes = 0;                   // run_network calls so far (dbg_skip)
     bool group_launch = true;              // yn_group_launch / YN_GROUP=0: the three heads' layers (and the laterals) as grouped launches
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
     int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
@@ -458,6 +459,27 @@ int tune_pw(yn_handle* h, GemmArgs a)
     return best;
 }
 
+// Timing ablation (tools/ablate.sh): YN_DBG_SKIP_LAYERS=<substr,substr,...> drops the launches of every layer whose name contains one of
+// the substrings, from the (YN_DBG_SKIP_AFTER, default 8)-th network pass of the handle on - the activation arena then still holds the
+// layer's output of the earlier passes on the same input, so everything downstream (NMS included) does its normal work.
+static bool dbg_skip(yn_handle* h, const std::string& name)
+{
+    static const char* pat = getenv("YN_DBG_SKIP_LAYERS");
+    if (!pat) return false;
+    static const int after = getenv("YN_DBG_SKIP_AFTER") ? atoi(getenv("YN_DBG_SKIP_AFTER")) : 8;
+    if (h->net_passes <= after) return false;
+    std::string p(pat);
+    size_t i = 0;
+    while (i <= p.size()) {
+        const size_t j = p.find(',', i);
+        const std::string tok = p.substr(i, j == std::string::npos ? std::string::npos : j - i);
+        if (!tok.empty() && name.find(tok) != std::string::npos) return true;
+        if (j == std::string::npos) break;
+        i = j + 1;
+    }
+    return false;
+}
+
 GemmArgs pw_args(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off, long M,
                  float* out, int out_ld, int out_off, const float* pass, int pass_ld, int pass_off, int n_store = 0)
 {
@@ -478,6 +500,7 @@ void run_pw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
 {
     GemmArgs a = pw_args(h, l, in, in_ld, in_off, M, out, out_ld, out_off, pass, pass_ld, pass_off, n_store);
     a.cfg = tune_pw(h, a);
+    if (dbg_skip(h, l.name)) return;
     Bracket br(h, l.name, 2.0 * M * l.cin * l.cout,
                4.0 * (M * (double)(l.cin + l.cout + (pass ? 2 * l.cout : 0)) + (double)l.cin * l.cout));
     launch_pw(a, h->cur);
@@ -491,6 +514,7 @@ void run_dw(yn_handle* h, const Layer& l, const float* in, int in_ld, int in_off
     a.out = out; a.out_ld = out_ld; a.out_off = out_off;
     a.B = B; a.H = H; a.W = W; a.C = l.cout; a.stride = l.stride; a.act = l.act;
     const double Mi = (double)B * H * W, Mo = (double)B * ((H - 1) / l.stride + 1) * ((W - 1) / l.stride + 1);
+    if (dbg_skip(h, l.name)) return;
     Bracket br(h, l.name, 2.0 * Mo * 9 * l.cout, 4.0 * (Mi + Mo) * l.cout);
     launch_dw(a, h->cur);
 }
@@ -567,6 +591,7 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
         a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw2.Npad; a.M = (int)M;
         Bracket br(h, P + (last ? ".dw+pw2" : ".dw+pw2+pw1n"), 2.0 * M * bf * (9.0 + bf + (last ? 0.0 : (double)bf)),
                    4.0 * (4.0 * M * bf + (last ? 1.0 : 2.0) * bf * bf + 10.0 * bf));
+        if (dbg_skip(h, P + ".chain")) { br.cancel(); x1 = a.out; x1_ld = bf; float* tq = tA; tA = tB; tB = tq; continue; }
         if (!launch_unit_chain(a, h->cur)) {                 // cannot happen after the coverage check above
             br.cancel();
             fail(h, "unit chain: no tile for stage %d unit %d after the coverage check", stage, bi);
@@ -596,6 +621,7 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
     a.M = B * H * W; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     a.cfg = -1;
     if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }     // split-f16 MFMA path (fp32-class); exact_f32: the f32-MFMA kernel
+    if (dbg_skip(h, l.name)) return;
     const double M = (double)a.M;
     const double in2px = resample == 1 ? M / 4 : (resample == 2 ? M * 4 : 0);
     Bracket br(h, l.name, 2.0 * M * 9 * l.cin * l.cout, 4.0 * ((M + in2px) * l.cin + M * l.cout + 9.0 * l.cin * l.cout));
@@ -606,6 +632,7 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
 bool run_pw_group(yn_handle* h, const Layer* const l[], GemmArgs a[], int n, const char* name)
 {
     a[0].cfg = tune_pw(h, a[0]);                            // the tile of the largest problem; every split configuration gives the same bits
+    if (dbg_skip(h, name)) return true;
     double fl = 0, by = 0;
     for (int p = 0; p < n; ++p) {
         fl += 2.0 * a[p].M * l[p]->cin * l[p]->cout;
@@ -625,6 +652,7 @@ void run_dw_group(yn_handle* h, const Layer* const l[], DwArgs a[], int n, const
         fl += 2.0 * M * 9 * l[p]->cout;
         by += 4.0 * 2 * M * l[p]->cout;
     }
+    if (dbg_skip(h, name)) return;
     Bracket br(h, name, fl, by);
     launch_dw_group(a, n, h->cur);
 }
@@ -685,6 +713,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     const int S = h->grid.S;
     h->arena_used = 0;
     h->cur = h->stream;
+    ++h->net_passes;
 #define TAKE(var, floats)                                                                   \
     float* var = arena_take(h, (size_t)(floats));                                           \
     if (!var) return fail(h, "activation arena exhausted (%zu bytes)", h->arena_bytes)
@@ -696,7 +725,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         const Layer& l = L(h, "stem");
         const double Mo = (double)B * H1 * H1;
         Bracket br(h, "stem+maxpool", 2.0 * Mo * 27 * 24, 4.0 * ((double)B * 3 * S * S + (double)B * H2 * H2 * 24));
-        launch_stem_pool(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a1, h->cur);
+        if (!dbg_skip(h, "stem")) launch_stem_pool(x, B, S, S, l.w_packed, l.b_packed, l.cout, l.act, a1, h->cur);
     }
     const float* cur = a1;
     int curC = 24, curH = H2;
@@ -856,7 +885,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                 }
                 set_last_kernel_name("head_decode_group_kernel");
                 Bracket br(h, "head_det_*.4+decode", fl, by);
-                launch_head_decode_group(g3, 3, h->grid, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->cur);
+                if (!dbg_skip(h, "head_det_*.4")) launch_head_decode_group(g3, 3, h->grid, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->cur);
             } else {
                 float* outs[3] = {heads[0], heads[1], heads[2]};
                 ok = pw_layer(4, hC, outs, head_ld, head_ld, "head_det_*.4");
