@@ -894,3 +894,30 @@ def test_grouped_launches_are_bit_identical(hcoco, hvoc, which, S, B):
         h.fuse_decode(True)
         h.group_launch(True)
         h.set_grid(old)
+
+
+@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 3), ("1.0x", 20, 320, 2), ("0.5x", 20, 224, 1), ("1.0x", 20, 288, 1)])
+def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
+    """yn_down_fuse: pw1 -> depthwise stride 2 -> pw2 -> concat+shuffle of stage 2's first unit as ONE kernel (down_unit_kernel) gives
+    exactly the backbone taps and raw heads of the three launches - maps whose size is not a multiple of the 8 x 4 output tile included
+    (288: 36 x 36, 224: 28 x 28)."""
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
+    h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
+    h.load_state_dict(weights.make_state_dict(backbone, C))
+    h.fold_bn()
+    x = dev(weights.make_input(B, S, seed=5))
+    h.down_fuse(False)
+    taps0 = [t.clone() for t in h.forward_taps(x)]
+    raw0 = [t.clone() for t in h.forward_raw(x)]
+    h.down_fuse(True)
+    h.profile_enable(True)
+    raw1 = h.forward_raw(x)
+    kernels = [r[1] for r in h.profile_records()]
+    h.profile_enable(False)
+    taps1 = h.forward_taps(x)
+    assert any(k.startswith("down_unit_kernel") for k in kernels), kernels
+    for a, b in zip(taps0, taps1):
+        assert torch.equal(a, b)
+    for a, b in zip(raw0, raw1):
+        assert torch.equal(a, b)
+    h.close()

@@ -50,6 +50,7 @@ SIGNATURES = {
     "yn_exact_f32": (_i32, [_vp, _i32]),
     "yn_fuse_decode": (_i32, [_vp, _i32]),
     "yn_group_launch": (_i32, [_vp, _i32]),
+    "yn_down_fuse": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -230,6 +231,10 @@ class Handle:
     def fuse_decode(self, on=True):
         """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
         self._ck(self.lib.yn_fuse_decode(self.h, int(on)), "yn_fuse_decode")      # 0 off, 1 when the heads are large enough, 2 always
+
+    def down_fuse(self, on=True):
+        """Main branch of the stride-2 unit of stage 2 as one kernel (default on; bit-identical outputs either way)."""
+        self._ck(self.lib.yn_down_fuse(self.h, int(bool(on))), "yn_down_fuse")
 
     def group_launch(self, on=True):
         """The three heads' layer k / the three laterals as one grouped launch each (default on; bit-identical outputs either way)."""

@@ -676,6 +676,274 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
 #undef YN_UC
     return false;
 }
+// -------------------------------------------------------------------------------------------------
+// The main branch of a STRIDE-2 ShuffleV2 unit (backbone/shufflenetv2.py:41-51, 73-74) as one kernel:
+//     y1 = relu(pw1(x))  at H x W   ->   y2 = dw3x3_s2(y1)  at H/2 x W/2   ->   y3 = relu(pw2(y2))   ->   out = shuffle(cat(branch1, y3))
+// y1 is the largest tensor of the network (stage 2: 104 x 104 x 58 per image, 80 MB per 32-image step written and read back once) and the
+// launches around it cost their full duration even with four streams (tools/ablate.sh: the big-tensor regions do not overlap with
+// anything).  One workgroup = an 8 x 4 tile of OUTPUT pixels of one image: pw1 on the 17 x 9 input pixels the tile's depthwise
+// windows cover (20 % recomputed on tile borders; K = cin <= 32 is one chunk), y1 in an fp32 LDS tile (zero outside the image: the
+// depthwise conv pads its INPUT), depthwise -> split planes, pw2 (K = bf <= 64: two chunks) and the concat+shuffle store.  Every sum runs
+// in the order of gemm_split_kernel / dwconv3x3_kernel: bit-identical to the three launches (test_down_unit_is_bit_identical).
+// LDS 70 KB: two workgroups per CU.
+// -------------------------------------------------------------------------------------------------
+template <int NP>                                           // Npad / 32 of both GEMMs (bf <= 32 * NP)
+__global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
+{
+    constexpr int TW = 8, TH = 4, WW = 2 * TW + 1, WH = 2 * TH + 1, NPIX = WW * WH, RT1 = (NPIX + 31) / 32;      // 17 x 9 = 153 window pixels, 5 row tiles
+    constexpr int BN = 32 * NP, AST1 = 32 + 8, AST2 = BN + 8, NO = TW * TH;
+    extern __shared__ __attribute__((aligned(16))) float du_smem[];
+    const int bf = a.bf, CS = bf + 2;
+    // region 1: A1 planes [RT1*32][AST1] x 2 + B1 [4][BN][8] x 2   (GEMM 1), later A2 planes [32][AST2] x 2 + B2 [8][BN][8] x 2 (GEMM 2)
+    uch16* A1h = reinterpret_cast<uch16*>(du_smem);
+    uch16* A1l = A1h + RT1 * 32 * AST1;
+    uch16* B1 = A1l + RT1 * 32 * AST1;                      // hi plane, then lo plane
+    constexpr int R1_HALVES_A = 2 * RT1 * 32 * AST1 + 2 * 4 * BN * 8, R1_HALVES_B = 2 * NO * AST2 + 2 * 8 * BN * 8;
+    constexpr int R1_HALVES = R1_HALVES_A > R1_HALVES_B ? R1_HALVES_A : R1_HALVES_B;
+    uch16* A2h = reinterpret_cast<uch16*>(du_smem);
+    uch16* A2l = A2h + NO * AST2;
+    uch16* B2 = A2l + NO * AST2;
+    float* T32 = du_smem + (R1_HALVES + 1) / 2;             // [RT1*32][CS] (rows >= NPIX are written as zeros, never read)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    const int tx_n = (Wo + TW - 1) / TW, ty_n = (Ho + TH - 1) / TH;
+    const int tile = (int)xcd_block(blockIdx.x, gridDim.x);
+    if (tile >= a.B * ty_n * tx_n) return;
+    const int b = tile / (ty_n * tx_n), trem = tile - b * (ty_n * tx_n);
+    const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;         // input pixel of window position (0, 0)
+    const int KQ1 = (a.cin + 7) >> 3, KQ2 = (bf + 7) >> 3;
+
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
+    // ---- 1. x window -> split planes; W1 -> LDS; W2, the depthwise taps and biases -> registers --------------------------------------
+    unsigned char* inside = reinterpret_cast<unsigned char*>(T32 + RT1 * 32 * CS);      // [RT1*32] window pixel lies inside the image
+    // depthwise work split: thread = (channel pair cp, pixel lane pl); its nine taps and bias stay in registers
+    const int cp_n = bf >> 1, ppl = 256 / cp_n;
+    const int cp = t % cp_n, dpl = t / cp_n, dc = cp * 2;
+    const bool dworker = dpl < ppl;
+    // biases of both GEMMs for this lane's columns: requested now, used after the MFMAs (a load inside the epilogue is a full wait)
+    const ActSel as1 = act_sel(a.act1), as2 = act_sel(a.act2);
+    float bias1[NP], bias2v = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NP; ++nt) bias1[nt] = (nt * 32 + l31 < bf) ? a.b1[nt * 32 + l31] : 0.0f;
+    if (wave < NP && wave * 32 + l31 < bf) bias2v = a.b2[wave * 32 + l31];
+    float2 wd[9], bd = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd[k] = dworker ? *reinterpret_cast<const float2*>(a.wdw + k * bf + dc) : make_float2(0.0f, 0.0f);
+    if (dworker) bd = *reinterpret_cast<const float2*>(a.bdw + dc);
+    if (t < RT1 * 32) {                                     // one window pixel per thread: all of its (<= 32) input channels
+        const int p = t;
+        const int wy = p / WW, wx = p - wy * WW;
+        const int iy = iy0 + wy, ix = ix0 + wx;
+        const bool ok = p < NPIX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        inside[p] = ok ? 1 : 0;
+        const float* px = a.x + ((size_t)(b * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.cin;
+        float2 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool kj = 2 * j < a.cin;
+            v[j] = vmask(*reinterpret_cast<const float2*>(px + (kj ? 2 * j : 0)), opaque_mask(ok && kj));
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            uch16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[o * 4 + j].x, x1 = v[o * 4 + j].y;
+                hi[2 * j] = (uch16)x0; hi[2 * j + 1] = (uch16)x1;
+                lo[2 * j] = (uch16)((x0 - (float)hi[2 * j]) * 2048.0f); lo[2 * j + 1] = (uch16)((x1 - (float)hi[2 * j + 1]) * 2048.0f);
+            }
+            *reinterpret_cast<uch16x8*>(A1h + p * AST1 + o * 8) = hi;
+            *reinterpret_cast<uch16x8*>(A1l + p * AST1 + o * 8) = lo;
+        }
+    }
+    for (int g = t; g < 2 * 4 * BN; g += 256) {             // W1: plane, octet, column
+        const int pl = g / (4 * BN), r = g - pl * (4 * BN);
+        const int o = r / BN, n = r - o * BN;
+        uch16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+        if (o < KQ1 && n < a.Npad1) v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? a.W1l : a.W1h) + ((size_t)o * a.Npad1 + n) * 8);
+        *reinterpret_cast<uch16x8*>(B1 + (size_t)g * 8) = v;
+    }
+    constexpr int B2_PER = (2 * 8 * BN + 255) / 256;
+    uch16x8 b2_reg[B2_PER];
+#pragma unroll
+    for (int i = 0; i < B2_PER; ++i) {
+        const int g = t + 256 * i;
+        const int pl = g / (8 * BN), r = g - pl * (8 * BN);
+        const int o = r / BN, n = r - o * BN;
+        uch16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+        if (g < 2 * 8 * BN && o < KQ2 && n < a.Npad2) v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? a.W2l : a.W2h) + ((size_t)o * a.Npad2 + n) * 8);
+        b2_reg[i] = v;
+    }
+    __syncthreads();
+    YN_TS();
+
+    // ---- 2. y1 = act(pw1) on the window pixels -> T32 (zero outside the image) ------------------------------------------------
+    for (int rt = wave; rt < RT1; rt += 4) {
+        f32x16 acc0[NP], acc1[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+        const uch16* Ahb = A1h + (rt * 32 + l31) * AST1 + h * 8;
+        const uch16* Alb = A1l + (rt * 32 + l31) * AST1 + h * 8;
+        const uch16* Bhb = B1 + (size_t)(h * BN + l31) * 8;
+        const uch16* Blb = Bhb + 4 * BN * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < NP; ++nt) {
+                const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+            }
+        }
+        unsigned in16 = 0;                                  // inside flags of this lane's 16 rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) in16 |= (unsigned)inside[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] << r;
+#pragma unroll
+        for (int nt = 0; nt < NP; ++nt) {
+            const int n = nt * 32 + l31;
+            const float bias = bias1[nt];
+            if (n < bf) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias, as1);
+                    T32[p * CS + n] = __uint_as_float(__float_as_uint(v) & (0u - ((in16 >> r) & 1u)));
+                }
+            }
+        }
+    }
+    __syncthreads();                                        // y1 complete; region 1 is free
+    YN_TS();
+
+    // ---- 3. depthwise 3x3 stride 2 (dwconv3x3_kernel's fma chain) -> split planes A2; W2 -> LDS ---------------------------------
+#pragma unroll
+    for (int i = 0; i < B2_PER; ++i) {
+        const int g = t + 256 * i;
+        if (g < 2 * 8 * BN) *reinterpret_cast<uch16x8*>(B2 + (size_t)g * 8) = b2_reg[i];
+    }
+    if (dworker) {
+        for (int op = dpl; op < NO; op += ppl) {
+            const int dy = op / TW, dx = op - dy * TW;
+            float2 acc = bd;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    vfma(acc, *reinterpret_cast<const float2*>(T32 + ((2 * dy + ky) * WW + 2 * dx + kx) * CS + dc), wd[ky * 3 + kx]);
+            acc = vact(acc, a.dw_act);
+            uch16x2 hi, lo;
+            hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
+            lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
+            *reinterpret_cast<uch16x2*>(A2h + op * AST2 + dc) = hi;
+            *reinterpret_cast<uch16x2*>(A2l + op * AST2 + dc) = lo;
+        }
+    }
+    {
+        const int padn = AST2 - bf;                         // K tail of both planes: zero
+        for (int i = t; i < NO * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; A2h[r * AST2 + c2] = (uch16)0.0f; A2l[r * AST2 + c2] = (uch16)0.0f; }
+    }
+    __syncthreads();
+    YN_TS();
+
+    // ---- 4. y3 = act(pw2(y2)) for the 32 output pixels; concat + shuffle store -------------------------------------------------
+    if (wave < NP) {                                        // one wavefront per 32 output columns
+        const int nt = wave;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+        const uch16* Ahb = A2h + l31 * AST2 + h * 8;
+        const uch16* Alb = A2l + l31 * AST2 + h * 8;
+        const uch16* Bhb = B2 + (size_t)(h * BN + nt * 32 + l31) * 8;
+        const uch16* Blb = Bhb + 8 * BN * 8;
+        for (int ks = 0; ks < 2 * ((KQ2 + 3) >> 2); ++ks) {                 // gemm_split_tile's chunks of 32: whole chunks, zero-padded
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+            const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN) * 8);
+            const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN) * 8);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+        }
+        const int n = nt * 32 + l31;
+        if (n < bf) {
+            const float bias = bias2v;
+            // the 16 pass-through values of this lane are requested together, before any store (a load issued next to the store that
+            // needs it is followed by a full wait: 16 memory latencies in a row)
+            float pv[16];
+            size_t mrow[16];
+            unsigned okm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int op = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+                const bool ok = oy < Ho && ox < Wo;
+                okm |= (ok ? 1u : 0u) << r;
+                mrow[r] = ((size_t)b * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0);
+                pv[r] = __uint_as_float(__float_as_uint(a.pass[mrow[r] * bf + n]) & opaque_mask(ok));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((okm >> r) & 1u) {
+                    const float v = apply_act(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias, as2);
+                    *reinterpret_cast<float2*>(a.out + mrow[r] * (2 * bf) + 2 * n) = make_float2(pv[r], v);
+                }
+            }
+        }
+    }
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && (blockIdx.x % 331) == 7) printf("downunit blk %d load+split %lld gemm1 %lld dw %lld gemm2+store %lld total %lld\n", (int)blockIdx.x, TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2], TS[4] - TS[3], TS[4] - TS[0]);
+#endif
+#undef YN_TS
+}
+
+static size_t down_unit_lds(int bf, int NP)
+{
+    const int BN = 32 * NP, RT1 = 5, NO = 32;
+    const size_t r1a = (size_t)2 * RT1 * 32 * 40 + (size_t)2 * 4 * BN * 8, r1b = (size_t)2 * NO * (BN + 8) + (size_t)2 * 8 * BN * 8;
+    const size_t r1 = r1a > r1b ? r1a : r1b;
+    return ((r1 + 1) / 2) * sizeof(float) + (size_t)160 * (bf + 2) * sizeof(float) + 160;       // + the window's inside flags
+}
+
+bool down_unit_covers(const DownArgs& a)
+{
+    return a.W1h && a.W1l && a.W2h && a.W2l && a.cin <= 32 && !(a.cin & 1) && a.bf <= 64 && !(a.bf & 1) && a.Npad1 == a.Npad2 && a.Npad1 <= 64 &&
+           !(a.H & 1) && !(a.W & 1) && a.pass && a.B > 0;
+}
+
+void launch_down_unit(const DownArgs& a, hipStream_t s)
+{
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    const unsigned tiles = (unsigned)a.B * ((Ho + 3) / 4) * ((Wo + 7) / 8);
+    const int NP = a.Npad1 / 32;
+    const size_t lds = down_unit_lds(a.bf, NP);
+    static unsigned long long attr = 0;
+    if (attr_pending(attr)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (NP == 1) { set_last_kernel_name("down_unit_kernel<1>"); hipLaunchKernelGGL(down_unit_kernel<1>, dim3(xcd_grid(tiles)), dim3(256), lds, s, a); }
+    else         { set_last_kernel_name("down_unit_kernel<2>"); hipLaunchKernelGGL(down_unit_kernel<2>, dim3(xcd_grid(tiles)), dim3(256), lds, s, a); }
+}
+
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
 bool unit_chain_covers(const ChainArgs& a) { return unit_chain_dispatch(a, nullptr, true); }
 

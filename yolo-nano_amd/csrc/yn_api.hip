@@ -120,6 +120,7 @@ struct yn_handle {
     // graphs / profiling
     bool use_graph = false;
     long net_passes = 0;                   // run_network calls so far (dbg_skip)
+    bool down_fuse = true;                 // yn_down_fuse / YN_DOWN_FUSE=0: the main branch of a stride-2 unit as one kernel (down_unit_kernel)
     bool group_launch = true;              // yn_group_launch / YN_GROUP=0: the three heads' layers (and the laterals) as grouped launches
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
     int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
@@ -748,10 +749,26 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
             run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
             back_to_main(h);
+            // branch 2 as ONE kernel where the tile fits (cin <= 32, bf <= 64: stage 2, whose pw1 output is the largest tensor of the network)
+            const Layer &lp1 = L(h, P0 + ".b2.pw1"), &ldw = L(h, P0 + ".b2.dw"), &lp2 = L(h, P0 + ".b2.pw2");
+            DownArgs d{};
+            d.x = cur; d.cin = curC;
+            d.W1h = lp1.ws_hi; d.W1l = lp1.ws_lo; d.b1 = lp1.b_packed; d.act1 = lp1.act; d.Npad1 = lp1.Npad;
+            d.wdw = ldw.w_packed; d.bdw = ldw.b_packed; d.dw_act = ldw.act;
+            d.W2h = lp2.ws_hi; d.W2l = lp2.ws_lo; d.b2 = lp2.b_packed; d.act2 = lp2.act; d.Npad2 = lp2.Npad;
+            d.pass = tb1; d.out = oA; d.B = B; d.H = curH; d.W = curH; d.bf = bf;
+            if (h->down_fuse && !h->exact_f32 && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 && down_unit_covers(d)) {
+                join_from(h, 0);
+                if (!dbg_skip(h, P0 + ".b2")) {
+                    Bracket br(h, P0 + ".b2", 2.0 * (Mi * curC * bf + Mo * bf * (9.0 + bf)), 4.0 * (Mi * (double)curC + 3.0 * Mo * bf + (double)curC * bf + (double)bf * bf));
+                    launch_down_unit(d, h->cur);
+                }
+            } else {
             run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
             run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
             join_from(h, 0);
             run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
+            }
         }
         float* o_cur = oA;
         float* o_nxt = oB;
@@ -974,6 +991,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
     if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
+    if (const char* e10 = getenv("YN_DOWN_FUSE")) h->down_fuse = atoi(e10) != 0;
     if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
@@ -1066,6 +1084,14 @@ int yn_set_pw_config(yn_handle* h, int index)
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
 int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
+int yn_down_fuse(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != h->down_fuse) drop_graphs(h);
+    h->down_fuse = enable != 0;
+    return 0;
+}
+
 int yn_group_launch(yn_handle* h, int enable)
 {
     if (!h) return 1;

@@ -44,6 +44,20 @@ struct ChainArgs {
     int B, H, W, bf, Npad, M;
 };
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
+
+// The main branch of a stride-2 ShuffleV2 unit as ONE kernel (kernels_chain.hip, down_unit_kernel): pw1 -> depthwise 3x3 stride 2 ->
+// pw2 -> concat + shuffle with the other branch's output.
+struct DownArgs {
+    const float* x; int cin;                    // unit input [B][H][W][cin] (dense)
+    const void *W1h, *W1l; const float* b1; int act1, Npad1;       // pw1: split packs [ceil(cin/8)][Npad1][8], bias, activation
+    const float* wdw; const float* bdw; int dw_act;                // depthwise [9][bf], [bf]
+    const void *W2h, *W2l; const float* b2; int act2, Npad2;       // pw2: split packs [ceil(bf/8)][Npad2][8]
+    const float* pass;                          // branch-1 output [B][Ho][Wo][bf]
+    float* out;                                 // [B][Ho][Wo][2*bf]: out[2n] = pass[n], out[2n+1] = pw2[n]
+    int B, H, W, bf;
+};
+bool down_unit_covers(const DownArgs& a);
+void launch_down_unit(const DownArgs& a, hipStream_t s);
 bool unit_chain_covers(const ChainArgs& a);     // same selection, nothing launched
 
 const char* last_kernel_name();            // symbol of the most recent launch_* on this thread
