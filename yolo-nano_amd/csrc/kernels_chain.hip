@@ -729,7 +729,6 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     const int cp = t % cp_n, dpl = t / cp_n, dc = cp * 2;
     const bool dworker = dpl < ppl;
     // biases of both GEMMs for this lane's columns: requested now, used after the MFMAs (a load inside the epilogue is a full wait)
-    const ActSel as1 = act_sel(a.act1), as2 = act_sel(a.act2);
     float bias1[NP], bias2v = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NP; ++nt) bias1[nt] = (nt * 32 + l31 < bf) ? a.b1[nt * 32 + l31] : 0.0f;
@@ -824,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int p = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias, as1);
+                    const float v = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias, a.act1);
                     T32[p * CS + n] = __uint_as_float(__float_as_uint(v) & (0u - ((in16 >> r) & 1u)));
                 }
             }
@@ -902,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if ((okm >> r) & 1u) {
-                    const float v = apply_act(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias, as2);
+                    const float v = apply_act(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias, a.act2);
                     *reinterpret_cast<float2*>(a.out + mrow[r] * (2 * bf) + 2 * n) = make_float2(pv[r], v);
                 }
             }
