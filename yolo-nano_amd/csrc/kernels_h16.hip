@@ -37,8 +37,22 @@ __device__ __forceinline__ h16x8 keep8(h16x8 v, bool ok)
     u.x &= mk; u.y &= mk; u.z &= mk; u.w &= mk;
     return __builtin_bit_cast(h16x8, u);
 }
-__device__ __forceinline__ float hact(float v, int act) { return act == 1 ? (v > 0.0f ? v : 0.0f) : (act == 2 ? (v > 0.0f ? v : 0.1f * v) : v); }
-__device__ __forceinline__ float hact_grad(float g, float zz, int act) { return zz > 0.0f ? g : (act == 2 ? 0.1f * g : 0.0f); }
+// activation and its derivative without control flow (a run-time `act` in an if-chain compiles to branches per VALUE in the unrolled
+// loops: 334 in hbn_apply_kernel); the same bits as v > 0 ? v : (act 1: 0, act 2: 0.1 v, else v)
+__device__ __forceinline__ float hact(float v, int act)
+{
+    const float slope = act == 2 ? 0.1f : 1.0f;
+    const unsigned keep = act == 1 ? 0u : 0xffffffffu;
+    const float neg = __uint_as_float(__float_as_uint(slope * v) & keep);
+    return v > 0.0f ? v : neg;
+}
+__device__ __forceinline__ float hact_grad(float g, float zz, int act)      // zz > 0 ? g : (act 0: g, act 1: +0, act 2: 0.1 g)
+{
+    const float slope = act == 2 ? 0.1f : 1.0f;
+    const unsigned keep = act == 1 ? 0u : 0xffffffffu;
+    const float neg = __uint_as_float(__float_as_uint(slope * g) & keep);
+    return zz > 0.0f ? g : neg;
+}
 __device__ __forceinline__ float hbn_value(float y, float mu, float is, float ga, float be) { return __fmaf_rn(__fmul_rn(__fsub_rn(y, mu), is), ga, be); }
 // physical channel p of a gapped row -> logical channel, or -1 for a pad
 __device__ __forceinline__ int logical_of(int p, int C, int half, int gap)
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
                         s0[j] += q.ok[u] ? (double)yv : 0.0;
                     } else {
                         float d = q.ok[u] ? g[j] : 0.0f;
-                        if (a.act) d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+                        d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
                         const float xh = (yv - mu[j]) * is[j];
                         s0[j] += (double)d;
                         s1[j] += (double)d * (double)xh;
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restric
         for (int j = 0; j < 8; ++j) {
             float d = g[j];
             const float yv = (float)v[j];
-            if (a.act) d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+            d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
             const float xh = (yv - mu[j]) * is[j];
             r[j] = lc[j] >= 0 ? (h16)(kk[j] * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
         }
