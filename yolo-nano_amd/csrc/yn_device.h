@@ -40,8 +40,8 @@ __device__ __forceinline__ float4 vmask(float4 v, unsigned mk)
 
 // ---- GEMM epilogue shared by the tiled and the persistent kernel: bias + activation (+ concat/shuffle interleave with
 //      the pass-through half).  mbase / nbase = first row / column of this wave's 32 x (32*NT) accumulator block.
-template <int NT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane,
+template <int NT, bool PASS>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane,
                                               const float* pre_bias = nullptr)   // pre_bias[nt]: bias of this lane's column, loaded earlier
 {
     const int l31 = lane & 31, h = lane >> 5;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
             // the pass-through half of the four row groups: requested together, before the transposes (issued one by one
             // inside the `if (m < M)` below, each load is followed by a full wait)
             float4 pv[4];
-            if (a.pass) {
+            if (PASS) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int m = mbase + 8 * g + 4 * h + j;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
                 }
                 const int m = mbase + 8 * g + 4 * h + j;
                 if (m < a.M && nq < a.N) {
-                    if (a.pass) {
+                    if (PASS) {
                         const float4 p = pv[g];
                         float* o = a.out + (size_t)m * a.out_ld + a.out_off + 2 * nq;
                         *reinterpret_cast<float4*>(o) = make_float4(p.x, v0, p.y, v1);
@@ -105,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
             const int m = mbase + row;
             if (m >= a.M) continue;
             const float v = apply_act(acc[nt][r] + bias, a.act);
-            if (a.pass) {
+            if (PASS) {
                 const float p = a.pass[(size_t)m * a.pass_ld + a.pass_off + n];
                 *reinterpret_cast<float2*>(a.out + (size_t)m * a.out_ld + a.out_off + 2 * n) = make_float2(p, v);
             } else {
@@ -115,6 +115,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     }
 }
 
+
+// the pass-through variant is selected ONCE: inside the unrolled loops a run-time `a.pass` test is a branch per accumulator group
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NT], int mbase, int nbase, bool vecO, int lane,
+                                              const float* pre_bias = nullptr)
+{
+    if (a.pass) gemm_epilogue_impl<NT, true>(a, acc, mbase, nbase, vecO, lane, pre_bias);
+    else gemm_epilogue_impl<NT, false>(a, acc, mbase, nbase, vecO, lane, pre_bias);
+}
 
 // ---- split-f16 pointwise GEMM tile (gemm_split_kernel and head_decode_kernel share it): the block's 32*WM x 32*NT*WN tile of
 //      in[M][K] x W[K][Npad] as three f16 MFMAs per 16-deep k-step on split fp32 operands (x = hi + lo*2^-11), K in
