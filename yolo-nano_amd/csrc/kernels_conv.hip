@@ -669,12 +669,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
             float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
             {
                 const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
-                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                 if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
             }
             {
                 const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
-                const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
                 if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
             }
             const int mm = p0 + wave * 32 + 8 * g + 4 * h + j;
@@ -878,12 +878,12 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
             float v0 = vv[0], v1 = vv[1], v2 = vv[2], v3 = vv[3];
             {
                 const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
-                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                 if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
             }
             {
                 const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
-                const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
                 if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
             }
             const int mm = p0 + wave * 32 + 8 * g + 4 * h + j;

@@ -18,6 +18,11 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v > 0.0f ? v : neg;
 }
 
+// lane ^ 1 / lane ^ 2 exchanges inside a quad as DPP quad_perm moves (one VALU instruction; __shfl_xor compiles to ds_bpermute_b32, an
+// LDS round trip: 16 of them per 32 output columns in the 16-byte-store epilogues)
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }   // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)); }   // quad_perm:[2,3,0,1]
+
 // Loads whose result is only sometimes wanted are issued UNCONDITIONALLY at a clamped (always legal) address and the
 // unwanted values are zeroed with a bit mask the optimiser cannot see through.  `if (ok) v = load` — and `ok ? load : 0`,
 // and `load & mask` with a visible mask — all compile to a branch around the load followed by s_waitcnt vmcnt(0), i.e.
@@ -71,12 +76,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& a, f32x16 (&a
                 float v2 = apply_act(acc[nt][4 * g + 2] + bias, a.act), v3 = apply_act(acc[nt][4 * g + 3] + bias, a.act);
                 {   // 2x2 blocks
                     const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
-                    const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                     if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 }
                 {   // 4x4
                     const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
-                    const float r0 = __shfl_xor(s0, 2), r1 = __shfl_xor(s1, 2);
+                    const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
                     if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
                 }
                 const int m = mbase + 8 * g + 4 * h + j;
