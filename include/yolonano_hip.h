@@ -78,9 +78,10 @@ int  yn_fuse_decode(yn_handle* h, int enable);
  * laterals (:286-288) run as ONE grouped launch each instead of three (default on; split-f16 family only).  Bit-identical outputs:
  * a speed switch for A/B runs.  Env: YN_GROUP=0/1. */
 int  yn_group_launch(yn_handle* h, int enable);
-/* The main branch of a stride-2 ShuffleV2 unit (backbone/shufflenetv2.py:41-51: pointwise -> depthwise stride 2 -> pointwise, then
- * concat + channel shuffle with the other branch) as ONE kernel where its tile fits (input channels <= 32, branch width <= 64: stage 2,
- * whose intermediate is the largest tensor of the network); default on, split-f16 family only, bit-identical.  Env: YN_DOWN_FUSE=0/1. */
+/* A stride-2 ShuffleV2 unit (backbone/shufflenetv2.py:30-51, 73-74: branch 2 = pointwise -> depthwise stride 2 -> pointwise, branch 1 =
+ * depthwise stride 2 -> pointwise, then concat + channel shuffle) as ONE kernel where its tile fits (input channels <= 32, branch
+ * width <= 64: stage 2, whose intermediate is the largest tensor of the network); default on, split-f16 family only, bit-identical to
+ * the five launches.  Env: YN_DOWN_FUSE=0/1. */
 int  yn_down_fuse(yn_handle* h, int enable);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on

@@ -677,15 +677,20 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
     return false;
 }
 // -------------------------------------------------------------------------------------------------
-// The main branch of a STRIDE-2 ShuffleV2 unit (backbone/shufflenetv2.py:41-51, 73-74) as one kernel:
-//     y1 = relu(pw1(x))  at H x W   ->   y2 = dw3x3_s2(y1)  at H/2 x W/2   ->   y3 = relu(pw2(y2))   ->   out = shuffle(cat(branch1, y3))
+// A STRIDE-2 ShuffleV2 unit (backbone/shufflenetv2.py:30-51, 73-74) as one kernel:
+//     branch 2:  y1 = relu(pw1(x)) at H x W  ->  y2 = dw3x3_s2(y1) at H/2 x W/2  ->  y3 = relu(pw2(y2))
+//     branch 1:  z1 = dw3x3_s2(x)  ->  z2 = relu(pw(z1))                                  out = shuffle(cat(z2, y3))
 // y1 is the largest tensor of the network (stage 2: 104 x 104 x 58 per image, 80 MB per 32-image step written and read back once) and the
 // launches around it cost their full duration even with four streams (tools/ablate.sh: the big-tensor regions do not overlap with
 // anything).  One workgroup = an 8 x 4 tile of OUTPUT pixels of one image: pw1 on the 17 x 9 input pixels the tile's depthwise
 // windows cover (20 % recomputed on tile borders; K = cin <= 32 is one chunk), y1 in an fp32 LDS tile (zero outside the image: the
-// depthwise conv pads its INPUT), depthwise -> split planes, pw2 (K = bf <= 64: two chunks) and the concat+shuffle store.  Every sum runs
-// in the order of gemm_split_kernel / dwconv3x3_kernel: bit-identical to the three launches (test_down_unit_is_bit_identical).
-// LDS 70 KB: two workgroups per CU.
+// depthwise conv pads its INPUT), depthwise -> split planes, pw2 (K = bf <= 64: two chunks) on wavefronts 0..NP-1 while wavefronts
+// NP..2NP-1 run branch 1's pointwise conv (its depthwise inputs come straight from global into registers at kernel start), and the
+// concat + shuffle is the store.  x is read once (x 1.2) and `out` written once: 80 MB per step instead of 360 MB in five launches.
+// Every sum runs in the order of gemm_split_kernel / dwconv3x3_kernel: bit-identical to the five launches
+// (test_down_unit_is_bit_identical).  LDS 76 KB: two workgroups per CU.  94 us of launches -> 75 us; 33.3 -> 35.2 k images/s together
+// with the branch-free activation this kernel led to (three branches per accumulator value in the first version's epilogue).
+// pass != null: branch 1's output is read from memory instead (the two-kernel form of branch 1; A/B runs, YN_DOWN_B1=0).
 // -------------------------------------------------------------------------------------------------
 template <int NP>                                           // Npad / 32 of both GEMMs (bf <= 32 * NP)
 __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
@@ -698,11 +703,16 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     uch16* A1h = reinterpret_cast<uch16*>(du_smem);
     uch16* A1l = A1h + RT1 * 32 * AST1;
     uch16* B1 = A1l + RT1 * 32 * AST1;                      // hi plane, then lo plane
-    constexpr int R1_HALVES_A = 2 * RT1 * 32 * AST1 + 2 * 4 * BN * 8, R1_HALVES_B = 2 * NO * AST2 + 2 * 8 * BN * 8;
+    constexpr int R1_HALVES_A = 2 * RT1 * 32 * AST1 + 2 * 4 * BN * 8;
+    constexpr int R1_HALVES_B = 2 * NO * AST2 + 2 * 8 * BN * 8 + 2 * NO * AST1 + 2 * 4 * BN * 8;      // A2, B2, then branch 1's A3 [32][AST1] x 2 and B3 [4][BN][8] x 2
     constexpr int R1_HALVES = R1_HALVES_A > R1_HALVES_B ? R1_HALVES_A : R1_HALVES_B;
     uch16* A2h = reinterpret_cast<uch16*>(du_smem);
     uch16* A2l = A2h + NO * AST2;
     uch16* B2 = A2l + NO * AST2;
+    uch16* A3h = B2 + 2 * 8 * BN * 8;
+    uch16* A3l = A3h + NO * AST1;
+    uch16* B3 = A3l + NO * AST1;
+    const bool fuse1 = a.pass == nullptr;                   // branch 1 (depthwise stride 2 on x, then pointwise) computed here too
     float* T32 = du_smem + (R1_HALVES + 1) / 2;             // [RT1*32][CS] (rows >= NPIX are written as zeros, never read)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -737,6 +747,43 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wd[k] = dworker ? *reinterpret_cast<const float2*>(a.wdw + k * bf + dc) : make_float2(0.0f, 0.0f);
     if (dworker) bd = *reinterpret_cast<const float2*>(a.bdw + dc);
+    // branch 1: thread = (channel pair c1, pixel lane p1) -> its <= 2 output pixels' 3x3 stride-2 windows of x, straight from global (the
+    // lines are the ones the window load below brings in), nine taps and the bias in registers; W3 -> registers
+    const int c1_n = a.cin >> 1, p1_n = 256 / c1_n;
+    const int c1 = (t % c1_n) * 2, p1 = t / c1_n;
+    constexpr int NI1 = 2;                                  // 32 output pixels over >= 16 pixel lanes (cin <= 32)
+    float2 x1w[NI1][9], w1d[9], b1d = make_float2(0.0f, 0.0f);
+    constexpr int B3_PER = (2 * 4 * BN + 255) / 256;
+    uch16x8 b3_reg[B3_PER];
+    float bias3v = 0.0f;
+    if (fuse1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w1d[k] = *reinterpret_cast<const float2*>(a.wdw1 + k * a.cin + c1);
+        b1d = *reinterpret_cast<const float2*>(a.bdw1 + c1);
+#pragma unroll
+        for (int i = 0; i < NI1; ++i) {
+            const int op = p1 + i * p1_n;
+            const int dy = op / TW, dx = op - dy * TW;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int iy = 2 * (oy0 + dy) - 1 + k / 3, ix = 2 * (ox0 + dx) - 1 + k % 3;
+                const bool ok = op < NO && p1 < p1_n && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                x1w[i][k] = vmask(*reinterpret_cast<const float2*>(a.x + ((size_t)(b * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.cin + c1), opaque_mask(ok));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B3_PER; ++i) {
+            const int g = t + 256 * i;
+            const int pl = g / (4 * BN), r = g - pl * (4 * BN);
+            const int o = r / BN, n = r - o * BN;
+            uch16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+            if (g < 2 * 4 * BN && o < KQ1 && n < a.Npad3) v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? a.W3l : a.W3h) + ((size_t)o * a.Npad3 + n) * 8);
+            b3_reg[i] = v;
+        }
+        if (wave >= NP && wave < 2 * NP && (wave - NP) * 32 + l31 < bf) bias3v = a.b3[(wave - NP) * 32 + l31];
+    }
     if (t < RT1 * 32) {                                     // one window pixel per thread: all of its (<= 32) input channels
         const int p = t;
         const int wy = p / WW, wx = p - wy * WW;
@@ -838,6 +885,32 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
         const int g = t + 256 * i;
         if (g < 2 * 8 * BN) *reinterpret_cast<uch16x8*>(B2 + (size_t)g * 8) = b2_reg[i];
     }
+    if (fuse1) {
+#pragma unroll
+        for (int i = 0; i < B3_PER; ++i) {
+            const int g = t + 256 * i;
+            if (g < 2 * 4 * BN) *reinterpret_cast<uch16x8*>(B3 + (size_t)g * 8) = b3_reg[i];
+        }
+        if (p1 < p1_n) {
+#pragma unroll
+            for (int i = 0; i < NI1; ++i) {
+                const int op = p1 + i * p1_n;
+                if (op < NO) {
+                    float2 acc = b1d;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) vfma(acc, x1w[i][k], w1d[k]);
+                    acc = vact(acc, a.dw1_act);
+                    uch16x2 hi, lo;
+                    hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
+                    lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
+                    *reinterpret_cast<uch16x2*>(A3h + op * AST1 + c1) = hi;
+                    *reinterpret_cast<uch16x2*>(A3l + op * AST1 + c1) = lo;
+                }
+            }
+        }
+        const int pad1 = AST1 - a.cin;                      // K tail of branch 1's planes: zero
+        for (int i = t; i < NO * pad1; i += 256) { const int r = i / pad1, c2 = a.cin + i - r * pad1; A3h[r * AST1 + c2] = (uch16)0.0f; A3l[r * AST1 + c2] = (uch16)0.0f; }
+    }
     if (dworker) {
         for (int op = dpl; op < NO; op += ppl) {
             const int dy = op / TW, dx = op - dy * TW;
@@ -862,12 +935,34 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     __syncthreads();
     YN_TS();
 
-    // ---- 4. y3 = act(pw2(y2)) for the 32 output pixels; concat + shuffle store -------------------------------------------------
-    if (wave < NP) {                                        // one wavefront per 32 output columns
-        const int nt = wave;
-        f32x16 acc0, acc1;
+    // ---- 4. branch 1's pointwise conv on wavefronts NP..2NP-1 (-> an LDS tile in the free T32 space) while wavefronts 0..NP-1 run pw2 --
+    float* PT = T32;                                        // [32][BN + 1]
+    f32x16 acc0, acc1;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+    for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+    if (fuse1 && wave >= NP && wave < 2 * NP) {
+        const int nt = wave - NP;
+        const uch16* Ahb = A3h + l31 * AST1 + h * 8;
+        const uch16* Alb = A3l + l31 * AST1 + h * 8;
+        const uch16* Bhb = B3 + (size_t)(h * BN + nt * 32 + l31) * 8;
+        const uch16* Blb = Bhb + 4 * BN * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+            const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN) * 8);
+            const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN) * 8);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+        }
+        const int n = nt * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            PT[((r & 3) + 8 * (r >> 2) + 4 * h) * (BN + 1) + n] = apply_act(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias3v, a.act3);
+    }
+    if (wave < NP) {                                        // pw2: one wavefront per 32 output columns
+        const int nt = wave;
         const uch16* Ahb = A2h + l31 * AST2 + h * 8;
         const uch16* Alb = A2l + l31 * AST2 + h * 8;
         const uch16* Bhb = B2 + (size_t)(h * BN + nt * 32 + l31) * 8;
@@ -881,7 +976,11 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
         }
-        const int n = nt * 32 + l31;
+    }
+    if (fuse1) __syncthreads();                             // branch 1's tile is complete
+    // ---- 5. concat + shuffle store: out[2n] = branch 1, out[2n+1] = branch 2 -------------------------------------------------------
+    if (wave < NP) {
+        const int n = wave * 32 + l31;
         if (n < bf) {
             const float bias = bias2v;
             // the 16 pass-through values of this lane are requested together, before any store (a load issued next to the store that
@@ -896,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
                 const bool ok = oy < Ho && ox < Wo;
                 okm |= (ok ? 1u : 0u) << r;
                 mrow[r] = ((size_t)b * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0);
-                pv[r] = __uint_as_float(__float_as_uint(a.pass[mrow[r] * bf + n]) & opaque_mask(ok));
+                pv[r] = fuse1 ? PT[op * (BN + 1) + n] : __uint_as_float(__float_as_uint(a.pass[mrow[r] * bf + n]) & opaque_mask(ok));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -917,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 static size_t down_unit_lds(int bf, int NP)
 {
     const int BN = 32 * NP, RT1 = 5, NO = 32;
-    const size_t r1a = (size_t)2 * RT1 * 32 * 40 + (size_t)2 * 4 * BN * 8, r1b = (size_t)2 * NO * (BN + 8) + (size_t)2 * 8 * BN * 8;
+    const size_t r1a = (size_t)2 * RT1 * 32 * 40 + (size_t)2 * 4 * BN * 8, r1b = (size_t)2 * NO * (BN + 8) + (size_t)2 * 8 * BN * 8 + (size_t)2 * NO * 40 + (size_t)2 * 4 * BN * 8;
     const size_t r1 = r1a > r1b ? r1a : r1b;
     return ((r1 + 1) / 2) * sizeof(float) + (size_t)160 * (bf + 2) * sizeof(float) + 160;       // + the window's inside flags
 }
@@ -925,7 +1024,8 @@ static size_t down_unit_lds(int bf, int NP)
 bool down_unit_covers(const DownArgs& a)
 {
     return a.W1h && a.W1l && a.W2h && a.W2l && a.cin <= 32 && !(a.cin & 1) && a.bf <= 64 && !(a.bf & 1) && a.Npad1 == a.Npad2 && a.Npad1 <= 64 &&
-           !(a.H & 1) && !(a.W & 1) && a.pass && a.B > 0;
+           !(a.H & 1) && !(a.W & 1) && a.B > 0 && a.cin >= 16 &&
+           (a.pass || (a.wdw1 && a.bdw1 && a.W3h && a.W3l && a.b3 && a.Npad3 == a.Npad1));
 }
 
 void launch_down_unit(const DownArgs& a, hipStream_t s)

@@ -744,30 +744,46 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         snprintf(nm, sizeof nm, "backbone.stage%d.0", si + 2);
         const std::string P0 = nm;
         // stride-2 block: backbone/shufflenetv2.py:73-74
-        fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
         {
-            run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
-            run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
-            back_to_main(h);
-            // branch 2 as ONE kernel where the tile fits (cin <= 32, bf <= 64: stage 2, whose pw1 output is the largest tensor of the network)
+            // the whole unit as ONE kernel where its tile fits (cin <= 32, bf <= 64: stage 2, whose pw1 output is the largest tensor of the
+            // network): branch 2 = pw1 -> depthwise s2 -> pw2, branch 1 = depthwise s2 -> pw, concat + shuffle in the store
             const Layer &lp1 = L(h, P0 + ".b2.pw1"), &ldw = L(h, P0 + ".b2.dw"), &lp2 = L(h, P0 + ".b2.pw2");
+            const Layer &l1d = L(h, P0 + ".b1.dw"), &l1p = L(h, P0 + ".b1.pw");
             DownArgs d{};
             d.x = cur; d.cin = curC;
             d.W1h = lp1.ws_hi; d.W1l = lp1.ws_lo; d.b1 = lp1.b_packed; d.act1 = lp1.act; d.Npad1 = lp1.Npad;
             d.wdw = ldw.w_packed; d.bdw = ldw.b_packed; d.dw_act = ldw.act;
             d.W2h = lp2.ws_hi; d.W2l = lp2.ws_lo; d.b2 = lp2.b_packed; d.act2 = lp2.act; d.Npad2 = lp2.Npad;
-            d.pass = tb1; d.out = oA; d.B = B; d.H = curH; d.W = curH; d.bf = bf;
-            if (h->down_fuse && !h->exact_f32 && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 && down_unit_covers(d)) {
-                join_from(h, 0);
-                if (!dbg_skip(h, P0 + ".b2")) {
-                    Bracket br(h, P0 + ".b2", 2.0 * (Mi * curC * bf + Mo * bf * (9.0 + bf)), 4.0 * (Mi * (double)curC + 3.0 * Mo * bf + (double)curC * bf + (double)bf * bf));
+            d.pass = nullptr;
+            d.wdw1 = l1d.w_packed; d.bdw1 = l1d.b_packed; d.dw1_act = l1d.act;
+            d.W3h = l1p.ws_hi; d.W3l = l1p.ws_lo; d.b3 = l1p.b_packed; d.act3 = l1p.act; d.Npad3 = l1p.Npad;
+            d.out = oA; d.B = B; d.H = curH; d.W = curH; d.bf = bf;
+            const bool use_down = h->down_fuse && !h->exact_f32 && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 &&
+                                  l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && down_unit_covers(d);
+            static const int down_b1 = getenv("YN_DOWN_B1") ? atoi(getenv("YN_DOWN_B1")) : 1;      // 0: branch 1 as its own two kernels (A/B runs)
+            if (use_down && !down_b1) {
+                run_dw(h, l1d, cur, curC, 0, B, curH, curH, tdw1, curC, 0);
+                run_pw(h, l1p, tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+                d.pass = tb1;
+                Bracket br(h, P0 + ".b2", 2.0 * (Mi * curC * bf + Mo * bf * (9.0 + bf)), 4.0 * (Mi * (double)curC + 3.0 * Mo * bf + (double)curC * bf + (double)bf * bf));
+                launch_down_unit(d, h->cur);
+            } else if (use_down) {
+                if (!dbg_skip(h, P0 + ".unit")) {
+                    Bracket br(h, P0 + ".unit", 2.0 * (Mi * curC * bf + Mo * bf * (9.0 + bf) + Mo * curC * (9.0 + bf)),
+                               4.0 * (Mi * (double)curC + 2.0 * Mo * bf + 2.0 * (double)curC * bf + (double)bf * bf));
                     launch_down_unit(d, h->cur);
                 }
             } else {
+        fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
+        {
+            run_dw(h, L(h, P0 + ".b1.dw"), cur, curC, 0, B, curH, curH, tdw1, curC, 0);
+            run_pw(h, L(h, P0 + ".b1.pw"), tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
+            back_to_main(h);
             run_pw(h, L(h, P0 + ".b2.pw1"), cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
             run_dw(h, L(h, P0 + ".b2.dw"), t1, bf, 0, B, curH, curH, t2, bf, 0);
             join_from(h, 0);
             run_pw(h, L(h, P0 + ".b2.pw2"), t2, bf, 0, Mo, oA, C, 0, tb1, bf, 0);     // cat + shuffle fused
+        }
             }
         }
         float* o_cur = oA;

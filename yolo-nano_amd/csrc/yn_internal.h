@@ -52,7 +52,9 @@ struct DownArgs {
     const void *W1h, *W1l; const float* b1; int act1, Npad1;       // pw1: split packs [ceil(cin/8)][Npad1][8], bias, activation
     const float* wdw; const float* bdw; int dw_act;                // depthwise [9][bf], [bf]
     const void *W2h, *W2l; const float* b2; int act2, Npad2;       // pw2: split packs [ceil(bf/8)][Npad2][8]
-    const float* pass;                          // branch-1 output [B][Ho][Wo][bf]
+    const float* pass;                          // branch-1 output [B][Ho][Wo][bf], or null: branch 1 is computed here too (the members below)
+    const float* wdw1; const float* bdw1; int dw1_act;             // branch 1 depthwise (stride 2, on x): [9][cin], [cin]
+    const void *W3h, *W3l; const float* b3; int act3, Npad3;       // branch 1 pointwise cin -> bf
     float* out;                                 // [B][Ho][Wo][2*bf]: out[2n] = pass[n], out[2n+1] = pw2[n]
     int B, H, W, bf;
 };
