@@ -889,7 +889,7 @@ def test_grouped_launches_are_bit_identical(hcoco, hvoc, which, S, B):
         h.infer(x)
         names = [r[0] for r in h.profile_records()]
         h.profile_enable(False)
-        assert sum(n.startswith("head_det_") for n in names) == 5, names
+        assert sum(n.startswith("head_det_") for n in names) in (3, 5), names      # 3: depthwise + pointwise pairs fused as well
     finally:
         h.fuse_decode(True)
         h.group_launch(True)

@@ -1043,6 +1043,169 @@ void launch_down_unit(const DownArgs& a, hipStream_t s)
     else         { set_last_kernel_name("down_unit_kernel<2>"); hipLaunchKernelGGL(down_unit_kernel<2>, dim3(xcd_grid(tiles)), dim3(256), lds, s, a); }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Depthwise 3x3 + pointwise conv of a detection head (models/yolo_nano.py:60-82: Conv(96, 96, k=3, g=96) -> Conv(96, 96, k=1)) as one
+// kernel, for up to three pyramid levels per launch (Group<>).  The depthwise output of the stride-8 head is 33 MB per 32-image step,
+// written by one launch and read back by the next; here it goes from registers into the GEMM's LDS operand planes.  Workgroup = an 8 x 4
+// tile of pixels of one image: thread = (4 channels, a run of 4 pixels along x) with its 3 x 6 window in ONE batch of clamped, masked
+// loads (dwconv3x3_kernel's thread, the same fma chain), the whole 96 x 96 pre-split weight matrix in LDS (no K-chunk barriers), three
+// wavefronts = the three 32-column tiles, 16-byte stores through the in-quad transpose.  Bit-identical to dwconv3x3_kernel +
+// gemm_split_kernel.  LDS 50 KB: three workgroups per CU.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsigned bid, unsigned nblocks)
+{
+    constexpr int TW = 8, TH = 4, NO = TW * TH, C = 96, KQ = C / 8, BN = 96, AST = C + 8, R = 4;
+    uch16* Ah = smem;                                       // [NO][AST]
+    uch16* Al = Ah + NO * AST;
+    uch16* Bs = Al + NO * AST;                              // [2][KQ][BN][8]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tx_n = (a.W + TW - 1) / TW, ty_n = (a.H + TH - 1) / TH;
+    const int tile = (int)xcd_block(bid, nblocks);
+    if (tile >= a.B * ty_n * tx_n) return;
+    const int b = tile / (ty_n * tx_n), trem = tile - b * (ty_n * tx_n);
+    const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
+
+    // ---- 1. every load of the workgroup in one batch: depthwise windows, taps, bias; the weight matrix; the GEMM bias ------------------
+    const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs (2 per tile row) = 192 workers
+    const bool worker = run < NO / R;
+    const int c = cq * 4, ry = run >> 1, rx = (run & 1) * R;
+    const int oy = oy0 + ry;
+    float4 win[3][R + 2], wd[9], bd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (worker) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            const bool yok = oy < a.H && iy >= 0 && iy < a.H;
+            const float* rowp = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * C + c;
+#pragma unroll
+            for (int j = 0; j < R + 2; ++j) {
+                const int ix = ox0 + rx - 1 + j;
+                const bool ok = yok && ix >= 0 && ix < a.W;
+                win[ky][j] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(a.wdw + k * C + c);
+        bd = *reinterpret_cast<const float4*>(a.bdw + c);
+    }
+    constexpr int B_PER = (2 * KQ * BN + 255) / 256;        // 9 granules of 16 bytes per thread
+    uch16x8 b_reg[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int g = t + 256 * i;                          // plane, octet, column
+        const int pl = g / (KQ * BN), r = g - pl * (KQ * BN);
+        const int o = r / BN, n = r - o * BN;
+        uch16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+        if (g < 2 * KQ * BN) v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? a.Wl : a.Wh) + ((size_t)o * a.Npad + n) * 8);
+        b_reg[i] = v;
+    }
+    const float gbias = (wave < 3) ? a.bias[wave * 32 + l31] : 0.0f;
+
+    // ---- 2. depthwise (dwconv3x3_kernel's chain) -> split planes; weights -> LDS -------------------------------------------------------
+    if (worker) {
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            float4 acc = bd;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) vfma(acc, win[ky][o + kx], wd[ky * 3 + kx]);
+            acc = vact(acc, a.dw_act);
+            const int op = ry * TW + rx + o;
+            const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
+            uch16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
+            *reinterpret_cast<uch16x4*>(Ah + op * AST + c) = hi;
+            *reinterpret_cast<uch16x4*>(Al + op * AST + c) = lo;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int g = t + 256 * i;
+        if (g < 2 * KQ * BN) *reinterpret_cast<uch16x8*>(Bs + (size_t)g * 8) = b_reg[i];
+    }
+    __syncthreads();
+
+    // ---- 3. pointwise conv: three wavefronts, 32 x 32 each, K = 96 in gemm_split_tile's order; bias, activation, 16-byte stores -----------
+    if (wave < 3) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+        const uch16* Ahb = Ah + l31 * AST + h * 8;
+        const uch16* Alb = Al + l31 * AST + h * 8;
+        const uch16* Bhb = Bs + (size_t)(h * BN + wave * 32 + l31) * 8;
+        const uch16* Blb = Bhb + (size_t)KQ * BN * 8;
+#pragma unroll
+        for (int ks = 0; ks < KQ / 2; ++ks) {
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+            const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN) * 8);
+            const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN) * 8);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+        }
+        const int j = lane & 3;
+        const int nq = wave * 32 + (l31 & ~3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = apply_act(__builtin_fmaf(acc1[4 * g + 0], 1.0f / 2048.0f, acc0[4 * g + 0]) + gbias, a.act);
+            float v1 = apply_act(__builtin_fmaf(acc1[4 * g + 1], 1.0f / 2048.0f, acc0[4 * g + 1]) + gbias, a.act);
+            float v2 = apply_act(__builtin_fmaf(acc1[4 * g + 2], 1.0f / 2048.0f, acc0[4 * g + 2]) + gbias, a.act);
+            float v3 = apply_act(__builtin_fmaf(acc1[4 * g + 3], 1.0f / 2048.0f, acc0[4 * g + 3]) + gbias, a.act);
+            {   // 2x2 blocks, then 4x4: lane j of the quad ends up with row j x 4 columns (gemm_epilogue's transpose)
+                const float s0 = (j & 1) ? v0 : v1, s1 = (j & 1) ? v2 : v3;
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
+                if (j & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            }
+            {
+                const float s0 = (j & 2) ? v0 : v2, s1 = (j & 2) ? v1 : v3;
+                const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
+                if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+            }
+            const int op = 8 * g + 4 * h + j;
+            const int py = oy0 + op / TW, px = ox0 + op % TW;
+            if (py < a.H && px < a.W)
+                *reinterpret_cast<float4*>(a.out + (((size_t)b * a.H + py) * a.W + px) * C + nq) = make_float4(v0, v1, v2, v3);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void dwpw_group_kernel(Group<DwPwArgs> g)
+{
+    extern __shared__ __attribute__((aligned(16))) float dwpw_smem[];
+    unsigned local, nb;
+    const int p = group_problem(g.first, blockIdx.x, local, nb);
+    dwpw_block(g.a[p], reinterpret_cast<uch16*>(dwpw_smem), local, nb);
+}
+
+bool dwpw_group_ok(const DwPwArgs* a, int n)
+{
+    if (n < 1 || n > YN_GROUP_MAX) return false;
+    for (int p = 0; p < n; ++p)
+        if (a[p].C != 96 || a[p].Npad != 96 || !a[p].Wh || !a[p].Wl || a[p].B <= 0) return false;
+    return true;
+}
+
+void launch_dwpw_group(const DwPwArgs* a, int n, hipStream_t s)
+{
+    Group<DwPwArgs> g{};
+    unsigned tot = 0;
+    for (int p = 0; p < YN_GROUP_MAX; ++p) {
+        g.first[p] = tot;
+        if (p < n) { g.a[p] = a[p]; tot += xcd_grid((unsigned)a[p].B * ((a[p].H + 3) / 4) * ((a[p].W + 7) / 8)); }
+    }
+    g.first[YN_GROUP_MAX] = tot;
+    const size_t lds = ((size_t)2 * 32 * 104 + (size_t)2 * 12 * 96 * 8) * 2;
+    static unsigned long long attr = 0;
+    if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set_last_kernel_name("dwpw_group_kernel");
+    hipLaunchKernelGGL(dwpw_group_kernel, dim3(tot), dim3(256), lds, s, g);
+}
+
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
 bool unit_chain_covers(const ChainArgs& a) { return unit_chain_dispatch(a, nullptr, true); }
 

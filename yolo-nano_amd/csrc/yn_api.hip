@@ -120,6 +120,7 @@ struct yn_handle {
     // graphs / profiling
     bool use_graph = false;
     long net_passes = 0;                   // run_network calls so far (dbg_skip)
+    bool dwpw_fuse = true;                 // YN_DWPW_FUSE=0: the heads' depthwise + pointwise pairs as two grouped launches instead of one kernel
     bool down_fuse = true;                 // yn_down_fuse / YN_DOWN_FUSE=0: the main branch of a stride-2 unit as one kernel (down_unit_kernel)
     bool group_launch = true;              // yn_group_launch / YN_GROUP=0: the three heads' layers (and the laterals) as grouped launches
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
@@ -904,8 +905,30 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                 g3[hd] = pw_args(h, *hl[k][hd], src[hd], NECK, 0, (long)B * Ws[hd] * Ws[hd], dst[hd], dst_ld, 0, nullptr, 0, 0, n_store);
             return run_pw_group(h, hl[k], g3, 3, name);
         };
-        bool ok = dw_layer(0, nullptr, feats, hA, "head_det_*.0") && pw_layer(1, hA, hB, NECK, 0, "head_det_*.1") &&
-                  dw_layer(2, hB, nullptr, hA, "head_det_*.2") && pw_layer(3, hA, hC, NECK, 0, "head_det_*.3");
+        // depthwise + pointwise pairs as one grouped kernel each (the depthwise output never reaches memory), else two grouped launches each
+        auto dwpw_layer = [&](int kd, float* const src_own[3], const float* const src_feat[3], float* const dst[3], const char* name) {
+            DwPwArgs q[3];
+            double fl = 0, by = 0;
+            for (int hd = 0; hd < 3; ++hd) {
+                const Layer &ld = *hl[kd][hd], &lp = *hl[kd + 1][hd];
+                q[hd] = DwPwArgs{};
+                q[hd].in = src_feat ? src_feat[hd] : src_own[hd];
+                q[hd].wdw = ld.w_packed; q[hd].bdw = ld.b_packed; q[hd].dw_act = ld.act;
+                q[hd].Wh = lp.ws_hi; q[hd].Wl = lp.ws_lo; q[hd].bias = lp.b_packed; q[hd].act = lp.act; q[hd].Npad = lp.Npad;
+                q[hd].out = dst[hd]; q[hd].B = B; q[hd].H = Ws[hd]; q[hd].W = Ws[hd]; q[hd].C = ld.cout;
+                if (ld.stride != 1 || ld.cout != NECK || lp.cin != NECK || lp.cout != NECK) return false;
+                const double M = (double)B * Ws[hd] * Ws[hd];
+                fl += 2.0 * M * NECK * (9.0 + NECK);
+                by += 4.0 * (2.0 * M * NECK + (double)NECK * NECK);
+            }
+            if (!h->dwpw_fuse || !dwpw_group_ok(q, 3)) return false;
+            if (dbg_skip(h, name)) return true;
+            Bracket br(h, name, fl, by);
+            launch_dwpw_group(q, 3, h->cur);
+            return true;
+        };
+        bool ok = (dwpw_layer(0, nullptr, feats, hB, "head_det_*.0+1") || (dw_layer(0, nullptr, feats, hA, "head_det_*.0") && pw_layer(1, hA, hB, NECK, 0, "head_det_*.1"))) &&
+                  (dwpw_layer(2, hB, nullptr, hC, "head_det_*.2+3") || (dw_layer(2, hB, nullptr, hA, "head_det_*.2") && pw_layer(3, hA, hC, NECK, 0, "head_det_*.3")));
         if (ok) {
             if (fuse_all) {
                 GemmArgs g3[3];
@@ -1008,6 +1031,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
     if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
     if (const char* e10 = getenv("YN_DOWN_FUSE")) h->down_fuse = atoi(e10) != 0;
+    if (const char* e11 = getenv("YN_DWPW_FUSE")) h->dwpw_fuse = atoi(e11) != 0;
     if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain

@@ -58,6 +58,16 @@ struct DownArgs {
     float* out;                                 // [B][Ho][Wo][2*bf]: out[2n] = pass[n], out[2n+1] = pw2[n]
     int B, H, W, bf;
 };
+// depthwise 3x3 (stride 1) + pointwise conv of a detection head as one kernel (kernels_chain.hip, dwpw_group_kernel): C = Cout = 96
+struct DwPwArgs {
+    const float* in;                            // [B][H][W][C] dense
+    const float* wdw; const float* bdw; int dw_act;                // depthwise [9][C], [C]
+    const void *Wh, *Wl; const float* bias; int act, Npad;         // pointwise: split packs [C/8][Npad][8]
+    float* out;                                 // [B][H][W][C] dense
+    int B, H, W, C;
+};
+bool dwpw_group_ok(const DwPwArgs* a, int n);
+void launch_dwpw_group(const DwPwArgs* a, int n, hipStream_t s);
 bool down_unit_covers(const DownArgs& a);
 void launch_down_unit(const DownArgs& a, hipStream_t s);
 bool unit_chain_covers(const ChainArgs& a);     // same selection, nothing launched
