@@ -1052,9 +1052,10 @@ void launch_down_unit(const DownArgs& a, hipStream_t s)
 // wavefronts = the three 32-column tiles, 16-byte stores through the in-quad transpose.  Bit-identical to dwconv3x3_kernel +
 // gemm_split_kernel.  LDS 50 KB: three workgroups per CU.
 // -------------------------------------------------------------------------------------------------
+template <int TH>                                           // tile height: 8 x TH pixels per workgroup, TH / 4 runs per thread
 __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsigned bid, unsigned nblocks)
 {
-    constexpr int TW = 8, TH = 4, NO = TW * TH, C = 96, KQ = C / 8, BN = 96, AST = C + 8, R = 4;
+    constexpr int TW = 8, NO = TW * TH, C = 96, KQ = C / 8, BN = 96, AST = C + 8, R = 4, NR = TH / 4;
     uch16* Ah = smem;                                       // [NO][AST]
     uch16* Al = Ah + NO * AST;
     uch16* Bs = Al + NO * AST;                              // [2][KQ][BN][8]
@@ -1066,22 +1067,25 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
     const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
 
     // ---- 1. every load of the workgroup in one batch: depthwise windows, taps, bias; the weight matrix; the GEMM bias ------------------
-    const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs (2 per tile row) = 192 workers
-    const bool worker = run < NO / R;
+    const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs (2 per tile row, rows run/2 + 4 i) = 192 workers
+    const bool worker = run < 8;
     const int c = cq * 4, ry = run >> 1, rx = (run & 1) * R;
-    const int oy = oy0 + ry;
-    float4 win[3][R + 2], wd[9], bd = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 win[NR][3][R + 2], wd[9], bd = make_float4(0.f, 0.f, 0.f, 0.f);
     if (worker) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy - 1 + ky;
-            const bool yok = oy < a.H && iy >= 0 && iy < a.H;
-            const float* rowp = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * C + c;
+        for (int i = 0; i < NR; ++i) {
+            const int oy = oy0 + ry + 4 * i;
 #pragma unroll
-            for (int j = 0; j < R + 2; ++j) {
-                const int ix = ox0 + rx - 1 + j;
-                const bool ok = yok && ix >= 0 && ix < a.W;
-                win[ky][j] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy - 1 + ky;
+                const bool yok = oy < a.H && iy >= 0 && iy < a.H;
+                const float* rowp = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * C + c;
+#pragma unroll
+                for (int j = 0; j < R + 2; ++j) {
+                    const int ix = ox0 + rx - 1 + j;
+                    const bool ok = yok && ix >= 0 && ix < a.W;
+                    win[i][ky][j] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+                }
             }
         }
 #pragma unroll
@@ -1106,14 +1110,16 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
     // ---- 2. depthwise (dwconv3x3_kernel's chain) -> split planes; weights -> LDS -------------------------------------------------------
     if (worker) {
 #pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
         for (int o = 0; o < R; ++o) {
             float4 acc = bd;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) vfma(acc, win[ky][o + kx], wd[ky * 3 + kx]);
+                for (int kx = 0; kx < 3; ++kx) vfma(acc, win[i][ky][o + kx], wd[ky * 3 + kx]);
             acc = vact(acc, a.dw_act);
-            const int op = ry * TW + rx + o;
+            const int op = (ry + 4 * i) * TW + rx + o;
             const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
             uch16x4 hi, lo;
 #pragma unroll
@@ -1131,11 +1137,13 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
 
     // ---- 3. pointwise conv: three wavefronts, 32 x 32 each, K = 96 in gemm_split_tile's order; bias, activation, 16-byte stores -----------
     if (wave < 3) {
+#pragma unroll
+        for (int rt = 0; rt < NO / 32; ++rt) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
-        const uch16* Ahb = Ah + l31 * AST + h * 8;
-        const uch16* Alb = Al + l31 * AST + h * 8;
+        const uch16* Ahb = Ah + (rt * 32 + l31) * AST + h * 8;
+        const uch16* Alb = Al + (rt * 32 + l31) * AST + h * 8;
         const uch16* Bhb = Bs + (size_t)(h * BN + wave * 32 + l31) * 8;
         const uch16* Blb = Bhb + (size_t)KQ * BN * 8;
 #pragma unroll
@@ -1166,20 +1174,22 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
                 const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
                 if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
             }
-            const int op = 8 * g + 4 * h + j;
+            const int op = rt * 32 + 8 * g + 4 * h + j;
             const int py = oy0 + op / TW, px = ox0 + op % TW;
             if (py < a.H && px < a.W)
                 *reinterpret_cast<float4*>(a.out + (((size_t)b * a.H + py) * a.W + px) * C + nq) = make_float4(v0, v1, v2, v3);
         }
+        }
     }
 }
 
-__global__ __launch_bounds__(256, 3) void dwpw_group_kernel(Group<DwPwArgs> g)
+template <int TH>
+__global__ __launch_bounds__(256, (TH == 4 ? 3 : 2)) void dwpw_group_kernel(Group<DwPwArgs> g)
 {
     extern __shared__ __attribute__((aligned(16))) float dwpw_smem[];
     unsigned local, nb;
     const int p = group_problem(g.first, blockIdx.x, local, nb);
-    dwpw_block(g.a[p], reinterpret_cast<uch16*>(dwpw_smem), local, nb);
+    dwpw_block<TH>(g.a[p], reinterpret_cast<uch16*>(dwpw_smem), local, nb);
 }
 
 bool dwpw_group_ok(const DwPwArgs* a, int n)
@@ -1192,18 +1202,26 @@ bool dwpw_group_ok(const DwPwArgs* a, int n)
 
 void launch_dwpw_group(const DwPwArgs* a, int n, hipStream_t s)
 {
+    static const int th_env = getenv("YN_DWPW_TH") ? atoi(getenv("YN_DWPW_TH")) : 0;
+    unsigned tiles4 = 0;
+    for (int p = 0; p < n; ++p) tiles4 += (unsigned)a[p].B * ((a[p].H + 3) / 4) * ((a[p].W + 7) / 8);
+    (void)tiles4;
+    const int TH = th_env == 8 ? 8 : 4;                     // 64-pixel tiles (half the weight traffic) measured the same end to end, 43 vs 39 us alone: YN_DWPW_TH=8 keeps them for A/B runs
     Group<DwPwArgs> g{};
     unsigned tot = 0;
     for (int p = 0; p < YN_GROUP_MAX; ++p) {
         g.first[p] = tot;
-        if (p < n) { g.a[p] = a[p]; tot += xcd_grid((unsigned)a[p].B * ((a[p].H + 3) / 4) * ((a[p].W + 7) / 8)); }
+        if (p < n) { g.a[p] = a[p]; tot += xcd_grid((unsigned)a[p].B * ((a[p].H + TH - 1) / TH) * ((a[p].W + 7) / 8)); }
     }
     g.first[YN_GROUP_MAX] = tot;
-    const size_t lds = ((size_t)2 * 32 * 104 + (size_t)2 * 12 * 96 * 8) * 2;
+    const size_t lds = ((size_t)2 * 8 * TH * 104 + (size_t)2 * 12 * 96 * 8) * 2;
     static unsigned long long attr = 0;
-    if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    set_last_kernel_name("dwpw_group_kernel");
-    hipLaunchKernelGGL(dwpw_group_kernel, dim3(tot), dim3(256), lds, s, g);
+    if (attr_pending(attr)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_group_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwpw_group_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (TH == 8) { set_last_kernel_name("dwpw_group_kernel<8>"); hipLaunchKernelGGL(dwpw_group_kernel<8>, dim3(tot), dim3(256), lds, s, g); }
+    else         { set_last_kernel_name("dwpw_group_kernel<4>"); hipLaunchKernelGGL(dwpw_group_kernel<4>, dim3(tot), dim3(256), lds, s, g); }
 }
 
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s) { return unit_chain_dispatch(a, s, false); }
