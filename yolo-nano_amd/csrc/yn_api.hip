@@ -633,7 +633,42 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
 // ---- grouped launches (Group<>, yn_internal.h): the same layer of the three detection heads / the three laterals as ONE launch ----
 bool run_pw_group(yn_handle* h, const Layer* const l[], GemmArgs a[], int n, const char* name)
 {
-    a[0].cfg = tune_pw(h, a[0]);                            // the tile of the largest problem; every split configuration gives the same bits
+    // the tile configuration is timed for the GROUP (one launch of every split configuration, as tune_pw does for a single layer): the
+    // best tile of the largest problem can leave a small-M / long-K member with a handful of serial workgroups (the laterals: K = 464 on
+    // 5 408 pixels rode for 57 us on the 128-row tile of the 86 528-pixel member).  Every split configuration gives the same bits.
+    a[0].cfg = -1;
+    if (h->autotune && h->force_pw_cfg < 0) {
+        std::vector<int> key = {h->cfg.device, -n};
+        for (int p = 0; p < n; ++p) { key.push_back(a[p].M); key.push_back(a[p].K); key.push_back(a[p].N); key.push_back(a[p].in_ld); key.push_back(a[p].out_ld); }
+        bool found = false;
+        {
+            std::lock_guard<std::mutex> lk(g_tune_mutex);
+            auto it = g_pw_tuned.find(key);
+            if (it != g_pw_tuned.end()) { a[0].cfg = it->second; found = true; }
+        }
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (!found && !h->profiling && hipStreamIsCapturing(h->cur, &st) == hipSuccess && st == hipStreamCaptureStatusNone) {
+            if (!h->tune_e0) { (void)hipEventCreate(&h->tune_e0); (void)hipEventCreate(&h->tune_e1); }
+            int best = -1;
+            float best_ms = 1e30f;
+            for (int round = 0; round < 2; ++round)
+                for (int c = pw_f32_config_count(); c < pw_config_count(); ++c) {
+                    if (!launch_pw_group(a, n, c, h->cur)) continue;                 // warm-up
+                    (void)hipEventRecord(h->tune_e0, h->cur);
+                    for (int r = 0; r < 5; ++r) (void)launch_pw_group(a, n, c, h->cur);
+                    (void)hipEventRecord(h->tune_e1, h->cur);
+                    if (hipEventSynchronize(h->tune_e1) != hipSuccess) { best = -1; break; }
+                    float ms = 0.0f;
+                    (void)hipEventElapsedTime(&ms, h->tune_e0, h->tune_e1);
+                    if (ms < best_ms) { best_ms = ms; best = c; }
+                }
+            if (best >= 0) {
+                std::lock_guard<std::mutex> lk(g_tune_mutex);
+                g_pw_tuned[key] = best;
+                a[0].cfg = best;
+            }
+        }
+    } else if (h->force_pw_cfg >= 0) a[0].cfg = h->force_pw_cfg;
     if (dbg_skip(h, name)) return true;
     double fl = 0, by = 0;
     for (int p = 0; p < n; ++p) {
@@ -816,10 +851,13 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     if (h->group_launch && !h->exact_f32) {
         const Layer* ll[3] = {&L(h, "conv1x1_0"), &L(h, "conv1x1_1"), &L(h, "conv1x1_2")};
         if (ll[0]->ws_hi && ll[1]->ws_hi && ll[2]->ws_hi) {
-            GemmArgs g3[3] = {pw_args(h, *ll[0], cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0),
+            // longest K first: a workgroup of the K = 464 lateral runs 15 chunk rounds against 4 for the stride-8 one, and workgroups start
+            // in id order - last in the grid, the few long ones were a 25 us tail behind the many short ones
+            const Layer* lo[3] = {ll[2], ll[1], ll[0]};
+            GemmArgs g3[3] = {pw_args(h, *ll[2], cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0),
                               pw_args(h, *ll[1], cfeat[1], h->stage_ch[1], 0, M4, p4, NECK, 0, nullptr, 0, 0),
-                              pw_args(h, *ll[2], cfeat[2], h->stage_ch[2], 0, M5, p5, NECK, 0, nullptr, 0, 0)};
-            lat_grouped = run_pw_group(h, ll, g3, 3, "conv1x1_*");
+                              pw_args(h, *ll[0], cfeat[0], h->stage_ch[0], 0, M3, p3, NECK, 0, nullptr, 0, 0)};
+            lat_grouped = run_pw_group(h, lo, g3, 3, "conv1x1_*");
         }
     }
     if (!lat_grouped) {
