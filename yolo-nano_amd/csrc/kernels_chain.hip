@@ -835,44 +835,40 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     __syncthreads();
     YN_TS();
 
-    // ---- 2. y1 = act(pw1) on the window pixels -> T32 (zero outside the image) ------------------------------------------------
-    for (int rt = wave; rt < RT1; rt += 4) {
-        f32x16 acc0[NP], acc1[NP];
+    // ---- 2. y1 = act(pw1) on the window pixels -> T32 (zero outside the image): RT1 x NP (row tile, 32-column tile) items over the four
+    //      wavefronts (10 items: 3, 3, 2, 2 - whole row tiles would be 2, 1, 1, 1 with twice the work each) -----------------------------
+    for (int it = wave; it < RT1 * NP; it += 4) {
+        const int rt = it / NP, nt = it - rt * NP;
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int i = 0; i < NP; ++i)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
         const uch16* Ahb = A1h + (rt * 32 + l31) * AST1 + h * 8;
         const uch16* Alb = A1l + (rt * 32 + l31) * AST1 + h * 8;
-        const uch16* Bhb = B1 + (size_t)(h * BN + l31) * 8;
+        const uch16* Bhb = B1 + (size_t)(h * BN + nt * 32 + l31) * 8;
         const uch16* Blb = Bhb + 4 * BN * 8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
             const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
-#pragma unroll
-            for (int nt = 0; nt < NP; ++nt) {
-                const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
-            }
+            const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN) * 8);
+            const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN) * 8);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
         }
         unsigned in16 = 0;                                  // inside flags of this lane's 16 rows
 #pragma unroll
         for (int r = 0; r < 16; ++r) in16 |= (unsigned)inside[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] << r;
+        const int n = nt * 32 + l31;
+        float bias = 0.0f;
 #pragma unroll
-        for (int nt = 0; nt < NP; ++nt) {
-            const int n = nt * 32 + l31;
-            const float bias = bias1[nt];
-            if (n < bf) {
+        for (int q = 0; q < NP; ++q) bias = (q == nt) ? bias1[q] : bias;
+        if (n < bf) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float v = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias, a.act1);
-                    T32[p * CS + n] = __uint_as_float(__float_as_uint(v) & (0u - ((in16 >> r) & 1u)));
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int p = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = apply_act(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias, a.act1);
+                T32[p * CS + n] = __uint_as_float(__float_as_uint(v) & (0u - ((in16 >> r) & 1u)));
             }
         }
     }
