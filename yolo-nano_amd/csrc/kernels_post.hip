@@ -603,9 +603,9 @@ __device__ __forceinline__ size_t band_off(int ri, int T) { return (size_t)64 * 
 __device__ __forceinline__ float vmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// word of sorted item ri*64+lane: bit t = "it suppresses sorted item ci*64+t" (columns after itself only on the diagonal tile)
 template <bool DIOU>
-__device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh,
-                                            u64* __restrict__ M, float4* cbox, float* carea)
+__device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, int ri, int ci, float thresh, float4* cbox, float* carea)
 {
     const int lane = threadIdx.x & 63;
     const int jc = ci * 64 + lane;
@@ -675,8 +675,16 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
             if (suppressed(bx, ar, bt, carea[t], thresh, DIOU ? 1 : 0)) mask |= 1ull << t;
         }
     }
-    M[band_off(ri, T) + (size_t)lane * (T - ri) + (ci - ri)] = mask;
     __builtin_amdgcn_wave_barrier();
+    return mask;
+}
+
+template <bool DIOU>
+__device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh,
+                                            u64* __restrict__ M, float4* cbox, float* carea)
+{
+    const u64 mask = tile_word<DIOU>(sb, n, ri, ci, thresh, cbox, carea);
+    M[band_off(ri, T) + (size_t)(threadIdx.x & 63) * (T - ri) + (ci - ri)] = mask;
 }
 
 // grid (G, B), block 64: block g of image b walks tiles g, g+G, ... of that image
@@ -869,6 +877,102 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict_
                     M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
 
+// ---- first-chunk prefilter ---------------------------------------------------------------------------------------------------------
+// The bit matrix costs n^2/2 pairs per class, and on clustered classes almost all of them are wasted: the benchmark's 1 181-box class
+// keeps 13 boxes.  The 64 best-scored boxes of a segment can be resolved on their own (nothing outside the chunk precedes them), and
+// every later box one of their KEPT boxes suppresses is out for good — a removed box suppresses nothing, so dropping it before the dense
+// phase cannot change any other decision.  One workgroup per segment: diagonal tile of chunk 0 + its serial resolve (wave 0), then the
+// band (0, ci) for every later chunk (the dense tile code, row words OR-ed over the kept rows), then an order-preserving compaction of
+// the survivors into a second candidate list.  matrix / resolve run on that list (chunk 0 is finished: its kept boxes are flagged here).
+// Segments of <= 64 boxes never reach the dense phase.  Exact: the kept sets equal the plain pipeline's (parity suite).
+struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int part[256]; float4 cbox[4][64]; float carea[4][64]; };
+
+__global__ __launch_bounds__(256) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
+                                                             const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
+                                                             int N, int C, float thresh, int32_t* __restrict__ keep,
+                                                             float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2)
+{
+    __shared__ PrefilterLds L;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int n = seg_count[(size_t)b * C + c];
+    if (n == 0) { if (threadIdx.x == 0) seg_count2[(size_t)b * C + c] = 0; return; }
+    const int off = seg_off[(size_t)b * C + c];
+    const float4* sb = sbox + (size_t)b * N + off;
+    const int32_t* ids = bucket + (size_t)b * N + off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const int T = (n + 63) >> 6;
+    float4* cbox = L.cbox[wave];
+    float* carea = L.carea[wave];
+    if (wave == 0) {                                        // chunk 0 among itself: the reference's loop restricted to 64 boxes
+        const u64 diag = tile_word<false>(sb, n, 0, 0, thresh, cbox, carea);
+        const int cnt = min(64, n);
+        u64 alive = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        u64 work = __ballot(((alive >> lane) & 1ull) && (diag & alive));
+        const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+        while (work) {
+            const int i = __ffsll((long long)work) - 1;                                  // alive at its turn: kept
+            const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+            const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+            alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+            work &= alive & ~(1ull << i);
+        }
+        if ((alive >> lane) & 1ull) keep[(size_t)b * N + ids[lane]] = 1;
+        if (lane == 0) L.keepm = alive;
+    }
+    __syncthreads();
+    const u64 keepm = L.keepm;
+    for (int ci = 1 + wave; ci < T; ci += 4) {              // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes
+        u64 w = tile_word<false>(sb, n, 0, ci, thresh, cbox, carea);
+        w = ((keepm >> lane) & 1ull) ? w : 0ull;
+        unsigned lo = (unsigned)(w & 0xffffffffu), hi = (unsigned)(w >> 32);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+        const int cnt = min(64, n - ci * 64);
+        const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        if (lane == 0) L.surv[ci] = valid & ~(((u64)hi << 32) | (u64)lo);
+    }
+    __syncthreads();
+    // order-preserving compaction: exclusive prefix of the chunks' survivor counts (thread = a run of Q chunks, then a block scan)
+    const int Q = (T - 1 + 255) / 256;
+    int mine = 0;
+    for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) mine += __popcll(L.surv[ci]); }
+    L.part[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? L.part[tid - o] : 0;
+        __syncthreads();
+        L.part[tid] += v;
+        __syncthreads();
+    }
+    int run = L.part[tid] - mine;                           // exclusive
+    for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) { L.base[ci] = run; run += __popcll(L.surv[ci]); } }
+    if (tid == 255) seg_count2[(size_t)b * C + c] = L.part[255];
+    __syncthreads();
+    for (int ci = 1 + wave; ci < T; ci += 4) {
+        const u64 m = L.surv[ci];
+        if ((m >> lane) & 1ull) {
+            const int dst = L.base[ci] + __popcll(m & ((1ull << lane) - 1ull));
+            sbox2[(size_t)b * N + off + dst] = sb[ci * 64 + lane];
+            bucket2[(size_t)b * N + off + dst] = ids[ci * 64 + lane];
+        }
+    }
+}
+
+// tile offsets of the prefiltered segments (one thread per image: C is small)
+__global__ void nms_tile_off_kernel(const int32_t* __restrict__ seg_count2, int C, int32_t* __restrict__ tile_off2)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int tiles = 0;
+    for (int c = 0; c < C; ++c) {
+        tile_off2[(size_t)b * (C + 1) + c] = tiles;
+        const int T = (seg_count2[(size_t)b * C + c] + 63) >> 6;
+        tiles += T * (T + 1) / 2;
+    }
+    tile_off2[(size_t)b * (C + 1) + C] = tiles;
+}
+
 // ---- single-class entry (YOLONano.nms): one segment = items 0..n-1 ------------------------------------
 __global__ __launch_bounds__(1024) void single_sort_kernel(const float* __restrict__ dets, const float* __restrict__ scores, int n,
                                                            int32_t* __restrict__ ids, float4* __restrict__ sbox, u64* __restrict__ gscratch)
@@ -1018,15 +1122,27 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap);
     }
+    const int32_t* m_count = wk.seg_count;
+    const int32_t* m_toff = wk.tile_off;
+    const int32_t* m_ids = wk.bucket;
+    const float4* m_box = sbox;
+    static const int prefilter_env = getenv("YN_NMS_PREFILTER") ? atoi(getenv("YN_NMS_PREFILTER")) : 1;
+    if (!diou && prefilter_env && wk.sbox2) {
+        mark("nms_prefilter_kernel");
+        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(C, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2);
+        hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2);
+        m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
+    }
     int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
     if (G < 32) G = 32;
     if (G > 2048) G = 2048;
     mark(diou ? "matrix_kernel<true>" : "matrix_kernel<false>");
     if (skip & 2) {}
-    else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
-    else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.tile_off, N, C, nms_thresh, M, wk.matrix_stride);
+    else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
+    else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
     mark("resolve_kernel");
-    if (!(skip & 4)) hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, N, C, M, wk.matrix_stride, wk.keep);
+    if (!(skip & 4)) hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep);
     mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }

@@ -311,7 +311,7 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     if (need > h->nms_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         void** ptrs[] = {(void**)&h->cand_boxes, (void**)&h->cand_scores, (void**)&h->cand_cls,
-                         (void**)&h->nms.bucket, (void**)&h->nms.keep, (void**)&h->nms.sbox};
+                         (void**)&h->nms.bucket, (void**)&h->nms.keep, (void**)&h->nms.sbox, (void**)&h->nms.bucket2, (void**)&h->nms.sbox2};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->cand_boxes, need * 4 * sizeof(float)));
         HIPCHK(h, hipMalloc((void**)&h->cand_scores, need * sizeof(float)));
@@ -319,17 +319,22 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.bucket, need * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.keep, need * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.sbox, need * 4 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.bucket2, need * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.sbox2, need * 4 * sizeof(float)));
         h->nms_cap = need;
         drop_graphs(h);
     }
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off, (void**)&h->nms.large_list};
+        void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off, (void**)&h->nms.large_list,
+                         (void**)&h->nms.seg_count2, (void**)&h->nms.tile_off2};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.large_list, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.seg_count2, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.tile_off2, need_seg * sizeof(int32_t)));
         h->nms_seg_cap = need_seg;
         drop_graphs(h);
     }
@@ -1094,7 +1099,8 @@ void yn_destroy(yn_handle* h)
         if (l.ws_lo) (void)hipFree(l.ws_lo);
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
-                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial};
+                    h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);

@@ -131,6 +131,8 @@ struct NmsWork {                                // per-handle scratch, sized for
     void*    matrix;                            // [B][matrix_stride] uint64 suppression bit-matrix tiles
     size_t   matrix_stride;                     // words per image
     int32_t* large_list;                        // [B][large_cap+1]  count, then class ids of segments with n > 1024
+    int32_t* bucket2; float* sbox2;             // [B][N], [B][N][4]: the candidates that survive the first-chunk prefilter, per segment at seg_off
+    int32_t* seg_count2; int32_t* tile_off2;    // [B][C], [B][C+1] of that list
     int      large_cap;
 };
 size_t nms_matrix_words_per_image(int N, int C);
