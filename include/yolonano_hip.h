@@ -83,6 +83,10 @@ int  yn_group_launch(yn_handle* h, int enable);
  * width <= 64: stage 2, whose intermediate is the largest tensor of the network); default on, split-f16 family only, bit-identical to
  * the five launches.  Env: YN_DOWN_FUSE=0/1. */
 int  yn_down_fuse(yn_handle* h, int enable);
+/* Per-class NMS (models/yolo_nano.py:159-188, 263-272): resolve the 64 best-scored boxes of every class first and drop every later box
+ * one of their KEPT boxes suppresses before the dense pairwise phase (exact: a removed box suppresses nothing).  mode 0 = off, 1 (default) =
+ * for batches of >= 4 images, 2 = always.  Same kept sets either way.  Env: YN_NMS_PREFILTER=0/1/2. */
+int  yn_nms_prefilter(yn_handle* h, int mode);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on
  * the handle's stream and caches the fastest.  All configurations of a family produce bit-identical results; disabling falls back

@@ -279,11 +279,14 @@ def _pp(h, boxes, conf):
 def test_postprocess_bit_exact(golden, hvoc):
     g = golden("nms.npz")
     hvoc.set_thresholds(float(g["conf_thresh"]), float(g["nms_thresh"]))
-    for k in g["pp_cases"]:
-        b, s, c, _ = _pp(hvoc, g["pp_%s_boxes" % k], g["pp_%s_conf" % k])
-        assert np.array_equal(b, g["pp_%s_out_boxes" % k]), k
-        assert np.array_equal(s, g["pp_%s_out_scores" % k]), k
-        assert np.array_equal(c, g["pp_%s_out_cls" % k]), k
+    for mode in (0, 2):
+        hvoc.nms_prefilter(mode)
+        for k in g["pp_cases"]:
+            b, s, c, _ = _pp(hvoc, g["pp_%s_boxes" % k], g["pp_%s_conf" % k])
+            assert np.array_equal(b, g["pp_%s_out_boxes" % k]), (k, mode)
+            assert np.array_equal(s, g["pp_%s_out_scores" % k]), (k, mode)
+            assert np.array_equal(c, g["pp_%s_out_cls" % k]), (k, mode)
+    hvoc.nms_prefilter(1)
 
 
 def test_postprocess_on_reference_scores(golden, hcoco):
@@ -305,15 +308,18 @@ def test_postprocess_batched_ragged(golden, hvoc):
     half[N // 2:] = 0
     batch_b = np.stack([boxes, boxes, boxes])
     batch_c = np.stack([conf, empty, half])
-    out = hvoc.postprocess(dev(batch_b), dev(batch_c))
-    counts = out[4].cpu().tolist()
-    assert counts[1] == 0
-    for bi, cf in ((0, conf), (2, half)):
-        rb, rs, rc = orc.postprocess(boxes, cf, 0.001, 0.5)
-        k = counts[bi]
-        assert k == len(rs)
-        assert np.array_equal(out[0][bi, :k].cpu().numpy(), rb) and np.array_equal(out[1][bi, :k].cpu().numpy(), rs)
-        assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
+    for mode in (0, 2):                                     # without / with the first-chunk prefilter of the per-class NMS
+        hvoc.nms_prefilter(mode)
+        out = hvoc.postprocess(dev(batch_b), dev(batch_c))
+        counts = out[4].cpu().tolist()
+        assert counts[1] == 0
+        for bi, cf in ((0, conf), (2, half)):
+            rb, rs, rc = orc.postprocess(boxes, cf, 0.001, 0.5)
+            k = counts[bi]
+            assert k == len(rs)
+            assert np.array_equal(out[0][bi, :k].cpu().numpy(), rb) and np.array_equal(out[1][bi, :k].cpu().numpy(), rs)
+            assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
+    hvoc.nms_prefilter(1)
 
 
 # ---- end to end ------------------------------------------------------------------------------------------
@@ -814,8 +820,9 @@ def test_fused_head_decode_is_bit_identical(hcoco, hvoc, which, S, B):
         h.set_grid(old)
 
 
+@pytest.mark.parametrize("prefilter", [0, 2])
 @pytest.mark.parametrize("thresh", [0.5, 0.3, 0.75, 1e-6, 0.0])
-def test_nms_guard_band_stress_vs_oracle(hvoc, thresh):
+def test_nms_guard_band_stress_vs_oracle(hvoc, thresh, prefilter):
     """The matrix kernel decides most pairs without dividing (inter vs thresh*union with a 1e-5 guard band) and sends the rest through
     the reference's own arithmetic.  Boxes built so that many pairs sit within 1e-7 ... 1e-3 of the threshold on either side, plus
     degenerate (zero / negative extent), huge, denormal-sized and NaN boxes, must give the oracle's kept indices exactly."""
@@ -848,6 +855,7 @@ def test_nms_guard_band_stress_vs_oracle(hvoc, thresh):
     conf = np.zeros((n, C), np.float32)
     conf[np.arange(n), np.arange(n) % 3] = scores
     hvoc.set_thresholds(0.001, thresh)
+    hvoc.nms_prefilter(prefilter)                          # 2: the first-chunk prefilter also for this one-image batch
     try:
         rb, rsc, rc = oracle.postprocess(boxes, conf, 0.001, thresh)
         out = hvoc.postprocess(dev(boxes)[None], dev(conf)[None])
@@ -857,6 +865,7 @@ def test_nms_guard_band_stress_vs_oracle(hvoc, thresh):
         assert np.array_equal(out[2][0, :k].cpu().numpy().astype(np.int64), np.asarray(rc).astype(np.int64))
     finally:
         hvoc.set_thresholds(0.001, 0.5)
+        hvoc.nms_prefilter(1)
 
 
 @pytest.mark.parametrize("which,S,B", [("coco", 416, 5), ("coco", 320, 1), ("voc", 320, 2)])

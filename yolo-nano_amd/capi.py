@@ -51,6 +51,7 @@ SIGNATURES = {
     "yn_fuse_decode": (_i32, [_vp, _i32]),
     "yn_group_launch": (_i32, [_vp, _i32]),
     "yn_down_fuse": (_i32, [_vp, _i32]),
+    "yn_nms_prefilter": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -231,6 +232,10 @@ class Handle:
     def fuse_decode(self, on=True):
         """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
         self._ck(self.lib.yn_fuse_decode(self.h, int(on)), "yn_fuse_decode")      # 0 off, 1 when the heads are large enough, 2 always
+
+    def nms_prefilter(self, mode=1):
+        """First-chunk prefilter of the per-class NMS: 0 off, 1 for batches of >= 4 images (default), 2 always; same kept sets."""
+        self._ck(self.lib.yn_nms_prefilter(self.h, int(mode)), "yn_nms_prefilter")
 
     def down_fuse(self, on=True):
         """Main branch of the stride-2 unit of stage 2 as one kernel (default on; bit-identical outputs either way)."""

@@ -604,13 +604,11 @@ __device__ __forceinline__ float vmin_raw(float a, float b) { float r; asm("v_mi
 __device__ __forceinline__ float vmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // word of sorted item ri*64+lane: bit t = "it suppresses sorted item ci*64+t" (columns after itself only on the diagonal tile)
+// core: this lane's row box bx (valid when jr < n) against the chunk's column boxes, this lane's one being cb
 template <bool DIOU>
-__device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, int ri, int ci, float thresh, float4* cbox, float* carea)
+__device__ __forceinline__ u64 tile_word_boxes(const float4 bx, const float4 cb, int n, int ri, int ci, float thresh, float4* cbox, float* carea)
 {
     const int lane = threadIdx.x & 63;
-    const int jc = ci * 64 + lane;
-    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (jc < n) cb = sb[jc];
     const float ca = (cb.z - cb.x) * (cb.w - cb.y);
     cbox[lane] = cb;
     carea[lane] = ca;
@@ -619,7 +617,6 @@ __device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, i
     const int jr = ri * 64 + lane;
     u64 mask = 0;
     if (jr < n) {
-        const float4 bx = sb[jr];
         const float ar = (bx.z - bx.x) * (bx.w - bx.y);
         const int t0 = (ri == ci) ? lane + 1 : 0;
         const int t1 = min(64, n - ci * 64);
@@ -677,6 +674,17 @@ __device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, i
     }
     __builtin_amdgcn_wave_barrier();
     return mask;
+}
+
+template <bool DIOU>
+__device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, int ri, int ci, float thresh, float4* cbox, float* carea)
+{
+    const int lane = threadIdx.x & 63;
+    const int jc = ci * 64 + lane, jr = ri * 64 + lane;
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), bx = cb;
+    if (jc < n) cb = sb[jc];
+    if (jr < n) bx = sb[jr];
+    return tile_word_boxes<DIOU>(bx, cb, n, ri, ci, thresh, cbox, carea);
 }
 
 template <bool DIOU>
@@ -885,9 +893,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict_
 // band (0, ci) for every later chunk (the dense tile code, row words OR-ed over the kept rows), then an order-preserving compaction of
 // the survivors into a second candidate list.  matrix / resolve run on that list (chunk 0 is finished: its kept boxes are flagged here).
 // Segments of <= 64 boxes never reach the dense phase.  Exact: the kept sets equal the plain pipeline's (parity suite).
-struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int part[256]; float4 cbox[4][64]; float carea[4][64]; };
+#define YN_PRE_W 8                                         // wavefronts per prefilter workgroup
+struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int part[64 * YN_PRE_W]; float4 cbox[YN_PRE_W][64]; float carea[YN_PRE_W][64]; };
 
-__global__ __launch_bounds__(256) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
+__global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
                                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, float thresh, int32_t* __restrict__ keep,
                                                              float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2)
@@ -922,24 +931,36 @@ __global__ __launch_bounds__(256) void nms_prefilter_kernel(const float4* __rest
     }
     __syncthreads();
     const u64 keepm = L.keepm;
-    for (int ci = 1 + wave; ci < T; ci += 4) {              // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes
-        u64 w = tile_word<false>(sb, n, 0, ci, thresh, cbox, carea);
-        w = ((keepm >> lane) & 1ull) ? w : 0ull;
-        unsigned lo = (unsigned)(w & 0xffffffffu), hi = (unsigned)(w >> 32);
+    {   // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes.  The row boxes are loaded once, the next tile's column
+        // boxes are requested before the current tile is evaluated.
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f), cb = bx, cbn = bx;
+        if (lane < n) bx = sb[lane];
+        int ci = 1 + wave;
+        if (ci < T && ci * 64 + lane < n) cb = sb[ci * 64 + lane];
+        for (; ci < T; ci += YN_PRE_W) {
+            const int cn = ci + YN_PRE_W;
+            cbn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cn < T && cn * 64 + lane < n) cbn = sb[cn * 64 + lane];
+            u64 w = keepm ? tile_word_boxes<false>(bx, cb, n, 0, ci, thresh, cbox, carea) : 0ull;
+            w = ((keepm >> lane) & 1ull) ? w : 0ull;
+            unsigned lo = (unsigned)(w & 0xffffffffu), hi = (unsigned)(w >> 32);
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
-        const int cnt = min(64, n - ci * 64);
-        const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-        if (lane == 0) L.surv[ci] = valid & ~(((u64)hi << 32) | (u64)lo);
+            for (int o = 32; o >= 1; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+            const int cnt = min(64, n - ci * 64);
+            const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            if (lane == 0) L.surv[ci] = valid & ~(((u64)hi << 32) | (u64)lo);
+            cb = cbn;
+        }
     }
     __syncthreads();
     // order-preserving compaction: exclusive prefix of the chunks' survivor counts (thread = a run of Q chunks, then a block scan)
-    const int Q = (T - 1 + 255) / 256;
+    constexpr int NTH = 64 * YN_PRE_W;
+    const int Q = (T - 1 + NTH - 1) / NTH;
     int mine = 0;
     for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) mine += __popcll(L.surv[ci]); }
     L.part[tid] = mine;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
+    for (int o = 1; o < NTH; o <<= 1) {
         const int v = tid >= o ? L.part[tid - o] : 0;
         __syncthreads();
         L.part[tid] += v;
@@ -947,9 +968,9 @@ __global__ __launch_bounds__(256) void nms_prefilter_kernel(const float4* __rest
     }
     int run = L.part[tid] - mine;                           // exclusive
     for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) { L.base[ci] = run; run += __popcll(L.surv[ci]); } }
-    if (tid == 255) seg_count2[(size_t)b * C + c] = L.part[255];
+    if (tid == NTH - 1) seg_count2[(size_t)b * C + c] = L.part[NTH - 1];
     __syncthreads();
-    for (int ci = 1 + wave; ci < T; ci += 4) {
+    for (int ci = 1 + wave; ci < T; ci += YN_PRE_W) {
         const u64 m = L.surv[ci];
         if ((m >> lane) & 1ull) {
             const int dst = L.base[ci] + __popcll(m & ((1ull << lane) - 1ull));
@@ -1126,10 +1147,11 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     const int32_t* m_toff = wk.tile_off;
     const int32_t* m_ids = wk.bucket;
     const float4* m_box = sbox;
-    static const int prefilter_env = getenv("YN_NMS_PREFILTER") ? atoi(getenv("YN_NMS_PREFILTER")) : 1;
-    if (!diou && prefilter_env && wk.sbox2) {
+    const int prefilter_env = wk.prefilter;
+    // (small batches: the prefilter is two more launches in a serial chain - bs = 1 latency 0.69 -> 0.72 ms - for chip time nobody else wants)
+    if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
-        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(C, B), dim3(256), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
+        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(C, B), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
                            reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2);
         hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2);
         m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);

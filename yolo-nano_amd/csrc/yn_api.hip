@@ -1072,6 +1072,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->stream = (hipStream_t)cfg->stream;
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
+    h->nms.prefilter = getenv("YN_NMS_PREFILTER") ? atoi(getenv("YN_NMS_PREFILTER")) : 1;
     if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
     if (const char* e10 = getenv("YN_DOWN_FUSE")) h->down_fuse = atoi(e10) != 0;
     if (const char* e11 = getenv("YN_DWPW_FUSE")) h->dwpw_fuse = atoi(e11) != 0;
@@ -1168,6 +1169,15 @@ int yn_set_pw_config(yn_handle* h, int index)
 }
 int yn_pw_config_count(void) { return pw_config_count(); }
 int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
+int yn_nms_prefilter(yn_handle* h, int mode)
+{
+    if (!h) return 1;
+    if (mode < 0 || mode > 2) return fail(h, "yn_nms_prefilter: mode %d is not 0, 1 or 2", mode);
+    if (mode != h->nms.prefilter) drop_graphs(h);
+    h->nms.prefilter = mode;
+    return 0;
+}
+
 int yn_down_fuse(yn_handle* h, int enable)
 {
     if (!h) return 1;
