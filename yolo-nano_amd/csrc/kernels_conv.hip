@@ -922,7 +922,7 @@ static size_t conv3x3_halo_lds(int W, int Cin, int NT)
 // runs the same MFMA sequence per k-chunk in the same chunk order: all split configurations are bit-identical to each other (not
 // to the f32-MFMA family, which rounds once per product-add; against float64 the split form is the more accurate of the two).
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int KC>
 __device__ __forceinline__ void gemm_split_block(const GemmArgs& a, c3h16* smem, unsigned bid, unsigned nblocks)
 {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
@@ -935,24 +935,24 @@ __device__ __forceinline__ void gemm_split_block(const GemmArgs& a, c3h16* smem,
     if (m0 >= a.M) return;
     const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0 && (!a.pass || ((a.pass_ld | a.pass_off) & 3) == 0);
     f32x16 acc0[NT];
-    gemm_split_tile<WM, WN, NT>(a, smem, m0, n0, acc0);
+    gemm_split_tile<WM, WN, NT, KC>(a, smem, m0, n0, acc0);
     gemm_epilogue<NT>(a, acc0, m0 + wm * 32, n0 + wn * NT * 32, vecO, lane);
 }
 
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int KC>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a)
 {
-    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN)];
-    gemm_split_block<WM, WN, NT>(a, smem, blockIdx.x, gridDim.x);
+    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN, KC)];
+    gemm_split_block<WM, WN, NT, KC>(a, smem, blockIdx.x, gridDim.x);
 }
 
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int KC>
 __global__ __launch_bounds__(256) void gemm_split_group_kernel(Group<GemmArgs> g)
 {
-    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN)];
+    __shared__ __attribute__((aligned(16))) c3h16 smem[gemm_split_smem_halves(32 * WM, 32 * NT * WN, KC)];
     unsigned local, nb;
     const int p = group_problem(g.first, blockIdx.x, local, nb);
-    gemm_split_block<WM, WN, NT>(g.a[p], smem, local, nb);
+    gemm_split_block<WM, WN, NT, KC>(g.a[p], smem, local, nb);
 }
 
 struct TileCfg { int WM, WN, NT, KP, NBUF; };
@@ -996,16 +996,18 @@ static const char* const g_pwd_names[] = {
 };
 constexpr int N_PWD_CFGS = (int)(sizeof(g_pwd_cfgs) / sizeof(g_pwd_cfgs[0]));
 
-// split-f16 configurations (gemm_split_kernel<WM, WN, NT>): bit-identical to each other; used when the layer carries split packs
-#define YN_PWS_CONFIGS(X) X(4, 1, 1) X(4, 1, 2) X(4, 1, 3) X(4, 1, 4) X(2, 2, 1) X(2, 2, 2) X(1, 4, 1) X(1, 4, 2) X(2, 2, 4)
-struct SplitCfg { int WM, WN, NT; };
+// split-f16 configurations (gemm_split_kernel<WM, WN, NT, KC>): bit-identical to each other; used when the layer carries split packs.
+// KC = 64: half as many barrier rounds for the layers that are a chain of them (small M, K = 232 / 464); only picked by the autotuner.
+#define YN_PWS_CONFIGS(X) X(4, 1, 1, 32) X(4, 1, 2, 32) X(4, 1, 3, 32) X(4, 1, 4, 32) X(2, 2, 1, 32) X(2, 2, 2, 32) X(1, 4, 1, 32) X(1, 4, 2, 32) X(2, 2, 4, 32) \
+    X(2, 2, 1, 64) X(2, 2, 2, 64) X(1, 4, 1, 64) X(4, 1, 1, 64)
+struct SplitCfg { int WM, WN, NT, KC; };
 static const SplitCfg g_pws_cfgs[] = {
-#define X(wm, wn, nt) {wm, wn, nt},
+#define X(wm, wn, nt, kc) {wm, wn, nt, kc},
     YN_PWS_CONFIGS(X)
 #undef X
 };
 static const char* const g_pws_names[] = {
-#define X(wm, wn, nt) "gemm_split_kernel<" #wm "," #wn "," #nt ">",
+#define X(wm, wn, nt, kc) "gemm_split_kernel<" #wm "," #wn "," #nt "," #kc ">",
     YN_PWS_CONFIGS(X)
 #undef X
 };
@@ -1024,6 +1026,7 @@ static bool launch_pw_split(const GemmArgs& a, int idx, hipStream_t s)
         long best = -1;
         for (int i = 0; i < N_PWS_CFGS; ++i) {
             const SplitCfg& c = g_pws_cfgs[i];
+            if (c.KC != 32) continue;
             const long BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
             if (BN > 32 * nt32 + 31 && BN != 32) continue;
             const long blocks = ((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN);
@@ -1037,8 +1040,8 @@ static bool launch_pw_split(const GemmArgs& a, int idx, hipStream_t s)
     dim3 grid(xcd_grid((a.M + BM - 1) / BM) * ((a.Npad + BN - 1) / BN));
     g_last_kernel = g_pws_names[idx];
     int i = 0;
-#define X(wm, wn, nt)                                                                                      \
-    if (i++ == idx) { hipLaunchKernelGGL((gemm_split_kernel<wm, wn, nt>), grid, dim3(256), 0, s, a); return true; }
+#define X(wm, wn, nt, kc)                                                                                  \
+    if (i++ == idx) { hipLaunchKernelGGL((gemm_split_kernel<wm, wn, nt, kc>), grid, dim3(256), 0, s, a); return true; }
     YN_PWS_CONFIGS(X)
 #undef X
     return false;
@@ -1056,6 +1059,7 @@ bool launch_pw_group(const GemmArgs* a, int n, int cfg, hipStream_t s)
         long best = -1;
         for (int i = 0; i < N_PWS_CFGS; ++i) {
             const SplitCfg& c = g_pws_cfgs[i];
+            if (c.KC != 32) continue;
             const long BM = 32 * c.WM, BN = 32 * c.NT * c.WN;
             if (BN > 32 * nt32 + 31 && BN != 32) continue;
             const long blocks = ((a[0].M + BM - 1) / BM) * ((a[0].Npad + BN - 1) / BN);
@@ -1075,9 +1079,9 @@ bool launch_pw_group(const GemmArgs* a, int n, int cfg, hipStream_t s)
     g.first[YN_GROUP_MAX] = tot;
     static char name[64];
     int i = 0;
-#define X(wm, wn, nt)                                                                                      \
-    if (i++ == idx) { g_last_kernel = "gemm_split_group_kernel<" #wm "," #wn "," #nt ">";                   \
-                      hipLaunchKernelGGL((gemm_split_group_kernel<wm, wn, nt>), dim3(tot), dim3(256), 0, s, g); return true; }
+#define X(wm, wn, nt, kc)                                                                                  \
+    if (i++ == idx) { g_last_kernel = "gemm_split_group_kernel<" #wm "," #wn "," #nt "," #kc ">";           \
+                      hipLaunchKernelGGL((gemm_split_group_kernel<wm, wn, nt, kc>), dim3(tot), dim3(256), 0, s, g); return true; }
     YN_PWS_CONFIGS(X)
 #undef X
     (void)name;
@@ -1442,13 +1446,10 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
                                                          int act, float* __restrict__ y)
 {
     constexpr int PR = 8, PC = 7, CR = 2 * PR + 1, CC = 2 * PC + 1;     // pooled tile, conv tile
-    __shared__ __attribute__((aligned(16))) float ws[28 * COUT];
-    // one LDS region, two lives: first every thread's private 27 input values (stride 27: conflict-free), then — after a
-    // barrier — the conv tile the pooling reads
-    constexpr int CT = CR * CC * COUT > 256 * 27 ? CR * CC * COUT : 256 * 27;
-    __shared__ __attribute__((aligned(16))) float ct[CT];
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
-    for (int i = threadIdx.x; i < COUT; i += 256) ws[27 * COUT + i] = bias[i];
+    // The weights are wave-uniform: they come through the scalar cache into SGPR operands of the packed FMAs (as broadcast
+    // 16-byte LDS reads they took 8 LDS cycles per 4 VALU cycles — the kernel ran at the LDS rate, 58 us); LDS only holds
+    // the conv tile the pooling reads.
+    __shared__ __attribute__((aligned(16))) float ct[CR * CC * COUT];
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;               // conv output extent
     const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;             // pooled extent
     const int tiles_x = (Wp + PC - 1) / PC, tiles_y = (Hp + PR - 1) / PR;
@@ -1460,9 +1461,9 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
     const int r = t / CC, c = t - r * CC;
     const int cy = 2 * py0 - 1 + r, cx = 2 * px0 - 1 + c;               // conv pixel of this thread
     const bool live = t < CR * CC && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+    // all 27 input values of the thread's conv pixel in ONE batch of unconditional (clamped, masked) loads
+    float in[27];
     {
-        // all 27 input values of the thread's conv pixel in ONE batch of unconditional (clamped, masked) loads
-        float in[27];
         const int cyc = live ? cy : 0, cxc = live ? cx : 0;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -1478,37 +1479,17 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
                 in[q * 3 + k] = __uint_as_float(__float_as_uint(xr[ix < 0 ? 0 : (ix >= W ? W - 1 : ix)]) & mk);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 27; ++i) ct[t * 27 + i] = in[i];
     }
-    __syncthreads();                                          // ws complete (the private input slots need no barrier)
     float acc[COUT];
-    if (live) {
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = ws[27 * COUT + co];
-#pragma unroll 1
-        for (int q = 0; q < 9; ++q) {
-            float in[3];
+    for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) in[k] = ct[t * 27 + q * 3 + k];
+    for (int i = 0; i < 27; ++i) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float4* wr = reinterpret_cast<const float4*>(ws + (q * 3 + kx) * COUT);
-#pragma unroll
-                for (int c4 = 0; c4 < COUT / 4; ++c4) {
-                    const float4 wv = wr[c4];
-                    acc[c4 * 4 + 0] += in[kx] * wv.x; acc[c4 * 4 + 1] += in[kx] * wv.y;
-                    acc[c4 * 4 + 2] += in[kx] * wv.z; acc[c4 * 4 + 3] += in[kx] * wv.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = apply_act(acc[co], act);
-    } else {
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = -INFINITY;              // max-pool padding
+        for (int co = 0; co < COUT; ++co) acc[co] += in[i] * w[i * COUT + co];
     }
-    __syncthreads();                                          // every thread is done with its input slot
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = live ? apply_act(acc[co], act) : -INFINITY;   // -inf = max-pool padding
     if (t < CR * CC) {
 #pragma unroll
         for (int co = 0; co < COUT; co += 4)

@@ -140,17 +140,18 @@ typedef _Float16 c3h16;
 typedef _Float16 c3h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 c3h16x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr int gemm_split_smem_halves(int BM, int BN) { return 2 * BM * (32 + 8) + 2 * 4 * BN * 8; }
+__host__ __device__ constexpr int gemm_split_smem_halves(int BM, int BN, int KC = 32) { return 2 * BM * (KC + 8) + 2 * (KC / 8) * BN * 8; }
 
-template <int WM, int WN, int NT>
+// KC = K per chunk (32, or 64: half the barrier rounds for the small-M / long-K layers; zero-padded chunks add exact zeros, same bits)
+template <int WM, int WN, int NT, int KC = 32>
 __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, int m0, int n0, f32x16 (&acc0)[NT])
 {
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, KC = 32, AST = KC + 8;
-    constexpr int A_PER = (BM * 4 + 255) / 256;             // (row, octet) granules per thread per chunk
-    constexpr int B_PER = (2 * 4 * BN + 255) / 256;         // 16-byte granules per thread per chunk (hi and lo planes)
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN, AST = KC + 8, OQ = KC / 8;
+    constexpr int A_PER = (BM * OQ + 255) / 256;            // (row, octet) granules per thread per chunk
+    constexpr int B_PER = (2 * OQ * BN + 255) / 256;        // 16-byte granules per thread per chunk (hi and lo planes)
     c3h16* Ah = smem;
     c3h16* Al = smem + BM * AST;
-    c3h16* Bh = smem + 2 * BM * AST;                        // [4][BN][8], then the lo plane
+    c3h16* Bh = smem + 2 * BM * AST;                        // [OQ][BN][8], then the lo plane
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
@@ -165,9 +166,9 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int g = t + 256 * i;
-            const int row = g >> 2, k = c * KC + (g & 3) * 8;
+            const int row = g / OQ, k = c * KC + (g % OQ) * 8;
             const int m = m0 + row;
-            const bool rok = g < BM * 4 && m < a.M;
+            const bool rok = g < BM * OQ && m < a.M;
             const float* p = a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off;
             if (vecA) {
                 const bool k0 = k < a.K, k1 = k + 4 < a.K;
@@ -187,10 +188,10 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int g = t + 256 * i;                      // plane, octet, column
-            const int pl = g / (4 * BN), r = g - pl * (4 * BN);
+            const int pl = g / (OQ * BN), r = g - pl * (OQ * BN);
             const int o = r / BN, n = r - o * BN;
             const int kq = c * (KC / 8) + o;
-            const bool ok = g < 2 * 4 * BN && kq < KQ && n0 + n < a.Npad;
+            const bool ok = g < 2 * OQ * BN && kq < KQ && n0 + n < a.Npad;
             c3h16x8 v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n0 + n : 0)) * 8);
             if (!ok) {
 #pragma unroll
@@ -203,19 +204,19 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int g = t + 256 * i;
-            if (g < BM * 4) {
+            if (g < BM * OQ) {
                 const float x8[8] = {a_reg[i][0].x, a_reg[i][0].y, a_reg[i][0].z, a_reg[i][0].w, a_reg[i][1].x, a_reg[i][1].y, a_reg[i][1].z, a_reg[i][1].w};
                 c3h16x8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { hi[j] = (c3h16)x8[j]; lo[j] = (c3h16)((x8[j] - (float)hi[j]) * 2048.0f); }
-                *reinterpret_cast<c3h16x8*>(Ah + (g >> 2) * AST + (g & 3) * 8) = hi;
-                *reinterpret_cast<c3h16x8*>(Al + (g >> 2) * AST + (g & 3) * 8) = lo;
+                *reinterpret_cast<c3h16x8*>(Ah + (g / OQ) * AST + (g % OQ) * 8) = hi;
+                *reinterpret_cast<c3h16x8*>(Al + (g / OQ) * AST + (g % OQ) * 8) = lo;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int g = t + 256 * i;
-            if (g < 2 * 4 * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)g * 8) = b_reg[i];
+            if (g < 2 * OQ * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)g * 8) = b_reg[i];
         }
     };
     f32x16 acc1[NT];
@@ -232,7 +233,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
         const c3h16* Ahb = Ah + (wm * 32 + l31) * AST + h * 8;
         const c3h16* Alb = Al + (wm * 32 + l31) * AST + h * 8;
         const c3h16* Bhb = Bh + (size_t)(h * BN + wn * NT * 32 + l31) * 8;
-        const c3h16* Blb = Bhb + 4 * BN * 8;
+        const c3h16* Blb = Bhb + OQ * BN * 8;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             const c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Ahb + ks * 16);
