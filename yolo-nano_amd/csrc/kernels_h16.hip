@@ -950,92 +950,145 @@ void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_of
 __global__ __launch_bounds__(256) void hstem_kernel(const float* __restrict__ x, int B, int H, int W, const float* __restrict__ w /*[27][24]*/,
                                                      const float* __restrict__ bias, h16* __restrict__ y)
 {
+    // thread = one output pixel x all 24 channels: its 27 input values in one batch of clamped, masked loads; the weights are
+    // wave-uniform and arrive through scalar loads as SGPR operands of the FMAs (the first version — thread = pixel x 8 channels —
+    // re-read the 27 inputs three times and fetched 216 weights per thread through the vector cache: 428 us at 608 x 608, bs 32).
+    // The fma chain per channel (ci, ky, kx ascending) is unchanged.
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * Ho * Wo * 3;
-    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int oc = (int)(i % 3);
-    const long p = i / 3;
+    const long total = (long)B * Ho * Wo;
+    const long p = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (p >= total) return;
     const int ox = (int)(p % Wo); const long q = p / Wo;
     const int oy = (int)(q % Ho), b = (int)(q / Ho);
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[oc * 8 + j] : 0.0f;
+    float in[27];
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = 2 * oy - 1 + ky;
             const bool yok = iy >= 0 && iy < H;
+            const float* xr = x + (((size_t)b * 3 + ci) * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = 2 * ox - 1 + kx;
-                const bool ok = yok && ix >= 0 && ix < W;
-                const float v = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.0f;
-                const float* wp = w + (size_t)(ci * 9 + ky * 3 + kx) * 24 + oc * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(v, wp[j], acc[j]);
+                unsigned mk = (yok && ix >= 0 && ix < W) ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(mk));
+                in[ci * 9 + ky * 3 + kx] = __uint_as_float(__float_as_uint(xr[ix < 0 ? 0 : (ix >= W ? W - 1 : ix)]) & mk);
             }
         }
-    h16x8 r;
+    float acc[24];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
-    sth8(y + (size_t)p * 24 + oc * 8, r);
+    for (int j = 0; j < 24; ++j) acc[j] = bias ? bias[j] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 27; ++i)
+#pragma unroll
+        for (int j = 0; j < 24; ++j) acc[j] = __builtin_fmaf(in[i], w[i * 24 + j], acc[j]);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        h16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)acc[o * 8 + j];
+        sth8(y + (size_t)p * 24 + o * 8, r);
+    }
 }
 
 void launch_hstem(const float* x, int B, int H, int W, const float* w, const float* bias, h16* y, hipStream_t s)
 {
-    const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 3;
+    const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
     hipLaunchKernelGGL(hstem_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, x, B, H, W, w, bias, y);
 }
 
+// dw[oc][r] = sum over output pixels p of patch[p][r] * dy[p][oc]  (r = (ci, ky, kx) < 27).  A block walks its range of pixels in chunks
+// of 64: the chunk's dy rows (h16 -> fp32) and its 64 x 27 input patch go to LDS once (the next chunk's values are requested into
+// registers before the current one is used), then thread = (pixel lane pg < 3, patch element r, channel octet og < 3) accumulates 8
+// channels over the pixels pg, pg + 3, ... from LDS: one x value and 8 dy values per 8 FMAs.  (First version: the same thread roles
+// reading straight from global — 81 threads x 2 loads per pixel, 27-fold redundant: 725 us at 608 x 608, bs 32, at the very end of
+// the backward pass where nothing overlaps it.)
 __global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict__ dy, const float* __restrict__ x, int B, int H, int W,
                                                            float* __restrict__ dw /* slots, reference layout [24][3][3][3] */, size_t slot_stride)
 {
-    // thread -> (row-lane rl = t/96 < 2, patch element r = (t%96)/3 < 27.., channel octet oc = t%3); 192 threads busy of 256 (162 do work)
-    __shared__ float red[256][8];
+    constexpr int P = 64, NX = 7;                          // 4 threads x 7 patch elements per chunk pixel
+    __shared__ __attribute__((aligned(16))) float xs[P * 27];
+    __shared__ __attribute__((aligned(16))) float gs[P * 24];
+    __shared__ __attribute__((aligned(16))) float red[256][8];
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int t = threadIdx.x;
-    const int rl = t / 96, u = t - rl * 96, r = u / 3, oc = u - r * 3;
-    const bool live = rl < 2 && r < 27;
-    const int ci = r / 9, ky = (r % 9) / 3, kx = r % 3;
+    const long npix = (long)B * Ho * Wo;
+    const long per = ((npix + gridDim.x - 1) / gridDim.x + P - 1) / P * P;
+    const long begin = (long)blockIdx.x * per;
+    const long end = begin + per < npix ? begin + per : npix;
+    float xr[NX];
+    h16x8 gr;
+    // patch loads: thread = (chunk pixel t / 4, patch elements r = t % 4 + 4 k): one pixel decode per thread and chunk
+    const int fpl = t >> 2, frq = t & 3;
+    auto fetch = [&](long base) {
+        const long pp = base + fpl;
+        const int pc = (int)(pp < npix ? pp : npix - 1);
+        const int ox = pc % Wo, q = pc / Wo;
+        const int oy = q % Ho, b = q / Ho;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int r = frq + 4 * i;
+            const int ci = r / 9, k9 = r - ci * 9, ky = k9 / 3, kx = k9 - ky * 3;
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            const bool ok = r < 27 && pp < end && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float v = x[(((size_t)b * 3 + (ci < 3 ? ci : 2)) * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix))];
+            unsigned mk = ok ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(mk));
+            xr[i] = __uint_as_float(__float_as_uint(v) & mk);
+        }
+        {
+            const int pl = t / 3, o = t - pl * 3;
+            const long pp = base + pl;
+            const bool ok = t < P * 3 && pp < end;
+            gr = ldh8(dy + (size_t)(ok ? pp : 0) * 24 + o * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gr[j] = (h16)0.0f;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int r = frq + 4 * i;
+            if (r < 27) xs[fpl * 27 + r] = xr[i];
+        }
+        if (t < P * 3) {
+            *reinterpret_cast<float4*>(gs + t * 8) = make_float4((float)gr[0], (float)gr[1], (float)gr[2], (float)gr[3]);
+            *reinterpret_cast<float4*>(gs + t * 8 + 4) = make_float4((float)gr[4], (float)gr[5], (float)gr[6], (float)gr[7]);
+        }
+    };
+    const int pg = t / 81, u = t - pg * 81, r = u / 3, og = u - r * 3;
+    const bool live = pg < 3;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    if (live) {
-        const long npix = (long)B * Ho * Wo;
-        const long lanes_total = (long)gridDim.x * 2;
-        const long per = (npix + lanes_total - 1) / lanes_total;
-        const long begin = ((long)blockIdx.x * 2 + rl) * per;
-        const long end = begin + per < npix ? begin + per : npix;
-        for (long p = begin; p < end; p += 4) {
-            float xv[4]; h16x8 g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                                // four output pixels' operands requested before any FMA
-                const long pp = p + u < end ? p + u : p;
-                const int ox = (int)(pp % Wo); const long q = pp / Wo;
-                const int oy = (int)(q % Ho), b = (int)(q / Ho);
-                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-                const bool ok = p + u < end && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float v = x[(((size_t)b * 3 + ci) * H + (iy < 0 ? 0 : (iy >= H ? H - 1 : iy))) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix))];
-                unsigned mk = ok ? 0xffffffffu : 0u;
-                asm volatile("" : "+v"(mk));
-                xv[u] = __uint_as_float(__float_as_uint(v) & mk);
-                g[u] = ldh8(dy + (size_t)pp * 24 + oc * 8);
+    if (begin < end) fetch(begin);
+    for (long base = begin; base < end; base += P) {
+        __syncthreads();                                    // the previous chunk has been consumed
+        stage();
+        __syncthreads();
+        if (base + P < end) fetch(base + P);
+        if (live) {
+#pragma unroll 2
+            for (int p = pg; p < P; p += 3) {
+                const float xv = xs[p * 27 + r];
+                const float4 g0 = *reinterpret_cast<const float4*>(gs + p * 24 + og * 8), g1 = *reinterpret_cast<const float4*>(gs + p * 24 + og * 8 + 4);
+                acc[0] = __builtin_fmaf(xv, g0.x, acc[0]); acc[1] = __builtin_fmaf(xv, g0.y, acc[1]);
+                acc[2] = __builtin_fmaf(xv, g0.z, acc[2]); acc[3] = __builtin_fmaf(xv, g0.w, acc[3]);
+                acc[4] = __builtin_fmaf(xv, g1.x, acc[4]); acc[5] = __builtin_fmaf(xv, g1.y, acc[5]);
+                acc[6] = __builtin_fmaf(xv, g1.z, acc[6]); acc[7] = __builtin_fmaf(xv, g1.w, acc[7]);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(xv[u], (float)g[u][j], acc[j]);
         }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[t][j] = acc[j];
     __syncthreads();
-    if (rl == 0 && r < 27) {
+    if (t < 81 && begin < end) {
         float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(out + (size_t)(oc * 8 + j) * 27 + r, red[t][j] + red[t + 96][j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(out + (size_t)(og * 8 + j) * 27 + r, red[t][j] + red[t + 81][j] + red[t + 162][j]);
     }
 }
 
