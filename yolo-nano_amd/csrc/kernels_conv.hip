@@ -999,7 +999,7 @@ constexpr int N_PWD_CFGS = (int)(sizeof(g_pwd_cfgs) / sizeof(g_pwd_cfgs[0]));
 // split-f16 configurations (gemm_split_kernel<WM, WN, NT, KC>): bit-identical to each other; used when the layer carries split packs.
 // KC = 64: half as many barrier rounds for the layers that are a chain of them (small M, K = 232 / 464); only picked by the autotuner.
 #define YN_PWS_CONFIGS(X) X(4, 1, 1, 32) X(4, 1, 2, 32) X(4, 1, 3, 32) X(4, 1, 4, 32) X(2, 2, 1, 32) X(2, 2, 2, 32) X(1, 4, 1, 32) X(1, 4, 2, 32) X(2, 2, 4, 32) \
-    X(2, 2, 1, 64) X(2, 2, 2, 64) X(1, 4, 1, 64) X(4, 1, 1, 64)
+    X(2, 2, 1, 64) X(2, 2, 2, 64) X(1, 4, 1, 64) X(4, 1, 1, 64) X(1, 4, 1, 128)
 struct SplitCfg { int WM, WN, NT, KC; };
 static const SplitCfg g_pws_cfgs[] = {
 #define X(wm, wn, nt, kc) {wm, wn, nt, kc},

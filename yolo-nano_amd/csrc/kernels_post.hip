@@ -133,7 +133,7 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
         const int c = j + 16 * k;
         v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
         if (v[k] == 1.0f) first = c;                                      // descending k: ends at this lane's lowest such class
-        general = general || (v[k] < 1.0f && v[k] > 0.99999f);
+        general = general | ((v[k] < 1.0f) & (v[k] > 0.99999f));           // bitwise: the short-circuit form compiled to an exec-mask branch per class slot
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) sum += v[k];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
 // head GEMM + decode_kernel (the parity suite pins that), the 4*A(5+C) bytes per pixel of raw head are neither written nor re-read.
 template <int NT> struct HeadDecodeLds {
     static constexpr int BM = 32, BN = 128 * NT, LD = BN + 4;
-    static constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2 + BM * 8 * 4;     // raw tile + [BM * A <= BM * 8] (sum, class)
+    static constexpr int GEMM_HALVES = gemm_split_smem_halves(BM, BN), RAW_HALVES = BM * LD * 2 + BM * 8 * 4 + BM * 4 * 2;     // raw tile + [BM * A <= BM * 8] (sum, class) + [BM] (first candidate, gx, gy)
     static constexpr int HALVES = GEMM_HALVES > RAW_HALVES ? GEMM_HALVES : RAW_HALVES;
 };
 
@@ -237,6 +237,16 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
 #pragma unroll
         for (int r = 0; r < 16; ++r) raw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + n] = acc[nt][r] + bias;
     }
+    // per row of the tile: index of its first candidate and its cell — the divisions by the map size happen once per pixel here, not
+    // once per candidate / coordinate in the passes below (three integer divisions were ~75 of their ~200 instructions per item)
+    int* rowinfo = reinterpret_cast<int*>(raw + BM * LD + BM * 16);     // [BM][4]
+    if (t < BM) {
+        const int m = min(m0 + t, a.M - 1);
+        const int b = m / g.hw[scale], cell = m - b * g.hw[scale];
+        const int gy = cell / g.w[scale], gx = cell - gy * g.w[scale];
+        *reinterpret_cast<int4*>(rowinfo + t * 4) = make_int4(b * g.N + g.off[scale] + cell * g.A, gx, gy, 0);
+    }
+    const unsigned magicA = (65536u + (unsigned)g.A - 1u) / (unsigned)g.A;     // c / A == (c * magicA) >> 16 for c < BM * A <= 256
     __syncthreads();
     if (dbg & 2) return;
     // Decode in three passes so that no per-candidate scalar work is replicated over 16 lanes:
@@ -249,7 +259,7 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
     const int j = t & 15;
     const int ncand = min(BM, a.M - m0) * g.A;
     for (int c = t >> 4; c < ncand; c += 16) {
-        const int row = c / g.A, an = c - row * g.A;
+        const int row = (int)(((unsigned)c * magicA) >> 16), an = c - row * g.A;
         float sum, sc;
         int cbest;
         const float* rp = raw + row * LD;
@@ -261,10 +271,9 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
         // items [0, ncand): scores; [ncand, 5 ncand): coordinates
         const bool is_score = q < ncand;
         const int c = is_score ? q : (q - ncand) >> 2, k = (q - ncand) & 3;
-        const int row = c / g.A, an = c - row * g.A;
-        const int m = m0 + row;
-        const int b = m / g.hw[scale], cell = m - b * g.hw[scale];
-        const int i = b * g.N + g.off[scale] + cell * g.A + an;
+        const int row = (int)(((unsigned)c * magicA) >> 16), an = c - row * g.A;
+        const int4 ri = *reinterpret_cast<const int4*>(rowinfo + row * 4);
+        const int i = ri.x + an;
         const float* rp = raw + row * LD;
         if (is_score) {
             const int cw = st_cls[c];
@@ -272,9 +281,8 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
             scores[i] = sc;
             cls[i] = (sc >= conf_thresh) ? (cw & 0x7fffffff) : -1;
         } else {
-            const int gy = cell / g.w[scale], gx = cell - gy * g.w[scale];
             const float* tb = rp + g.A * (1 + g.C) + an * 4;
-            boxes[(size_t)i * 4 + k] = decode_coord(g, scale, gx, gy, an, tb[k & 1], tb[2 + (k & 1)], (float)g.S, k);
+            boxes[(size_t)i * 4 + k] = decode_coord(g, scale, ri.y, ri.z, an, tb[k & 1], tb[2 + (k & 1)], (float)g.S, k);
         }
     }
 }
