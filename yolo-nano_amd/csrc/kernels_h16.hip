@@ -500,6 +500,37 @@ void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H,
 // dz: dense with y's own map (dz_odd = 0), or the odd logical channels of a gapped 2C-channel tensor (dz_odd = 1: channel c
 // of this layer is logical channel 2c+1 there — the concat+shuffle of backbone/shufflenetv2.py:72-74).
 // =================================================================================================
+// dz_odd addressing of one octet of this layer's channels (c = p0 .. p0+7 <-> logical 2c+1 of the gapped 2C-channel unit gradient): the 16
+// interleaved values are the logical positions l0 = 2 p0 .. l0 + 15, i.e. two 8-half vectors d0 / d1, each addressed in the plane of its
+// first element; when the plane boundary `half` falls INSIDE one of them (bf = 116: the octet of c = 56..63) that vector's tail comes
+// from a third load `e` in second-plane addressing.  Every lane thus gets its row in at most three 16-byte loads (the first version sent
+// the straddling octet and the ragged last one through 8 scalar loads per row, issued where they were needed: a full memory latency per
+// row for every wavefront holding such a lane — the reduce over a 10 MB stage-3 tensor took 23 us against 9 us for the statistics pass).
+struct DzOdd { int o0, o1, oe, sv, cut; bool load1, vec; };
+__device__ __forceinline__ DzOdd dz_odd_map(const HRedArgs& a, int p0)
+{
+    DzOdd m;
+    const int l0 = 2 * p0, half = a.dz_half, gap = a.dz_gap;
+    m.o0 = l0 + (l0 >= half ? gap : 0);
+    m.o1 = l0 + 8 + (l0 + 8 >= half ? gap : 0);
+    m.sv = (l0 < half && half < l0 + 8) ? 0 : ((l0 + 8 < half && half < l0 + 16) ? 1 : -1);
+    m.oe = m.sv >= 0 ? l0 + 8 * m.sv + gap : m.o0;
+    m.cut = m.sv >= 0 ? half - (l0 + 8 * m.sv) : 8;
+    m.load1 = p0 + 4 < a.C;
+    m.vec = m.o0 + 8 <= a.dz_ld && (!m.load1 || m.o1 + 8 <= a.dz_ld) && m.oe + 8 <= a.dz_ld;
+    if (!m.load1) m.o1 = m.o0;                              // pad channels only: any valid address, the values are never used
+    return m;
+}
+__device__ __forceinline__ void dz_odd_pick(const DzOdd& m, const h16x8& d0, const h16x8& d1, const h16x8& e, float (&g)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 2 * j + 1;
+        g[j] = (float)((m.sv == 0 && i >= m.cut) ? e[i] : d0[i]);
+        g[4 + j] = m.load1 ? (float)((m.sv == 1 && i >= m.cut) ? e[i] : d1[i]) : 0.0f;
+    }
+}
+
 __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, float (&g)[8])
 {
     if (!a.dz_odd) {
@@ -507,12 +538,11 @@ __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = (float)v[j];
     } else {
-        const int l0 = 2 * p0;                                          // y is dense here (half == C): physical == logical
-        if (p0 + 8 <= a.C && (l0 + 16 <= a.dz_half || l0 >= a.dz_half)) {             // the 16 interleaved values sit in one plane: two 16-byte loads
-            const h16* q = a.dz + row * a.dz_ld + l0 + (l0 >= a.dz_half ? a.dz_gap : 0);
-            const h16x8 v0 = ldh8(q), v1 = ldh8(q + 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { g[j] = (float)v0[2 * j + 1]; g[4 + j] = (float)v1[2 * j + 1]; }
+        const DzOdd m = dz_odd_map(a, p0);                              // y is dense here (half == C): physical == logical
+        if (m.vec) {
+            const h16* q = a.dz + row * a.dz_ld;
+            const h16x8 d0 = ldh8(q + m.o0), d1 = ldh8(q + m.o1), e = ldh8(q + m.oe);
+            dz_odd_pick(m, d0, d1, e, g);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -550,10 +580,11 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
         // previous one (the reductions ran at 1.3-2 TB/s with the loads and the arithmetic strictly alternating).
         constexpr int U = 4;
         const long step = (long)gridDim.x * rowsPer;
-        const bool fastdz = MODE == 2 && a.dz_odd && p0 + 8 <= a.C && (2 * p0 + 16 <= a.dz_half || 2 * p0 >= a.dz_half);
-        const bool slowdz = MODE == 2 && a.dz_odd && !fastdz;
-        const size_t dzo = (MODE == 2 && a.dz_odd) ? (size_t)(2 * p0 + (2 * p0 >= a.dz_half ? a.dz_gap : 0)) : (size_t)(a.dz_off + p0);
-        struct Batch { h16x8 v[U], d0[U], d1[U]; bool ok[U]; };            // two of them, indexed statically (a run-time index spills to scratch)
+        DzOdd dm{};
+        if (MODE == 2 && a.dz_odd) dm = dz_odd_map(a, p0);
+        const bool slowdz = MODE == 2 && a.dz_odd && !dm.vec;
+        const size_t dzo = (MODE == 2 && a.dz_odd) ? (size_t)dm.o0 : (size_t)(a.dz_off + p0);
+        struct Batch { h16x8 v[U], d0[U], d1[U], e[U]; bool ok[U]; };      // two of them, indexed statically (a run-time index spills to scratch)
         auto issue = [&](Batch& q, long r) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
                 q.v[u] = ldh8(a.y + row * a.y_ld + a.y_off + p0);
                 if (MODE == 2 && !slowdz) {
                     q.d0[u] = ldh8(a.dz + row * a.dz_ld + dzo);
-                    if (a.dz_odd) q.d1[u] = ldh8(a.dz + row * a.dz_ld + dzo + 8);
+                    if (a.dz_odd) { q.d1[u] = ldh8(a.dz + row * a.dz_ld + dm.o1); q.e[u] = ldh8(a.dz + row * a.dz_ld + dm.oe); }
                 }
             }
         };
@@ -572,10 +603,8 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
                 float g[8];
                 if (MODE == 2) {
                     if (slowdz) load_dz8(a, (size_t)(q.ok[u] ? r + u * step : r), p0, g);
-                    else if (a.dz_odd) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { g[j] = (float)q.d0[u][2 * j + 1]; g[4 + j] = (float)q.d1[u][2 * j + 1]; }
-                    } else {
+                    else if (a.dz_odd) dz_odd_pick(dm, q.d0[u], q.d1[u], q.e[u], g);
+                    else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) g[j] = (float)q.d0[u][j];
                     }
