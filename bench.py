@@ -507,7 +507,7 @@ def main():
                 n = a["launches"]
                 avg_ms = a["ms"] / n
                 ai = a["flops"] / max(a["bytes"], 1.0)
-                split = "split" in kern or kern.startswith(("head_decode", "down_unit"))   # f16 MFMA with split fp32 operands: never MFMA-bound at these shapes
+                split = "split" in kern or kern.startswith(("head_decode", "head_tail", "down_unit", "dwpw"))   # f16 MFMA with split fp32 operands: never MFMA-bound at these shapes
                 bound = "mfma" if (ai > ridge and not split) else "hbm"
                 if ai > PEAK_SPLIT_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
                     bound = "mfma"
@@ -540,7 +540,7 @@ def main():
                     "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
                     "avg_us": d["avg_us"], "share_of_step": d["share"]}
             fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
-            fl_split = sum(a["flops"] for k, a in agg.items() if "split" in k or k.startswith(("head_decode", "down_unit"))) / args.profile_steps
+            fl_split = sum(a["flops"] for k, a in agg.items() if "split" in k or k.startswith(("head_decode", "head_tail", "down_unit", "dwpw"))) / args.profile_steps
             by = sum(a["bytes"] for a in agg.values()) / args.profile_steps
             # matrix-pipe time: the split-f16 kernels at 833 TFLOP/s of fp32-class work, everything else at the f32-MFMA peak
             mfma_ms = ((fl - fl_split) / (PEAK_F32_TFLOPS * 1e12) + fl_split / (PEAK_SPLIT_TFLOPS * 1e12)) * 1e3

@@ -83,6 +83,11 @@ int  yn_group_launch(yn_handle* h, int enable);
  * width <= 64: stage 2, whose intermediate is the largest tensor of the network); default on, split-f16 family only, bit-identical to
  * the five launches.  Env: YN_DOWN_FUSE=0/1. */
 int  yn_down_fuse(yn_handle* h, int enable);
+/* Layers .2 + .3 + .4 of the three detection heads and the candidate decode as ONE grouped kernel — depthwise 3x3 + pointwise conv +
+ * last conv + decode on an 8 x 4 pixel tile; layer .3's activation never reaches memory (models/yolo_nano.py:60-82, 299-330, 362-367).
+ * Default on; needs yn_fuse_decode and yn_group_launch in effect and a head of 129..256 columns (COCO); otherwise, or with 0, two
+ * grouped kernels (depthwise + pointwise, last conv + decode).  Bit-identical either way.  Env: YN_TAIL_FUSE=0/1. */
+int  yn_tail_fuse(yn_handle* h, int enable);
 /* Per-class NMS (models/yolo_nano.py:159-188, 263-272): resolve the 64 best-scored boxes of every class first and drop every later box
  * one of their KEPT boxes suppresses before the dense pairwise phase (exact: a removed box suppresses nothing).  mode 0 = off, 1 (default) =
  * for batches of >= 4 images, 2 = always.  Same kept sets either way.  Env: YN_NMS_PREFILTER=0/1/2. */

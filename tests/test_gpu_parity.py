@@ -800,6 +800,7 @@ def test_fused_head_decode_is_bit_identical(hcoco, hvoc, which, S, B):
     h.set_thresholds(0.001, 0.5)
     x = dev(weights.make_input(B, S, seed=21))
     try:
+        h.tail_fuse(False)                                     # this test is about head_decode_kernel; the wider fusion has its own
         h.fuse_decode(False)
         ref = [t.clone() for t in h.infer(x)]
         h.fuse_decode(2)                                       # 2 = also below the size rule
@@ -816,6 +817,40 @@ def test_fused_head_decode_is_bit_identical(hcoco, hvoc, which, S, B):
         h.profile_enable(False)
         assert any(k.startswith("head_decode") for k in kernels) and not any(k.startswith("decode_kernel") for k in kernels)
     finally:
+        h.tail_fuse(True)
+        h.fuse_decode(True)
+        h.set_grid(old)
+
+
+@pytest.mark.parametrize("S,B", [(416, 4), (320, 3), (224, 2)])
+def test_head_tail_is_bit_identical(hcoco, S, B):
+    """yn_tail_fuse: layers .2 + .3 + .4 of the heads and the decode as one grouped kernel (head_tail_group_kernel, 8x4 pixel tiles)
+    give exactly the detections of dwpw_group_kernel + head_decode_group_kernel — map sizes that are not multiples of the tile
+    (52/26/13, 40/20/10, 28/14/7 cells per side) included."""
+    h = hcoco
+    old = h.S
+    h.set_grid(S)
+    h.set_thresholds(0.001, 0.5)
+    x = dev(weights.make_input(B, S, seed=33))
+    try:
+        h.fuse_decode(2)                                       # 2 = also below the size rule
+        h.tail_fuse(False)
+        ref = [t.clone() for t in h.infer(x)]
+        h.tail_fuse(True)
+        got = h.infer(x)
+        counts = ref[4].cpu().tolist()
+        assert got[4].cpu().tolist() == counts and sum(counts) > 0
+        for b in range(B):
+            k = counts[b]
+            for r, g_ in zip(ref[:4], got[:4]):
+                assert torch.equal(r[b, :k], g_[b, :k])
+        h.profile_enable(True)
+        h.infer(x)
+        kernels = [r[1] for r in h.profile_records()]
+        h.profile_enable(False)
+        assert any(k.startswith("head_tail") for k in kernels) and not any(k.startswith("head_decode") for k in kernels)
+    finally:
+        h.tail_fuse(True)
         h.fuse_decode(True)
         h.set_grid(old)
 
@@ -898,7 +933,7 @@ def test_grouped_launches_are_bit_identical(hcoco, hvoc, which, S, B):
         h.infer(x)
         names = [r[0] for r in h.profile_records()]
         h.profile_enable(False)
-        assert sum(n.startswith("head_det_") for n in names) in (3, 5), names      # 3: depthwise + pointwise pairs fused as well
+        assert sum(n.startswith("head_det_") for n in names) in (2, 3, 5), names   # 3: depthwise + pointwise pairs fused as well; 2: layers .2-.4 + decode in one kernel
     finally:
         h.fuse_decode(True)
         h.group_launch(True)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "yn_fuse_decode": (_i32, [_vp, _i32]),
     "yn_group_launch": (_i32, [_vp, _i32]),
     "yn_down_fuse": (_i32, [_vp, _i32]),
+    "yn_tail_fuse": (_i32, [_vp, _i32]),
     "yn_nms_prefilter": (_i32, [_vp, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
@@ -240,6 +241,10 @@ class Handle:
     def down_fuse(self, on=True):
         """Main branch of the stride-2 unit of stage 2 as one kernel (default on; bit-identical outputs either way)."""
         self._ck(self.lib.yn_down_fuse(self.h, int(bool(on))), "yn_down_fuse")
+
+    def tail_fuse(self, on=True):
+        """Layers .2-.4 of the detection heads + the decode as one grouped kernel (default on; bit-identical outputs either way)."""
+        self._ck(self.lib.yn_tail_fuse(self.h, int(bool(on))), "yn_tail_fuse")
 
     def group_launch(self, on=True):
         """The three heads' layer k / the three laterals as one grouped launch each (default on; bit-identical outputs either way)."""

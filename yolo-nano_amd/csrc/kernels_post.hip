@@ -370,6 +370,280 @@ void launch_head_decode_group(const GemmArgs* a, int n, const GridInfo& g, float
 #undef YN_HDG
 }
 
+// -------------------------------------------------------------------------------------------------
+// The tail of a detection head in ONE kernel (models/yolo_nano.py:60-82, 299-330, 362-367): depthwise 3x3 + pointwise conv (layers .2 and
+// .3: dwpw_group_kernel's tile and thread roles), the last conv (.4) on the tile while it is still in LDS, and the candidate decode of
+// head_decode_kernel.  Against dwpw_group_kernel + head_decode_group_kernel the 96-channel activation of layer .3 (44 MB per 32-image step
+// at 416 x 416) is neither written nor read back, and a chip-filling launch disappears.  Workgroup = an 8 x 4 pixel tile of one image.
+//   1. depthwise windows, taps, biases, the 96 x 96 split weight matrix and the first weight chunk of the last conv: one batch of loads
+//   2. depthwise -> split planes A [32][104] x 2; W -> LDS; three wavefronts run the 96 -> 96 GEMM (K in gemm_split_tile's order)
+//   3. barrier; activation, split -> the SAME planes (now the last conv's A operand); last conv's chunk 0 -> the weight space
+//   4. four wavefronts x 64 columns: K = 96 in three chunks of 32 through one LDS buffer (register prefetch), as gemm_split_tile<1,4,2>
+//   5. raw head tile [32][260] fp32 over the weight space, per-row candidate index / cell, then head_decode_kernel's three decode passes
+// Every sum runs in the order of the separate kernels and the operand split is the same function of the same fp32 values: bit-identical
+// outputs (test_head_tail_is_bit_identical).  LDS 50 KB: three workgroups per CU.
+// -------------------------------------------------------------------------------------------------
+template <int KMAX>
+__device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const GridInfo& g, int scale, float conf_thresh,
+                                                float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
+                                                c3h16* smem, unsigned bid, unsigned nblocks)
+{
+    constexpr int TW = 8, TH = 4, NO = TW * TH, C = 96, KQ = C / 8, BN1 = 96, AST = C + 8, R = 4, BN2 = 256, LD = BN2 + 4;
+    c3h16* Ah = smem;                                       // [NO][AST]
+    c3h16* Al = Ah + NO * AST;
+    c3h16* Bs = Al + NO * AST;                              // [2][KQ][BN1][8], then chunks [2][4][BN2][8], then the raw tile
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+    const int tx_n = (a.W + TW - 1) / TW, ty_n = (a.H + TH - 1) / TH;
+    const int tile = (int)(((bid & 7u) * (nblocks >> 3)) + (bid >> 3));
+    if (tile >= a.B * ty_n * tx_n) return;
+    const int b = tile / (ty_n * tx_n), trem = tile - b * (ty_n * tx_n);
+    const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
+
+    // ---- 1. loads -----------------------------------------------------------------------------------------------------------------
+    const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs of 4 pixels = 192 workers
+    const bool worker = run < 8;
+    const int c = cq * 4, ry = run >> 1, rx = (run & 1) * R;
+    float4 win[3][R + 2], wd[9], bd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (worker) {
+        const int oy = oy0 + ry;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            const bool yok = oy < a.H && iy >= 0 && iy < a.H;
+            const float* rowp = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * C + c;
+#pragma unroll
+            for (int j = 0; j < R + 2; ++j) {
+                const int ix = ox0 + rx - 1 + j;
+                const bool ok = yok && ix >= 0 && ix < a.W;
+                win[ky][j] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(a.wdw + k * C + c);
+        bd = *reinterpret_cast<const float4*>(a.bdw + c);
+    }
+    constexpr int B1_PER = (2 * KQ * BN1 + 255) / 256;      // 9 granules of 16 bytes per thread
+    c3h16x8 b1_reg[B1_PER];
+#pragma unroll
+    for (int i = 0; i < B1_PER; ++i) {
+        const int gi = t + 256 * i;                         // plane, octet, column
+        const int pl = gi / (KQ * BN1), r = gi - pl * (KQ * BN1);
+        const int o = r / BN1, n = r - o * BN1;
+        c3h16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
+        if (gi < 2 * KQ * BN1) v = *reinterpret_cast<const c3h16x8*>(reinterpret_cast<const c3h16*>(pl ? a.Wl : a.Wh) + ((size_t)o * BN1 + n) * 8);
+        b1_reg[i] = v;
+    }
+    const float gbias = (wave < 3) ? a.bias[wave * 32 + l31] : 0.0f;
+    constexpr int B2_PER = 2 * 4 * BN2 / 256;               // 8 granules per thread and chunk
+    c3h16x8 b2_reg[B2_PER];
+    auto prefetch_b2 = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < B2_PER; ++i) {
+            const int gi = t + 256 * i;
+            const int pl = gi / (4 * BN2), r = gi - pl * (4 * BN2);
+            const int o = r / BN2, n = r - o * BN2;
+            const bool ok = n < a.Npad;
+            c3h16x8 v = *reinterpret_cast<const c3h16x8*>(reinterpret_cast<const c3h16*>(pl ? a.Wfl : a.Wfh) + ((size_t)(chunk * 4 + o) * a.Npad + (ok ? n : 0)) * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
+            }
+            b2_reg[i] = v;
+        }
+    };
+    auto stage_b2 = [&]() {
+#pragma unroll
+        for (int i = 0; i < B2_PER; ++i) *reinterpret_cast<c3h16x8*>(Bs + (size_t)(t + 256 * i) * 8) = b2_reg[i];
+    };
+    float fbias[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { const int n = wave * 64 + nt * 32 + l31; fbias[nt] = a.fbias[n < a.Npad ? n : 0]; }
+
+    // ---- 2. depthwise -> split planes; W -> LDS; 96 -> 96 GEMM on three wavefronts -----------------------------------------------------
+    if (worker) {
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            float4 acc = bd;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) vfma(acc, win[ky][o + kx], wd[ky * 3 + kx]);
+            acc = vact(acc, a.dw_act);
+            const int op = ry * TW + rx + o;
+            const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
+            c3h16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
+            *reinterpret_cast<c3h16x4*>(Ah + op * AST + c) = hi;
+            *reinterpret_cast<c3h16x4*>(Al + op * AST + c) = lo;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B1_PER; ++i) {
+        const int gi = t + 256 * i;
+        if (gi < 2 * KQ * BN1) *reinterpret_cast<c3h16x8*>(Bs + (size_t)gi * 8) = b1_reg[i];
+    }
+    prefetch_b2(0);
+    __syncthreads();
+    f32x16 m0, m1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { m0[k] = 0.0f; m1[k] = 0.0f; }
+    if (wave < 3) {
+        const c3h16* Ahb = Ah + l31 * AST + h * 8;
+        const c3h16* Alb = Al + l31 * AST + h * 8;
+        const c3h16* Bhb = Bs + (size_t)(h * BN1 + wave * 32 + l31) * 8;
+        const c3h16* Blb = Bhb + (size_t)KQ * BN1 * 8;
+#pragma unroll
+        for (int ks = 0; ks < KQ / 2; ++ks) {
+            const c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Ahb + ks * 16);
+            const c3h16x8 al = *reinterpret_cast<const c3h16x8*>(Alb + ks * 16);
+            const c3h16x8 bh = *reinterpret_cast<const c3h16x8*>(Bhb + (size_t)(ks * 2 * BN1) * 8);
+            const c3h16x8 bl = *reinterpret_cast<const c3h16x8*>(Blb + (size_t)(ks * 2 * BN1) * 8);
+            m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, m1, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, m1, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                        // every operand read of the first GEMM is done: planes and weight space are free
+
+    // ---- 3. layer .3's output tile -> the planes (the last conv's A operand); its first weight chunk -> LDS ------------------------------
+    if (wave < 3) {
+        const int n = wave * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = apply_act(__builtin_fmaf(m1[r], 1.0f / 2048.0f, m0[r]) + gbias, a.act);
+            const c3h16 hi = (c3h16)v;
+            Ah[row * AST + n] = hi;
+            Al[row * AST + n] = (c3h16)((v - (float)hi) * 2048.0f);
+        }
+    }
+    stage_b2();
+    __syncthreads();
+    prefetch_b2(1);
+
+    // ---- 4. the last conv: 32 x 256, wavefront = 64 columns ---------------------------------------------------------------------------
+    f32x16 acc0[2], acc1[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[nt][k] = 0.0f; acc1[nt][k] = 0.0f; }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const c3h16* Ahb = Ah + l31 * AST + ch * 32 + h * 8;
+        const c3h16* Alb = Al + l31 * AST + ch * 32 + h * 8;
+        const c3h16* Bhb = Bs + (size_t)(h * BN2 + wave * 64 + l31) * 8;
+        const c3h16* Blb = Bhb + (size_t)4 * BN2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Ahb + ks * 16);
+            const c3h16x8 al = *reinterpret_cast<const c3h16x8*>(Alb + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const c3h16x8 bh = *reinterpret_cast<const c3h16x8*>(Bhb + (size_t)(ks * 2 * BN2 + nt * 32) * 8);
+                const c3h16x8 bl = *reinterpret_cast<const c3h16x8*>(Blb + (size_t)(ks * 2 * BN2 + nt * 32) * 8);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // every wavefront is done with this chunk's weights (and, after the last one, with the planes)
+        if (ch + 1 < 3) {
+            stage_b2();
+            __syncthreads();
+            if (ch + 2 < 3) prefetch_b2(ch + 2);
+        }
+    }
+
+    // ---- 5. raw tile, per-row candidate index, decode ------------------------------------------------------------------------------------
+    float* raw = reinterpret_cast<float*>(Bs);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = wave * 64 + nt * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            raw[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + n] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + fbias[nt];
+    }
+    int* rowinfo = reinterpret_cast<int*>(raw + NO * LD + NO * 16);     // [32][4]: first candidate, gx, gy, inside the image
+    if (t < NO) {
+        const int py = oy0 + t / TW, px = ox0 + t % TW;
+        const bool ok = py < a.H && px < a.W;
+        const int cell = ok ? py * a.W + px : 0;
+        *reinterpret_cast<int4*>(rowinfo + t * 4) = make_int4(b * g.N + g.off[scale] + cell * g.A, px, py, ok ? 1 : 0);
+    }
+    const unsigned magicA = (65536u + (unsigned)g.A - 1u) / (unsigned)g.A;     // c / A == (c * magicA) >> 16 for c < 32 * A <= 256
+    __syncthreads();
+    float* st_sum = raw + NO * LD;                          // [32 * A] sum of exponentials, or the final score (general path)
+    int* st_cls = reinterpret_cast<int*>(st_sum + NO * g.A);
+    const int j = t & 15;
+    const int ncand = NO * g.A;
+    for (int cnd = t >> 4; cnd < ncand; cnd += 16) {
+        const int row = (int)(((unsigned)cnd * magicA) >> 16), an = cnd - row * g.A;
+        float sum, sc;
+        int cbest;
+        const float* rp = raw + row * LD;
+        const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
+        if (j == 0) { st_sum[cnd] = fin ? sc : sum; st_cls[cnd] = fin ? (cbest | (int)0x80000000) : cbest; }
+    }
+    __syncthreads();
+    for (int q = t; q < 5 * ncand; q += 256) {
+        const bool is_score = q < ncand;
+        const int cnd = is_score ? q : (q - ncand) >> 2, k = (q - ncand) & 3;
+        const int row = (int)(((unsigned)cnd * magicA) >> 16), an = cnd - row * g.A;
+        const int4 ri = *reinterpret_cast<const int4*>(rowinfo + row * 4);
+        if (!ri.w) continue;                                // tile pixel outside the image
+        const int i = ri.x + an;
+        const float* rp = raw + row * LD;
+        if (is_score) {
+            const int cw = st_cls[cnd];
+            const float sc = (cw < 0) ? st_sum[cnd] : 1.0f / st_sum[cnd] * sigmoid_f(rp[an]);
+            scores[i] = sc;
+            cls[i] = (sc >= conf_thresh) ? (cw & 0x7fffffff) : -1;
+        } else {
+            const float* tb = rp + g.A * (1 + g.C) + an * 4;
+            boxes[(size_t)i * 4 + k] = decode_coord(g, scale, ri.y, ri.z, an, tb[k & 1], tb[2 + (k & 1)], (float)g.S, k);
+        }
+    }
+}
+
+constexpr int HEAD_TAIL_HALVES = 2 * 32 * 104 + 2 * 12 * 96 * 8;        // planes + the larger of {W 96x96, a chunk of the last conv, the raw tile}
+static_assert(2 * 12 * 96 * 8 >= 2 * 4 * 256 * 8 && 2 * 12 * 96 * 8 >= 32 * 260 * 2 + 32 * 8 * 4 + 32 * 4 * 2, "weight space holds a chunk and the raw tile");
+
+template <int KMAX>
+__global__ __launch_bounds__(256, 3) void head_tail_group_kernel(Group<HeadTailArgs> q, GridInfo g, float conf_thresh,
+                                                                  float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls)
+{
+    extern __shared__ __attribute__((aligned(16))) float head_tail_smem[];
+    unsigned local, nb;
+    const int p = group_problem(q.first, blockIdx.x, local, nb);
+    head_tail_block<KMAX>(q.a[p], g, p, conf_thresh, boxes, scores, cls, reinterpret_cast<c3h16*>(head_tail_smem), local, nb);
+}
+
+bool head_tail_ok(const HeadTailArgs* q, int n, const GridInfo& g)
+{
+    if (n < 1 || n > YN_GROUP_MAX || g.C > 80 || g.C <= 32 || g.A > 8 || g.A < 1) return false;
+    for (int p = 0; p < n; ++p)
+        if (!q[p].Wh || !q[p].Wl || !q[p].Wfh || !q[p].Wfl || q[p].Npad <= 128 || q[p].Npad > 256 || g.A * (5 + g.C) > q[p].Npad || q[p].B <= 0) return false;
+    return true;
+}
+
+void launch_head_tail_group(const HeadTailArgs* a, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s)
+{
+    Group<HeadTailArgs> q{};
+    unsigned tot = 0;
+    for (int p = 0; p < YN_GROUP_MAX; ++p) {
+        q.first[p] = tot;
+        if (p < n) { q.a[p] = a[p]; tot += (unsigned)(((unsigned)a[p].B * ((a[p].H + 3) / 4) * ((a[p].W + 7) / 8) + 7u) & ~7u); }
+    }
+    q.first[YN_GROUP_MAX] = tot;
+    const size_t lds = (size_t)HEAD_TAIL_HALVES * 2;
+    static unsigned long long attr = 0;
+    if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_group_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((head_tail_group_kernel<5>), dim3(tot), dim3(256), lds, s, q, g, conf_thresh, boxes, scores, cls);
+}
+
 // YOLONano.decode_boxes: txtytwth [B, sumHW, A, 4] -> xyxy pixels [B, N, 4]
 __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* __restrict__ t, GridInfo g, int B, float* __restrict__ out)
 {

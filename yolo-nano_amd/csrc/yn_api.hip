@@ -121,6 +121,7 @@ struct yn_handle {
     bool use_graph = false;
     long net_passes = 0;                   // run_network calls so far (dbg_skip)
     bool dwpw_fuse = true;                 // YN_DWPW_FUSE=0: the heads' depthwise + pointwise pairs as two grouped launches instead of one kernel
+    bool tail_fuse = true;                 // YN_TAIL_FUSE=0: layers .2+.3 and .4+decode of the heads as two grouped kernels instead of one (head_tail_group_kernel)
     bool down_fuse = true;                 // yn_down_fuse / YN_DOWN_FUSE=0: the main branch of a stride-2 unit as one kernel (down_unit_kernel)
     bool group_launch = true;              // yn_group_launch / YN_GROUP=0: the three heads' layers (and the laterals) as grouped launches
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
@@ -970,9 +971,36 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             launch_dwpw_group(q, 3, h->cur);
             return true;
         };
-        bool ok = (dwpw_layer(0, nullptr, feats, hB, "head_det_*.0+1") || (dw_layer(0, nullptr, feats, hA, "head_det_*.0") && pw_layer(1, hA, hB, NECK, 0, "head_det_*.1"))) &&
-                  (dwpw_layer(2, hB, nullptr, hC, "head_det_*.2+3") || (dw_layer(2, hB, nullptr, hA, "head_det_*.2") && pw_layer(3, hA, hC, NECK, 0, "head_det_*.3")));
-        if (ok) {
+        // layers .2 + .3 + .4 + the decode as ONE grouped kernel (head_tail_group_kernel): layer .3's output never reaches memory
+        auto tail_layer = [&](float* const src[3]) {
+            if (!fuse_all || !h->tail_fuse || !h->dwpw_fuse) return false;
+            HeadTailArgs q[3];
+            double fl = 0, by = 0;
+            for (int hd = 0; hd < 3; ++hd) {
+                const Layer &ld = *hl[2][hd], &lp = *hl[3][hd], &lf = *hl[4][hd];
+                if (ld.stride != 1 || ld.cout != NECK || lp.cin != NECK || lp.cout != NECK || lp.Npad != NECK || lf.cin != NECK || NECK != 96 || !lf.ws_hi) return false;
+                const GemmArgs gf = head_final_args(h, lf, src[hd], (long)B * Ws[hd] * Ws[hd]);
+                if (gf.act != 0 || gf.pass) return false;
+                q[hd] = HeadTailArgs{};
+                q[hd].in = src[hd]; q[hd].wdw = ld.w_packed; q[hd].bdw = ld.b_packed; q[hd].dw_act = ld.act;
+                q[hd].Wh = lp.ws_hi; q[hd].Wl = lp.ws_lo; q[hd].bias = lp.b_packed; q[hd].act = lp.act;
+                q[hd].Wfh = gf.Wsh; q[hd].Wfl = gf.Wsl; q[hd].fbias = gf.bias; q[hd].Npad = gf.Npad;
+                q[hd].B = B; q[hd].H = Ws[hd]; q[hd].W = Ws[hd];
+                const double M = (double)B * Ws[hd] * Ws[hd];
+                fl += 2.0 * M * NECK * (9.0 + NECK) + 2.0 * M * lf.cin * lf.cout;
+                by += 4.0 * (M * NECK + (double)NECK * NECK + (double)lf.cin * lf.cout + 6.0 * M * h->grid.A);
+            }
+            if (!head_tail_ok(q, 3, h->grid)) return false;
+            if (dbg_skip(h, "head_det_*.2+3+4")) return true;
+            set_last_kernel_name("head_tail_group_kernel");
+            Bracket br(h, "head_det_*.2+3+4+decode", fl, by);
+            launch_head_tail_group(q, 3, h->grid, h->cfg.conf_thresh, h->cand_boxes, h->cand_scores, h->cand_cls, h->cur);
+            return true;
+        };
+        bool ok = dwpw_layer(0, nullptr, feats, hB, "head_det_*.0+1") || (dw_layer(0, nullptr, feats, hA, "head_det_*.0") && pw_layer(1, hA, hB, NECK, 0, "head_det_*.1"));
+        const bool tailed = ok && tail_layer(hB);
+        if (ok && !tailed) ok = dwpw_layer(2, hB, nullptr, hC, "head_det_*.2+3") || (dw_layer(2, hB, nullptr, hA, "head_det_*.2") && pw_layer(3, hA, hC, NECK, 0, "head_det_*.3"));
+        if (ok && !tailed) {
             if (fuse_all) {
                 GemmArgs g3[3];
                 double fl = 0, by = 0;
@@ -1076,6 +1104,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
     if (const char* e10 = getenv("YN_DOWN_FUSE")) h->down_fuse = atoi(e10) != 0;
     if (const char* e11 = getenv("YN_DWPW_FUSE")) h->dwpw_fuse = atoi(e11) != 0;
+    if (const char* e12 = getenv("YN_TAIL_FUSE")) h->tail_fuse = atoi(e12) != 0;
     if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
@@ -1183,6 +1212,14 @@ int yn_down_fuse(yn_handle* h, int enable)
     if (!h) return 1;
     if ((enable != 0) != h->down_fuse) drop_graphs(h);
     h->down_fuse = enable != 0;
+    return 0;
+}
+
+int yn_tail_fuse(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != h->tail_fuse) drop_graphs(h);
+    h->tail_fuse = enable != 0;
     return 0;
 }
 

@@ -235,6 +235,16 @@ void launch_dw_group(const DwArgs* a, int n, hipStream_t s);                    
 bool dw_group_ok(const DwArgs* a, int n);
 bool launch_pw_group(const GemmArgs* a, int n, int cfg, hipStream_t s);          // split-f16 family only; cfg = pointwise configuration index or -1
 void launch_head_decode_group(const GemmArgs* a, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s);
+// the tail of a detection head as one kernel: depthwise 3x3 + pointwise conv (layers .2 + .3) + last conv (.4) + candidate decode
+struct HeadTailArgs {
+    const float* in;                                    // [B][H][W][96] dense (the output of layers .0 + .1)
+    const float* wdw; const float* bdw; int dw_act;     // depthwise [9][96], [96]
+    const void *Wh, *Wl; const float* bias; int act;    // pointwise 96 -> 96: split packs [12][96][8]
+    const void *Wfh, *Wfl; const float* fbias; int Npad;   // last conv 96 -> A(5+C): split packs [12][Npad][8], bias [Npad]
+    int B, H, W;
+};
+bool head_tail_ok(const HeadTailArgs* q, int n, const GridInfo& g);
+void launch_head_tail_group(const HeadTailArgs* q, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s);
 
 // hipFuncSetAttribute acts on the CURRENT device: every call site keeps a bit mask of the devices it has configured
 inline bool attr_pending(unsigned long long& mask)
