@@ -888,7 +888,13 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     }
     // small batches: three 16 us fused launches against three 10 us GEMMs + one 7 us decode (bs = 1) - the fusion pays from the
     // traffic it removes, i.e. when the stride-8 head is large (bs >= 4 at 416x416); yn_fuse_decode(2) forces it (tests)
-    if (h->fuse_decode_mode != 2 && (long)B * W3 * W3 < 8192) fuse_all = false;
+    // ... unless the wider fusion applies (head_tail_group_kernel: layers .2-.4 + decode as ONE launch instead of three: bs = 1 0.602 -> 0.593 ms)
+    bool tail_possible = false;
+    if (fuse_all && h->tail_fuse && h->dwpw_fuse && h->group_launch && h->grid.C > 32) {
+        const GemmArgs gf = head_final_args(h, L(h, "head_det_1.4"), nullptr, (long)B * W3 * W3);
+        tail_possible = gf.Npad > 128 && gf.Npad <= 256;
+    }
+    if (h->fuse_decode_mode != 2 && (long)B * W3 * W3 < 8192 && !tail_possible) fuse_all = false;
     if (fused) *fused = fuse_all;
     auto run_head = [&](int hd) {
         const long M = (long)B * Ws[hd] * Ws[hd];
