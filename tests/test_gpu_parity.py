@@ -720,6 +720,38 @@ def test_nms_segment_larger_than_32768(hvoc, capi):
         hvoc.nms(torch.zeros((140000, 4), device="cuda"), torch.zeros((140000,), device="cuda"), 0.5)
 
 
+@pytest.mark.parametrize("prefilter", [0, 2])
+def test_postprocess_very_large_classes(hvoc, prefilter):
+    """Class segments above 4 160 boxes (608 x 608 with random weights: ~5 000 boxes of one class per image) go through
+    resolve_large_kernel — 512 threads, eight per matrix row, up to 129 chunks staged in registers, the generic band walk beyond —
+    while the smaller classes of the same image stay on resolve_kernel: kept sets identical to the oracle's."""
+    rs = np.random.RandomState(17)
+    N, C = 14000, 20
+    def image(sizes):
+        cls = np.concatenate([np.full(k, c) for c, k in sizes.items()] + [rs.randint(10, C, N - sum(sizes.values()))]).astype(np.int64)
+        rs.shuffle(cls)
+        ctr = rs.uniform(0.05, 0.95, (N, 2)); wh = rs.uniform(0.02, 0.09, (N, 2))
+        boxes = np.clip(np.concatenate([ctr - wh / 2, ctr + wh / 2], 1), 0, 1).astype(np.float32)
+        conf = np.zeros((N, C), np.float32)
+        conf[np.arange(N), cls] = rs.uniform(0.01, 1.0, N).astype(np.float32)
+        return boxes, conf
+    b0, c0 = image({0: 6500, 1: 4300, 2: 900})              # 102 chunks (staged walk), 68 chunks, a mid-sized class
+    b1, c1 = image({3: 9000, 4: 64})                        # 141 chunks: beyond the staged walk
+    hvoc.set_thresholds(0.001, 0.5)
+    hvoc.nms_prefilter(prefilter)
+    try:
+        out = hvoc.postprocess(dev(np.stack([b0, b1])), dev(np.stack([c0, c1])))
+        counts = out[4].cpu().tolist()
+        for bi, (bb, cc) in enumerate(((b0, c0), (b1, c1))):
+            rb, rs_, rc = orc.postprocess(bb, cc, 0.001, 0.5)
+            k = counts[bi]
+            assert k == len(rs_), (bi, k, len(rs_))
+            assert np.array_equal(out[0][bi, :k].cpu().numpy(), rb) and np.array_equal(out[1][bi, :k].cpu().numpy(), rs_)
+            assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
+    finally:
+        hvoc.nms_prefilter(1)
+
+
 def test_pack_detections(hcoco):
     """yn_pack_detections: the whole batch's kept rows as one record list + offsets == the per-image outputs."""
     hcoco.set_grid(416)

@@ -1024,7 +1024,7 @@ struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; int kidx[64]; int nk; 
 template <int NB>
 struct ResolvePre { u64 nb[NB]; u64 diag; int id; };
 
-template <int NB>
+template <int NB, int TPR>
 __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_t* __restrict__ ids, int n, const u64* __restrict__ M, int T, int ri,
                                                  int lane, int wave, int pr, int pc)
 {
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_
     const size_t boff = band_off(ri, T) + (size_t)pr * W;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        const int w = 1 + pc + 4 * u;
+        const int w = 1 + pc + TPR * u;
         p.nb[u] = (w < W) ? M[boff + w] : 0ull;
     }
 }
@@ -1074,28 +1074,28 @@ __device__ __forceinline__ void resolve_diag(u64 diag, int id, int n, int ri, in
     if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; }
 }
 
-template <int NB>
+template <int NB, int TPR = 4>                               // TPR threads per matrix row (64 * TPR threads per workgroup), NB words per thread
 __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
                                              int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = (n + 63) >> 6;
-    const int pr = tid >> 2, pc = tid & 3;
+    const int pr = tid / TPR, pc = tid % TPR;
     ResolvePre<NB> P0, P1, P2;
-    resolve_prefetch<NB>(P0, ids, n, M, T, 0, lane, wave, pr, pc);
-    resolve_prefetch<NB>(P1, ids, n, M, T, 1, lane, wave, pr, pc);
+    resolve_prefetch<NB, TPR>(P0, ids, n, M, T, 0, lane, wave, pr, pc);
+    resolve_prefetch<NB, TPR>(P1, ids, n, M, T, 1, lane, wave, pr, pc);
     __syncthreads();
     int picked = 0;
 #define YN_BAND(P, PNEXT2, ri_)                                                                              \
     {                                                                                                        \
         const int ri = (ri_);                                                                                \
-        resolve_prefetch<NB>(PNEXT2, ids, n, M, T, ri + 2, lane, wave, pr, pc);                              \
+        resolve_prefetch<NB, TPR>(PNEXT2, ids, n, M, T, ri + 2, lane, wave, pr, pc);                         \
         if (wave == 0) resolve_diag(P.diag, P.id, n, ri, lane, picked, keep_flags, pick_list, L);            \
         __syncthreads();                                                                                     \
         picked += L.nk;                                                                                      \
         if ((L.keepm >> pr) & 1ull) {                                                                        \
             _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                   \
-                if (P.nb[u]) atomicOr(&L.rem[ri + 1 + pc + 4 * u], P.nb[u]);                                 \
+                if (P.nb[u]) atomicOr(&L.rem[ri + 1 + pc + TPR * u], P.nb[u]);                               \
         }                                                                                                    \
         __syncthreads();                                                                                     \
     }
@@ -1119,6 +1119,7 @@ __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, 
         if (T <= 33) return resolve_bands<8>(ids, n, M, keep_flags, pick_list, L);
         if (T <= 65) return resolve_bands<16>(ids, n, M, keep_flags, pick_list, L);
     }
+    if (nthr == 512 && T <= 129) return resolve_bands<16, 8>(ids, n, M, keep_flags, pick_list, L);     // resolve_large_kernel: eight threads per row
     // very large segments (n > 4160): no register staging, the kept rows' words are read when they are needed
     u64 diag_next = 0;
     int id_next = 0;
@@ -1157,12 +1158,33 @@ __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, 
 
 __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                        const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
-                                                       int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep)
+                                                       int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep, int n_max)
 {
     __shared__ ResolveLds L;
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
-    if (n == 0) return;
+    if (n == 0 || n > n_max) return;                        // n > n_max: resolve_large_kernel's
+    resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
+                    M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
+}
+
+// Segments above YN_RESOLVE_SPLIT boxes (more than 65 chunks: the register-staged band walk of a 256-thread workgroup ends there, and the
+// generic loop behind it reads every kept row's words when it needs them — 352 us at 608 x 608, where random weights put ~5 000 boxes into
+// one class): a 512-thread workgroup, eight threads per matrix row, covers 129 chunks with the same staged walk.  grid.x indexes the image's
+// list of large segments (bucket_kernel's, n > 1024 before the prefilter).
+#define YN_RESOLVE_SPLIT 4160
+__global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                             const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
+                                                             int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep,
+                                                             const int32_t* __restrict__ large_list, int large_cap)
+{
+    __shared__ ResolveLds L;
+    const int b = blockIdx.y;
+    const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+    if ((int)blockIdx.x >= ll[0]) return;
+    const int c = ll[1 + blockIdx.x];
+    const int n = seg_count[(size_t)b * C + c];
+    if (n <= YN_RESOLVE_SPLIT) return;
     resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
                     M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
@@ -1446,7 +1468,13 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
     else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
     mark("resolve_kernel");
-    if (!(skip & 4)) hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep);
+    const bool split = N > YN_RESOLVE_SPLIT && wk.large_list && large_cap > 0;
+    if (!(skip & 4)) {
+        hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
+                           split ? YN_RESOLVE_SPLIT : 1 << 30);
+        if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
+                                      wk.keep, (const int32_t*)wk.large_list, large_cap);
+    }
     mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
 }
