@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
 // rem[] bounds the segment size: n <= 64 * YN_RESOLVE_MAX_T = 131 072 boxes of one class (nms_max_segment(); the C ABI
 // rejects larger work before anything is launched — the suppression matrix of such a segment would be > 1 GB anyway)
 #define YN_RESOLVE_MAX_T 2048
-struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; int kidx[64]; int nk; };
+struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; u64 keepm2[2]; int kidx[64]; int nk; };     // keepm2: band ri's kept mask in slot ri & 1 (resolve_bands)
 
 // Everything a band reads from memory — its diagonal word and candidate id (wave 0), its off-diagonal words (all threads:
 // thread -> row tid/4, columns 1 + (tid&3) + 4u) — is requested TWO bands ahead, into one of three register sets: a band's own work
@@ -1022,7 +1022,7 @@ struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; int kidx[64]; int nk; 
 // version) every band waited for its loads: 132 k cycles for the 39 bands of the benchmark's largest segment, 37 serial steps in all
 // (81 -> 66 us; issuing the loads unconditionally at clamped addresses to keep the vmcnt bookkeeping static was slower: 104 us).
 template <int NB>
-struct ResolvePre { u64 nb[NB]; u64 diag; int id; };
+struct ResolvePre { u64 nb[NB]; u64 diag, c1; int id; };       // c1 (wave 0): the band's column-1 word of row `lane`
 
 template <int NB, int TPR>
 __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_t* __restrict__ ids, int n, const u64* __restrict__ M, int T, int ri,
@@ -1032,6 +1032,7 @@ __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_
     const int W = T - ri;
     if (wave == 0) {
         p.diag = M[band_off(ri, T) + (size_t)lane * W];
+        p.c1 = W > 1 ? M[band_off(ri, T) + (size_t)lane * W + 1] : 0ull;
         p.id = (ri * 64 + lane < n) ? ids[ri * 64 + lane] : 0;
     }
     const size_t boff = band_off(ri, T) + (size_t)pr * W;
@@ -1043,8 +1044,8 @@ __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_
 }
 
 // wave 0: which boxes of chunk ri survive (-> L.keepm, L.kidx, L.nk; keep flags / pick list)
-__device__ __forceinline__ void resolve_diag(u64 diag, int id, int n, int ri, int lane, int picked,
-                                             int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+__device__ __forceinline__ u64 resolve_diag(u64 diag, int id, int n, int ri, int lane, int picked,
+                                            int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
     const int cnt = min(64, n - ri * 64);
     const u64 validm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
@@ -1071,7 +1072,8 @@ __device__ __forceinline__ void resolve_diag(u64 diag, int id, int n, int ri, in
         if (keep_flags) keep_flags[id] = 1;
         if (pick_list) pick_list[picked + rank] = id;
     }
-    if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; }
+    if (lane == 0) { L.nk = __popcll(keepm); L.keepm = keepm; L.keepm2[ri & 1] = keepm; }
+    return keepm;
 }
 
 template <int NB, int TPR = 4>                               // TPR threads per matrix row (64 * TPR threads per workgroup), NB words per thread
@@ -1085,18 +1087,25 @@ __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, in
     resolve_prefetch<NB, TPR>(P0, ids, n, M, T, 0, lane, wave, pr, pc);
     resolve_prefetch<NB, TPR>(P1, ids, n, M, T, 1, lane, wave, pr, pc);
     __syncthreads();
+    // One barrier per band, the serial step overlapped with the bulk work: in iteration ri wavefront 0 resolves the diagonal tile of band
+    // ri and ORs the kept rows' COLUMN-1 words into rem[ri + 1] itself (its own LDS operations execute in order, so it sees them when it
+    // resolves band ri + 1), while all threads apply band ri - 1's remaining words — kept mask from slot (ri - 1) & 1 — to rem[ri + 1 ...]:
+    // what diag(ri + 1) needs from bands <= ri - 1 is complete at the barrier that ends iteration ri.  (First version: diag, barrier,
+    // apply, barrier per band, 1.9 us each: 159 us for the 83 bands of the largest class at 608 x 608, bs 1.)
     int picked = 0;
-#define YN_BAND(P, PNEXT2, ri_)                                                                              \
+#define YN_BAND(P, PPREV, ri_)                                                                               \
     {                                                                                                        \
         const int ri = (ri_);                                                                                \
-        resolve_prefetch<NB, TPR>(PNEXT2, ids, n, M, T, ri + 2, lane, wave, pr, pc);                         \
-        if (wave == 0) resolve_diag(P.diag, P.id, n, ri, lane, picked, keep_flags, pick_list, L);            \
-        __syncthreads();                                                                                     \
-        picked += L.nk;                                                                                      \
-        if ((L.keepm >> pr) & 1ull) {                                                                        \
-            _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                   \
-                if (P.nb[u]) atomicOr(&L.rem[ri + 1 + pc + TPR * u], P.nb[u]);                               \
+        if (wave == 0) {                                                                                     \
+            const u64 km = resolve_diag(P.diag, P.id, n, ri, lane, picked, keep_flags, pick_list, L);        \
+            picked += __popcll(km);                                                                          \
+            if (((km >> lane) & 1ull) && P.c1) atomicOr(&L.rem[ri + 1], P.c1);                               \
         }                                                                                                    \
+        if (ri >= 1 && ((L.keepm2[(ri - 1) & 1] >> pr) & 1ull)) {                                            \
+            _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                   \
+                if (PPREV.nb[u]) atomicOr(&L.rem[ri + pc + TPR * u], PPREV.nb[u]);                           \
+        }                                                                                                    \
+        resolve_prefetch<NB, TPR>(PPREV, ids, n, M, T, ri + 2, lane, wave, pr, pc);                          \
         __syncthreads();                                                                                     \
     }
     for (int r0 = 0; r0 < T; r0 += 3) {
@@ -1105,7 +1114,9 @@ __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, in
         if (r0 + 2 < T) YN_BAND(P2, P1, r0 + 2)
     }
 #undef YN_BAND
-    return picked;
+    if (tid == 0) L.nk = picked;
+    __syncthreads();
+    return L.nk;
 }
 
 __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
@@ -1336,31 +1347,83 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
                                                         int32_t* __restrict__ out_cls, int32_t* __restrict__ out_index,
                                                         int32_t* __restrict__ count)
 {
-    __shared__ int wave_sums[16];
-    __shared__ int base;
+    // 32 chunks of 1024 candidates per pass: every keep flag of the pass is requested in one batch, the per-chunk wavefront counts go to
+    // LDS, ONE barrier, then every thread derives the positions of its (up to 32) kept candidates.  (First version: load, ballot,
+    // barrier x 3 per chunk — a 1.2 us serial step 11 / 23 times per image at 416 / 608: 15 / 27 us of the bs = 1 chain.)
+    constexpr int IT = 32;
+    __shared__ int wave_sums[IT][16];
+    __shared__ int part[8];
+    __shared__ int base, total_next;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
-    for (int n0 = 0; n0 < N; n0 += 1024) {
-        const int n = n0 + threadIdx.x;
-        const int f = (n < N && keep[(size_t)b * N + n]) ? 1 : 0;
-        const unsigned long long bal = __ballot(f);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_sums[wave] = __popcll(bal);
-        __syncthreads();
-        int wbase = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) { const int v = wave_sums[w]; if (w < wave) wbase += v; tot += v; }
-        const int pos = base + wbase + before;
-        if (f) {
-            const size_t src = (size_t)b * N + n, dst = (size_t)b * N + pos;
-            *reinterpret_cast<float4*>(out_boxes + dst * 4) = *reinterpret_cast<const float4*>(boxes + src * 4);
-            out_scores[dst] = scores[src];
-            out_cls[dst] = cls[src];
-            if (out_index) out_index[dst] = n;
+    for (int n0 = 0; n0 < N; n0 += IT * 1024) {
+        int kf[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int n = n0 + it * 1024 + threadIdx.x;
+            kf[it] = keep[(size_t)b * N + (n < N ? n : N - 1)];
+        }
+        unsigned flags = 0;
+        int before[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int n = n0 + it * 1024 + threadIdx.x;
+            const int f = (n < N && kf[it]) ? 1 : 0;
+            const unsigned long long bal = __ballot(f);
+            before[it] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_sums[it][wave] = __popcll(bal);
+            flags |= (unsigned)f << it;
         }
         __syncthreads();
-        if (threadIdx.x == 0) base += tot;
+        // exclusive scan of the 512 (chunk, wavefront) counts in candidate order: wavefront scan (shuffles), then the 8 wavefront totals
+        int v = 0, incl = 0;
+        if (threadIdx.x < IT * 16) {
+            v = (&wave_sums[0][0])[threadIdx.x];
+            incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(incl, o); if (lane >= o) incl += t2; }
+            if (lane == 63) part[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < IT * 16) {
+            int add = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) add += (w < wave) ? part[w] : 0;
+            (&wave_sums[0][0])[threadIdx.x] = base + add + incl - v;          // position of the first kept candidate of (chunk, wavefront)
+            if (threadIdx.x == IT * 16 - 1) total_next = base + add + incl;
+        }
+        __syncthreads();
+        // the copies in groups of eight chunks: all loads of a group are issued before its first store (a load next to a store of
+        // unknown aliasing waits for it: up to 32 dependent round trips per thread otherwise)
+#pragma unroll
+        for (int g8 = 0; g8 < IT; g8 += 8) {
+            float4 bx[8]; float sc[8]; int cl[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = g8 + k;
+                const int n = n0 + it * 1024 + threadIdx.x;
+                const size_t src = (size_t)b * N + (((flags >> it) & 1u) ? n : 0);
+                bx[k] = *reinterpret_cast<const float4*>(boxes + src * 4);
+                sc[k] = scores[src];
+                cl[k] = cls[src];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = g8 + k;
+                if ((flags >> it) & 1u) {
+                    const int n = n0 + it * 1024 + threadIdx.x;
+                    const size_t dst = (size_t)b * N + wave_sums[it][wave] + before[it];
+                    *reinterpret_cast<float4*>(out_boxes + dst * 4) = bx[k];
+                    out_scores[dst] = sc[k];
+                    out_cls[dst] = cl[k];
+                    if (out_index) out_index[dst] = n;
+                }
+            }
+        }
+        __syncthreads();                                    // every thread has read this pass's positions
+        if (threadIdx.x == 0) base = total_next;
         __syncthreads();
     }
     if (threadIdx.x == 0) count[b] = base;
