@@ -722,9 +722,9 @@ def test_nms_segment_larger_than_32768(hvoc, capi):
 
 @pytest.mark.parametrize("prefilter", [0, 2])
 def test_postprocess_very_large_classes(hvoc, prefilter):
-    """Class segments above 4 160 boxes (608 x 608 with random weights: ~5 000 boxes of one class per image) go through
-    resolve_large_kernel — 512 threads, eight per matrix row, up to 129 chunks staged in registers, the generic band walk beyond —
-    while the smaller classes of the same image stay on resolve_kernel: kept sets identical to the oracle's."""
+    """Class segments above 1 024 boxes go through resolve_large_kernel — 512 threads, eight per matrix row, up to 129 chunks (8 256 boxes;
+    608 x 608 with random weights has ~5 000 of one class) staged in registers, the unstaged band walk beyond — while the smaller classes
+    of the same image stay on resolve_kernel: kept sets identical to the oracle's."""
     rs = np.random.RandomState(17)
     N, C = 14000, 20
     def image(sizes):

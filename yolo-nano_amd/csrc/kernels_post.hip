@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
 // rem[] bounds the segment size: n <= 64 * YN_RESOLVE_MAX_T = 131 072 boxes of one class (nms_max_segment(); the C ABI
 // rejects larger work before anything is launched — the suppression matrix of such a segment would be > 1 GB anyway)
 #define YN_RESOLVE_MAX_T 2048
-struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; u64 keepm; u64 keepm2[2]; int kidx[64]; int nk; };     // keepm2: band ri's kept mask in slot ri & 1 (resolve_bands)
+struct ResolveLds { u64 rem[YN_RESOLVE_MAX_T]; int pbase[YN_RESOLVE_MAX_T]; u64 keepm; u64 keepm2[2]; int kidx[64]; int nk; };     // keepm2: band ri's kept mask in slot ri & 1 (resolve_bands)
 
 // Everything a band reads from memory — its diagonal word and candidate id (wave 0), its off-diagonal words (all threads:
 // thread -> row tid/4, columns 1 + (tid&3) + 4u) — is requested TWO bands ahead, into one of three register sets: a band's own work
@@ -1033,17 +1033,22 @@ __device__ __forceinline__ void resolve_prefetch(ResolvePre<NB>& p, const int32_
     if (wave == 0) {
         p.diag = M[band_off(ri, T) + (size_t)lane * W];
         p.c1 = W > 1 ? M[band_off(ri, T) + (size_t)lane * W + 1] : 0ull;
-        p.id = (ri * 64 + lane < n) ? ids[ri * 64 + lane] : 0;
     }
+    // no per-word branches (each was a saveexec / branch region: ~40 of them per band made the walk instruction-bound at one or two
+    // wavefronts per SIMD): words past the row's end are read at a clamped column and ignored where they would be used
     const size_t boff = band_off(ri, T) + (size_t)pr * W;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int w = 1 + pc + TPR * u;
-        p.nb[u] = (w < W) ? M[boff + w] : 0ull;
+        p.nb[u] = M[boff + (w < W ? w : W - 1)];
     }
 }
 
 // wave 0: which boxes of chunk ri survive (-> L.keepm, L.kidx, L.nk; keep flags / pick list)
+// DEFER (resolve_bands): nothing goes to global memory here — on this architecture stores count in vmcnt like loads, so a keep-flag store
+// per band made every later wait for prefetched matrix words wait for that store's acknowledgement as well: ~1.8 us per band whatever
+// the look-ahead.  The kept mask replaces rem[ri] (dead once the band is resolved) and the flags / pick list are written after the walk.
+template <bool DEFER = false>
 __device__ __forceinline__ u64 resolve_diag(u64 diag, int id, int n, int ri, int lane, int picked,
                                             int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
@@ -1065,6 +1070,10 @@ __device__ __forceinline__ u64 resolve_diag(u64 diag, int id, int n, int ri, int
             work &= alive & ~(1ull << i);                                                // bits <= i of later words are zero
         }
         keepm = alive;
+    }
+    if (DEFER) {
+        if (lane == 0) { L.rem[ri] = keepm; L.pbase[ri] = picked; L.keepm2[ri & 1] = keepm; }
+        return keepm;
     }
     if ((keepm >> lane) & 1ull) {
         const int rank = __popcll(keepm & ((1ull << lane) - 1ull));
@@ -1097,13 +1106,17 @@ __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, in
     {                                                                                                        \
         const int ri = (ri_);                                                                                \
         if (wave == 0) {                                                                                     \
-            const u64 km = resolve_diag(P.diag, P.id, n, ri, lane, picked, keep_flags, pick_list, L);        \
+            const u64 km = resolve_diag<true>(P.diag, 0, n, ri, lane, picked, keep_flags, pick_list, L);     \
             picked += __popcll(km);                                                                          \
             if (((km >> lane) & 1ull) && P.c1) atomicOr(&L.rem[ri + 1], P.c1);                               \
         }                                                                                                    \
         if (ri >= 1 && ((L.keepm2[(ri - 1) & 1] >> pr) & 1ull)) {                                            \
-            _Pragma("unroll") for (int u = 0; u < NB; ++u)                                                   \
-                if (PPREV.nb[u]) atomicOr(&L.rem[ri + pc + TPR * u], PPREV.nb[u]);                           \
+            u64 any = 0;                                                                                     \
+            _Pragma("unroll") for (int u = 0; u < NB; ++u) any |= PPREV.nb[u];                               \
+            if (any) {                                       /* rare: most kept rows suppress nothing */     \
+                _Pragma("unroll") for (int u = 0; u < NB; ++u)                                               \
+                    if (pc + TPR * u > 0 && ri + pc + TPR * u < T && PPREV.nb[u]) atomicOr(&L.rem[ri + pc + TPR * u], PPREV.nb[u]); /* column 1 is wavefront 0's */ \
+            }                                                                                                \
         }                                                                                                    \
         resolve_prefetch<NB, TPR>(PPREV, ids, n, M, T, ri + 2, lane, wave, pr, pc);                          \
         __syncthreads();                                                                                     \
@@ -1116,21 +1129,42 @@ __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, in
 #undef YN_BAND
     if (tid == 0) L.nk = picked;
     __syncthreads();
+    // rem[ri] now holds band ri's kept mask: the keep flags / the pick list (np order: score-descending inside the class) in one coalesced pass
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int ri = i >> 6, l = i & 63;
+        const u64 km = L.rem[ri];
+        if ((km >> l) & 1ull) {
+            const int id = ids[i];
+            if (keep_flags) keep_flags[id] = 1;
+            if (pick_list) pick_list[L.pbase[ri] + __popcll(km & ((1ull << l) - 1ull))] = id;
+        }
+    }
     return L.nk;
 }
 
+// MODE selects the staged walks a kernel instantiates (its register count is the largest one's): 0 = 256 threads, T <= 17 only
+// (resolve_kernel: segments up to 1 024 boxes); 1 = 512 threads, eight per matrix row, up to 129 chunks (resolve_large_kernel); 2 = 256
+// threads, up to 65 chunks (single_resolve_kernel).  Anything larger takes the unstaged loop below.
+template <int MODE>
 __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
                                                int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int T = (n + 63) >> 6;
     for (int w = tid; w < T; w += nthr) L.rem[w] = 0;
-    if (nthr == 256) {                                      // the band words of a row fit four threads' register sets
+    if (MODE == 0 && nthr == 256) {
+        if (T <= 17) return resolve_bands<4>(ids, n, M, keep_flags, pick_list, L);
+    }
+    if (MODE == 2 && nthr == 256) {                         // the band words of a row fit four threads' register sets
         if (T <= 17) return resolve_bands<4>(ids, n, M, keep_flags, pick_list, L);
         if (T <= 33) return resolve_bands<8>(ids, n, M, keep_flags, pick_list, L);
         if (T <= 65) return resolve_bands<16>(ids, n, M, keep_flags, pick_list, L);
     }
-    if (nthr == 512 && T <= 129) return resolve_bands<16, 8>(ids, n, M, keep_flags, pick_list, L);     // resolve_large_kernel: eight threads per row
+    if (MODE == 1 && nthr == 512) {                         // eight threads per matrix row: 129 chunks (8 256 boxes) in the staged walk
+        if (T <= 33) return resolve_bands<4, 8>(ids, n, M, keep_flags, pick_list, L);
+        if (T <= 65) return resolve_bands<8, 8>(ids, n, M, keep_flags, pick_list, L);
+        if (T <= 129) return resolve_bands<16, 8>(ids, n, M, keep_flags, pick_list, L);
+    }
     // very large segments (n > 4160): no register staging, the kept rows' words are read when they are needed
     u64 diag_next = 0;
     int id_next = 0;
@@ -1175,19 +1209,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict_
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
     if (n == 0 || n > n_max) return;                        // n > n_max: resolve_large_kernel's
-    resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
+    resolve_segment<0>(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
                     M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
 
-// Segments above YN_RESOLVE_SPLIT boxes (more than 65 chunks: the register-staged band walk of a 256-thread workgroup ends there, and the
-// generic loop behind it reads every kept row's words when it needs them — 352 us at 608 x 608, where random weights put ~5 000 boxes into
-// one class): a 512-thread workgroup, eight threads per matrix row, covers 129 chunks with the same staged walk.  grid.x indexes the image's
-// list of large segments (bucket_kernel's, n > 1024 before the prefilter).
-#define YN_RESOLVE_SPLIT 4160
+// The segments of bucket_kernel's large list (more than 1 024 boxes before the prefilter) that still hold more than YN_SORT_SMALL boxes:
+// ONE launch of 512-thread workgroups, eight threads per matrix row, so that the few long walks of an image run side by side (a
+// 256-thread walk up to 65 chunks followed by a second kernel for the larger ones ran the two longest walks of a 608 x 608 image one
+// after the other: 155 us for 65 + 83 bands) and resolve_kernel — 2 560 mostly tiny segments at bs 32 — only carries the registers of
+// the shortest staged walk.
 __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                              const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep,
-                                                             const int32_t* __restrict__ large_list, int large_cap)
+                                                             const int32_t* __restrict__ large_list, int large_cap, int n_min)
 {
     __shared__ ResolveLds L;
     const int b = blockIdx.y;
@@ -1195,9 +1229,9 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
     if ((int)blockIdx.x >= ll[0]) return;
     const int c = ll[1 + blockIdx.x];
     const int n = seg_count[(size_t)b * C + c];
-    if (n <= YN_RESOLVE_SPLIT) return;
-    resolve_segment(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
-                    M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
+    if (n <= n_min) return;
+    resolve_segment<1>(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
+                       M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
 
 // ---- first-chunk prefilter ---------------------------------------------------------------------------------------------------------
@@ -1336,7 +1370,7 @@ __global__ __launch_bounds__(256) void single_resolve_kernel(const int32_t* __re
                                                               int32_t* __restrict__ pick_list, int32_t* __restrict__ count)
 {
     __shared__ ResolveLds L;
-    const int picked = n > 0 ? resolve_segment(ids, n, M, nullptr, pick_list, L) : 0;
+    const int picked = n > 0 ? resolve_segment<2>(ids, n, M, nullptr, pick_list, L) : 0;
     if (threadIdx.x == 0) *count = picked;
 }
 
@@ -1531,12 +1565,12 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
     else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
     mark("resolve_kernel");
-    const bool split = N > YN_RESOLVE_SPLIT && wk.large_list && large_cap > 0;
+    const bool split = N > YN_SORT_SMALL && wk.large_list && large_cap > 0;
     if (!(skip & 4)) {
         hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
-                           split ? YN_RESOLVE_SPLIT : 1 << 30);
+                           split ? YN_SORT_SMALL : 1 << 30);
         if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
-                                      wk.keep, (const int32_t*)wk.large_list, large_cap);
+                                      wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
     mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
