@@ -169,7 +169,7 @@ def preprocess_bench(args, rank, world, dev, dist):
     us = e0.elapsed_time(e1) * 1e3 / args.steps / ((B + 31) // 32)         # HIP events over the timed region: per launch (32 images)
     alg = min(B, 32) * (h0 * w0 * 3 + 3 * S * S * 4)                       # source frames read once (u8) + the float tensors written
     if rank == 0:
-        print(json.dumps({"metric": "images/sec ValTransforms %dx%d -> %dx%d (device preprocess)" % (w0, h0, S, S),
+        emit({"metric": "images/sec ValTransforms %dx%d -> %dx%d (device preprocess)" % (w0, h0, S, S),
                           "value": round(world * B * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32", "data": "synthetic",
@@ -177,7 +177,7 @@ def preprocess_bench(args, rank, world, dev, dist):
                           "roofline": {"kernel": "preprocess_batch_kernel", "bound": "hbm", "achieved": round(alg / us / 1e3, 1), "peak": PEAK_HBM_GBS,
                                        "unit": "GB/s", "frac": round(alg / us / 1e3 / PEAK_HBM_GBS, 4), "traffic": None,
                                        "alg_bytes_per_launch": alg, "avg_us": round(us, 2)},
-                          "cpu_baseline": None}), flush=True)
+                          "cpu_baseline": None})
     hd.close()
 
 
@@ -377,12 +377,35 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+_RESULT_FD = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL's version banner, Gloo's connection chatter — C-level
+    writes to fd 1): from here on fd 1 IS stderr for everybody, and the result line goes to the saved descriptor (emit)."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        os.write(1, data)
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if not os.environ.get("YN_BENCH_ONE_GPU") and torch.cuda.device_count() < args.gpus:     # device_count() does not initialise the GPU
             raise SystemExit("bench.py --gpus %d: only %d GPUs visible" % (args.gpus, torch.cuda.device_count()))
         raise SystemExit(spawn_ranks(args))
+    quiet_stdout()
     from yolo_nano_amd import arch, capi, parallel, weights
     rank, local_rank, world = parallel.env_rank()
     if world != args.gpus:
@@ -407,7 +430,7 @@ def main():
     if args.train:
         line = train_bench(args, rank, world, dev, dist, args.dtype)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit(line)
         return finish()
 
     B, S = args.batch, args.size
@@ -433,12 +456,12 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
         if rank == 0:
-            print(json.dumps({"metric": "p50 latency YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
+            emit({"metric": "p50 latency YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS)" % (args.backbone, S, S, B),
                               "value": round(lat[len(lat) // 2], 4), "unit": "ms", "p99_ms": round(lat[int(len(lat) * 0.99)], 4),
                               "min_ms": round(lat[0], 4), "n_gpus": world, "steps": args.latency, "warmup": max(args.warmup, 50),
                               "higher_is_better": False, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
                               "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d fp32, folded BN, %s, conf %.3g nms %.2f"
-                                                     % (args.backbone, S, S, B, "hipGraph replay" if use_graph else "eager launches", args.conf, args.nms), "hipgraph": bool(use_graph)}}), flush=True)
+                                                     % (args.backbone, S, S, B, "hipGraph replay" if use_graph else "eager launches", args.conf, args.nms), "hipgraph": bool(use_graph)}})
         rig.close()
         return finish()
 
@@ -621,7 +644,7 @@ def main():
             "extras": extras,
             "kernels": kernels,
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     finish()
 
 
