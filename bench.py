@@ -28,7 +28,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
 PEAK_SPLIT_TFLOPS = 2500.0 / 3  # split-f16 kernels: three f16 MFMAs (2.5 PF dense) per fp32 product => 833 TFLOP/s of fp32-class work
-PMC_LAYERS_FILE = "r02_pmc_layers.json"
+PMC_LAYERS_FILES = ("r03_pmc_layers.json", "r03_pmc_layers_608_bs32.json", "r03_pmc_layers_05x_bs128.json", "r02_pmc_layers.json")
 
 
 def source_hash():
@@ -84,6 +84,10 @@ def parse():
                          "f16 MFMA with fp32 accumulation, fp32 master weights, loss scaling; f32 = the reference's own arithmetic)")
     ap.add_argument("--no-extras", action="store_true",
                     help="default run: skip the extra witnessed workloads (single stream, 608x608 bs=32, 0.5x bs=128, the training steps)")
+    ap.add_argument("--latency-calls", type=int, default=1000, help="synchronous bs=1 calls per entry of the latency_bs1 block (after 50 warm-up calls)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="always go through the rank launcher (probe -> child torch.distributed.run), also for --gpus 1, and build the "
+                         "process group even at world size 1: the N-GPU code path, RCCL included, on a one-GPU box")
     ap.add_argument("--latency", type=int, default=0, metavar="N",
                     help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
@@ -219,8 +223,24 @@ def train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
     for _ in range(args.steps):
         losses = step()
     sync_all()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    mine = time.perf_counter() - t0
+    rank_seconds = parallel.all_ranks(mine, dev)
+    elapsed = parallel.max_over_ranks(mine, dev)
     lv = [float(v) for v in losses.tolist()]
+    # the gradient exchange on its own: the flat bucket through the process group's all-reduce (RCCL), HIP events on the launch stream
+    allreduce_us = None
+    if dist is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        keep = h.flat_grads.clone()
+        for _ in range(3):
+            dist.all_reduce(h.flat_grads, op=dist.ReduceOp.SUM)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(h.flat_grads, op=dist.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        allreduce_us = round(e0.elapsed_time(e1) * 1e3 / 20, 1)
+        h.flat_grads.copy_(keep)
     assign = None
     if rank == 0 and not brief:                              # the label assigner alone, and the CPU restatement of the reference beside it
         torch.cuda.synchronize(dev)
@@ -245,13 +265,92 @@ def train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
                                "loss, backward, SGD(0.9, 5e-4), label assignment on the device; %d-class head (BASELINE configs[2])"
                                % (args.backbone, S, S, B, prec, args.classes),
                    "global_batch": world * B, "parameters": n_param, "rccl_ranks": world,
+                   "process_group": (dist.get_backend() if dist is not None else None),
+                   "allreduce_us_per_step": allreduce_us, "allreduce_bytes": n_param * 4,
+                   "per_rank_images_per_s": [round(B * args.steps / t, 1) for t in rank_seconds],
                    "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
         "label_assigner": assign,
         "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}
     h.close()
     if brief:
-        return {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite")}
+        out = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite")}
+        out["allreduce_us_per_step"] = allreduce_us
+        out["per_rank_images_per_s"] = line["config"]["per_rank_images_per_s"]
+        return out
     return line
+
+
+SPLIT_KERNELS = ("head_decode", "head_tail", "down_unit", "dwpw", "head_tower")      # besides every symbol with "split" in its name
+
+
+def is_split_kernel(kern):
+    return "split" in kern or kern.startswith(SPLIT_KERNELS)
+
+
+def live_rooflines(h, x, out, stream, nsteps, workload_key):
+    """Per-kernel durations of `nsteps` eager yn_infer calls, measured live with HIP events on the launch stream (yn_profile_*),
+    priced against the kernel's roofline: -> (roofline of the dominant symbol, per-symbol table, whole-pipeline floors, last call's
+    launch records).  achieved = ALGORITHMIC bytes (or flops) per launch / average launch duration."""
+    agg, recs = {}, []
+    for _ in range(nsteps):
+        h.profile_enable(True)                 # resets the record list
+        h.infer(x, out)
+        stream.synchronize()
+        recs = h.profile_records()
+        for layer, kern, ms, fl, by in recs:
+            a = agg.setdefault(kern, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            a["ms"] += ms; a["launches"] += 1; a["flops"] += fl; a["bytes"] += by
+    h.profile_enable(False)
+    kernels = []
+    ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    tot_ms = sum(a["ms"] for a in agg.values())
+    for kern, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        n = a["launches"]
+        avg_ms = a["ms"] / n
+        ai = a["flops"] / max(a["bytes"], 1.0)
+        split = is_split_kernel(kern)              # f16 MFMA with split fp32 operands: never MFMA-bound at these shapes
+        bound = "mfma" if (ai > ridge and not split) else "hbm"
+        if ai > PEAK_SPLIT_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+            bound = "mfma"
+        if bound == "mfma":
+            ach, peak, unit = a["flops"] / n / (avg_ms * 1e-3) / 1e12, (PEAK_SPLIT_TFLOPS if split else PEAK_F32_TFLOPS), "TFLOP/s"
+        else:
+            ach, peak, unit = a["bytes"] / n / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        kernels.append({"kernel": kern, "launches_per_step": n // nsteps, "avg_us": round(avg_ms * 1e3, 2),
+                        "share": round(a["ms"] / tot_ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
+                        "unit": unit, "frac": round(ach / peak, 4)})
+    d = kernels[0]
+    # HBM bytes per launch of the dominant symbol, from the committed per-LAYER PMC pass ((2*FETCH_SIZE + WRITE_SIZE) KiB,
+    # joined on the launch order of one call: the symbol a layer runs under is autotuned).  PMC counters need rocprofv3
+    # around the process, so they cannot be taken inside this run; the file is stamped with the hash of the kernel
+    # sources it was measured on and is ignored (traffic = null) when the sources have changed since.
+    traffic, traffic_src = None, None
+    for fname in PMC_LAYERS_FILES:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            if pmc["_meta"]["workload"] == workload_key and pmc["_meta"].get("source_hash") == source_hash():
+                per = [pmc["%d:%s" % (i, layer)]["hbm_bytes"] for i, (layer, kern, ms, fl, by) in enumerate(recs) if kern == d["kernel"]]
+                traffic = round(sum(per) / len(per)) if per else None
+                traffic_src = "profiles/" + fname
+                break
+        except Exception:
+            traffic = None
+    roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+            "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
+            "alg_bytes_per_launch": round(agg[d["kernel"]]["bytes"] / agg[d["kernel"]]["launches"]),
+            "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
+            "avg_us": d["avg_us"], "share_of_step": d["share"], "launches_per_step": len(recs)}
+    fl = sum(a["flops"] for a in agg.values()) / nsteps
+    fl_split = sum(a["flops"] for k, a in agg.items() if is_split_kernel(k)) / nsteps
+    by = sum(a["bytes"] for a in agg.values()) / nsteps
+    # matrix-pipe time: the split-f16 kernels at 833 TFLOP/s of fp32-class work, everything else at the f32-MFMA peak
+    mfma_ms = ((fl - fl_split) / (PEAK_F32_TFLOPS * 1e12) + fl_split / (PEAK_SPLIT_TFLOPS * 1e12)) * 1e3
+    floor_ms = max(mfma_ms, by / (PEAK_HBM_GBS * 1e9) * 1e3)
+    pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_gflop_on_split_f16_kernels": round(fl_split / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
+                "mfma_floor_ms": round(mfma_ms, 4), "hbm_floor_ms": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                "f32_mfma_only_floor_ms": round(fl / (PEAK_F32_TFLOPS * 1e12) * 1e3, 4),
+                "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / nsteps, 4), "launches_per_step": len(recs)}
+    return roof, kernels, pipeline, recs
 
 
 class InferRig:
@@ -330,6 +429,29 @@ class InferRig:
             hk.close()
 
 
+def build_rig(args, dev, rank, world, dist, *a, **kw):
+    """InferRig for every rank of the job with ONE autotune pass: rank 0 builds its rig, runs the untimed eager pass that times the
+    tile configurations of every layer shape, writes the table (yn_tune_save); the other ranks adopt it (yn_tune_load) before they
+    build theirs.  Identical GPUs and shapes: eight ranks timing the same shapes at once only perturbs each other's brackets, and
+    replicas on different tiles make the slowest rank the job's time.  (One rank: plain construction.)"""
+    from yolo_nano_amd import capi
+    if dist is None or world < 2:
+        return InferRig(args, dev, rank, *a, **kw)
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "yn_tune_%s_%s.txt" % (source_hash(), os.environ.get("MASTER_PORT", "0")))
+    if rank != 0:
+        dist.barrier()
+        capi.tune_load(path, dev.index)
+        return InferRig(args, dev, rank, *a, **kw)
+    rig = InferRig(args, dev, rank, *a, **kw)
+    for _ in range(rig.ns):
+        rig.step()
+    rig.drain()
+    capi.tune_save(path, dev.index)
+    dist.barrier()
+    return rig
+
+
 def timed_infer(rig, steps, warmup, dev, dist):
     from yolo_nano_amd import parallel
 
@@ -346,18 +468,61 @@ def timed_infer(rig, steps, warmup, dev, dist):
     for _ in range(steps):
         rig.step()
     sync_all()                                           # includes the last steps' record copies
-    return parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    mine = time.perf_counter() - t0
+    rig.rank_seconds = parallel.all_ranks(mine, dev)     # every rank's own time for the same region (the headline uses the MAX)
+    return parallel.max_over_ranks(mine, dev)
 
 
-def side_workload(args, dev, rank, world, dist, S, B, backbone, steps, warmup, ns):
-    """A further named workload measured the same way as the headline one (host delivery included): -> dict."""
-    rig = InferRig(args, dev, rank, S, B, backbone, ns, False)
+def side_workload(args, dev, rank, world, dist, S, B, backbone, steps, warmup, ns, exact=False):
+    """A further named workload measured the same way as the headline one (host delivery included), with its own roofline blocks:
+    the dominant kernel of THAT workload and the whole-pipeline floor, from HIP events on rank 0 after the timed region.  -> dict.
+    exact: every GEMM-shaped conv on the f32 MFMA (yn_exact_f32) instead of the split-f16 family."""
+    rig = build_rig(args, dev, rank, world, dist, S, B, backbone, ns, False)
+    if exact:
+        for hk in rig.handles:
+            hk.exact_f32(True)
     el = timed_infer(rig, steps, warmup, dev, dist)
-    out = {"images_per_s": round(world * B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "streams_per_gpu": ns,
+    ms = el / steps * 1e3
+    out = {"images_per_s": round(world * B * steps / el, 1), "ms_per_step": round(ms, 4), "steps": steps, "streams_per_gpu": ns,
            "detections_per_step_rank0": rig.delivered // steps,
-           "workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference + NMS + host delivery" % (backbone, S, S, B)}
+           "workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference + NMS + host delivery%s" % (backbone, S, S, B, " (yn_exact_f32: f32 MFMA only)" if exact else "")}
+    if rank == 0:
+        with torch.cuda.stream(rig.streams[0]):
+            roof, kernels, pipeline, _ = live_rooflines(rig.handles[0], rig.xs[0], rig.outs[0], rig.streams[0], 3,
+                                                        "%s %dx%d bs=%d C=%d conf %.3g" % (backbone, S, S, B, args.classes, args.conf))
+        out["roofline"] = roof
+        out["pipeline"] = dict(pipeline, frac_of_floor=round(pipeline["roofline_floor_ms"] / ms, 4))
+        out["kernels_top5"] = kernels[:5]
+        dwk = [k for k in kernels if k["kernel"].startswith("dwconv3x3")]
+        if dwk:
+            out["depthwise_kernels"] = dwk                   # BASELINE configs[3]: "depthwise-bound, HBM roofline check"
     rig.close()
     return out
+
+
+def visible_gpu_count():
+    """How many GPUs this job could use, WITHOUT touching HIP (the parent must stay GPU-free: it starts the ranks as a child):
+    KFD topology nodes that have SIMDs (CPU nodes report simd_count 0), narrowed by the *_VISIBLE_DEVICES lists.
+    None when sysfs is not readable (then there is no pre-check and the ranks fail loudly themselves)."""
+    import glob
+    n, seen = 0, False
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            txt = open(path).read()
+        except OSError:
+            continue
+        seen = True
+        for ln in txt.splitlines():
+            f = ln.split()
+            if len(f) == 2 and f[0] == "simd_count" and f[1].isdigit() and int(f[1]) > 0:
+                n += 1
+    if not seen:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip():
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
 
 
 def spawn_ranks(args):
@@ -374,6 +539,8 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", "4")
+    if args.spawn:
+        env["YN_BENCH_FORCE_DIST"] = "1"                    # a 1-rank job still builds its process group: RCCL at world 1
     return subprocess.call(cmd, env=env)
 
 
@@ -401,9 +568,10 @@ def emit(obj):
 
 def main():
     args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if not os.environ.get("YN_BENCH_ONE_GPU") and torch.cuda.device_count() < args.gpus:     # device_count() does not initialise the GPU
-            raise SystemExit("bench.py --gpus %d: only %d GPUs visible" % (args.gpus, torch.cuda.device_count()))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        have = visible_gpu_count()                          # sysfs / environment only: this process never initialises HIP
+        if not os.environ.get("YN_BENCH_ONE_GPU") and have is not None and have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPUs visible" % (args.gpus, have))
         raise SystemExit(spawn_ranks(args))
     quiet_stdout()
     from yolo_nano_amd import arch, capi, parallel, weights
@@ -417,8 +585,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("YN_BENCH_BACKEND", "nccl")
-    parallel.init(backend, dev)                              # RCCL; inference uses it only for the barrier / max-over-ranks
-    dist = torch.distributed if world > 1 else None
+    force_dist = bool(os.environ.get("YN_BENCH_FORCE_DIST"))
+    parallel.init(backend, dev, force=force_dist)            # RCCL; inference uses it only for the barrier / max-over-ranks
+    dist = torch.distributed if (world > 1 or force_dist) else None
 
     def finish():
         if dist is not None:
@@ -439,7 +608,7 @@ def main():
     if args.latency > 0 and mode == "auto":
         mode = "eager"
     use_graph = mode == "graph"
-    rig = InferRig(args, dev, rank, S, B, args.backbone, ns, use_graph, deliver=args.latency == 0)
+    rig = build_rig(args, dev, rank, world, dist, S, B, args.backbone, ns, use_graph, deliver=args.latency == 0)
     sd, anchors = rig.sd, rig.anchors
     stream, h, x, out = rig.streams[0], rig.handles[0], rig.xs[0], rig.outs[0]
 
@@ -482,6 +651,7 @@ def main():
         calib = {"eager_steps_per_s": round(r_e, 1), "graph_steps_per_s": round(r_g, 1)}
         rig.use_graph(use_graph)
     elapsed = timed_infer(rig, args.steps, args.warmup, dev, dist)
+    rank_seconds = list(rig.rank_seconds)
     kept = rig.delivered // max(1, args.steps)
 
     # the same step without the host delivery (detections stay in HBM; only the 32 counts cross PCIe): the round-1 definition
@@ -505,17 +675,8 @@ def main():
     with torch.cuda.stream(stream):
         if rank == 0:
             h.use_graph(False)
-            h.profile_enable(True)
-            agg = {}
-            for _ in range(args.profile_steps):
-                h.profile_enable(True)                 # resets the record list
-                h.infer(x, out)
-                stream.synchronize()
-                recs = h.profile_records()
-                for layer, kern, ms, fl, by in recs:
-                    a = agg.setdefault(kern, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-                    a["ms"] += ms; a["launches"] += 1; a["flops"] += fl; a["bytes"] += by
-            h.profile_enable(False)
+            roof, kernels, pipeline, recs = live_rooflines(h, x, out, stream, args.profile_steps,
+                                                           "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf))
             if args.layers:
                 for layer, kern, ms, fl, by in recs:
                     print("%-28s %-28s %8.1f us  %7.2f GFLOP %7.1f MB  %6.1f TF/s %7.1f GB/s" % (
@@ -524,54 +685,6 @@ def main():
                 json.dump([{"layer": layer, "kernel": kern, "flops": fl, "bytes": by, "source_hash": source_hash(),
                             "workload": "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf)}
                            for layer, kern, ms, fl, by in recs], open(args.dump_layers, "w"), indent=1)
-            ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            tot_ms = sum(a["ms"] for a in agg.values())
-            for kern, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-                n = a["launches"]
-                avg_ms = a["ms"] / n
-                ai = a["flops"] / max(a["bytes"], 1.0)
-                split = "split" in kern or kern.startswith(("head_decode", "head_tail", "down_unit", "dwpw"))   # f16 MFMA with split fp32 operands: never MFMA-bound at these shapes
-                bound = "mfma" if (ai > ridge and not split) else "hbm"
-                if ai > PEAK_SPLIT_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-                    bound = "mfma"
-                if bound == "mfma":
-                    ach, peak, unit = a["flops"] / n / (avg_ms * 1e-3) / 1e12, (PEAK_SPLIT_TFLOPS if split else PEAK_F32_TFLOPS), "TFLOP/s"
-                else:
-                    ach, peak, unit = a["bytes"] / n / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-                kernels.append({"kernel": kern, "launches_per_step": n // args.profile_steps, "avg_us": round(avg_ms * 1e3, 2),
-                                "share": round(a["ms"] / tot_ms, 4), "bound": bound, "achieved": round(ach, 2), "peak": peak,
-                                "unit": unit, "frac": round(ach / peak, 4)})
-            d = kernels[0]
-            # HBM bytes per launch of the dominant symbol, from the committed per-LAYER PMC pass ((2*FETCH_SIZE + WRITE_SIZE) KiB,
-            # joined on the launch order of one call: the symbol a layer runs under is autotuned).  PMC counters need rocprofv3
-            # around the process, so they cannot be taken inside this run; the file is stamped with the hash of the kernel
-            # sources it was measured on and is ignored (traffic = null) when the sources have changed since.
-            traffic, traffic_src = None, None
-            try:
-                pf = os.path.join(ROOT, "profiles", PMC_LAYERS_FILE)
-                pmc = json.load(open(pf))
-                if (pmc["_meta"]["workload"] == "%s %dx%d bs=%d C=%d conf %.3g" % (args.backbone, S, S, B, args.classes, args.conf)
-                        and pmc["_meta"].get("source_hash") == source_hash()):
-                    per = [pmc["%d:%s" % (i, layer)]["hbm_bytes"] for i, (layer, kern, ms, fl, by) in enumerate(recs) if kern == d["kernel"]]
-                    traffic = round(sum(per) / len(per)) if per else None
-                    traffic_src = "profiles/" + PMC_LAYERS_FILE
-            except Exception:
-                traffic = None
-            roof = {"kernel": d["kernel"], "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                    "alg_bytes_per_launch": round(agg[d["kernel"]]["bytes"] / agg[d["kernel"]]["launches"]),
-                    "alg_flops_per_launch": round(agg[d["kernel"]]["flops"] / agg[d["kernel"]]["launches"]),
-                    "avg_us": d["avg_us"], "share_of_step": d["share"]}
-            fl = sum(a["flops"] for a in agg.values()) / args.profile_steps
-            fl_split = sum(a["flops"] for k, a in agg.items() if "split" in k or k.startswith(("head_decode", "head_tail", "down_unit", "dwpw"))) / args.profile_steps
-            by = sum(a["bytes"] for a in agg.values()) / args.profile_steps
-            # matrix-pipe time: the split-f16 kernels at 833 TFLOP/s of fp32-class work, everything else at the f32-MFMA peak
-            mfma_ms = ((fl - fl_split) / (PEAK_F32_TFLOPS * 1e12) + fl_split / (PEAK_SPLIT_TFLOPS * 1e12)) * 1e3
-            floor_ms = max(mfma_ms, by / (PEAK_HBM_GBS * 1e9) * 1e3)
-            pipeline = {"alg_gflop_per_step": round(fl / 1e9, 2), "alg_gflop_on_split_f16_kernels": round(fl_split / 1e9, 2), "alg_mb_per_step": round(by / 1e6, 1),
-                        "mfma_floor_ms": round(mfma_ms, 4), "hbm_floor_ms": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
-                        "f32_mfma_only_floor_ms": round(fl / (PEAK_F32_TFLOPS * 1e12) * 1e3, 4),
-                        "roofline_floor_ms": round(floor_ms, 4), "sum_kernel_ms": round(tot_ms / args.profile_steps, 4)}
 
         # ---- the second half of BASELINE's metric: p50 latency at bs=1 (rank 0, after the timed region; benchmark.py:62-75 protocol:
         #      launch, wait for the device, repeat), at the bench resolution and at BASELINE config 5's 608x608 (eager and hipGraph)
@@ -588,17 +701,17 @@ def main():
                 ent = {}
                 for tag, g in (("eager", False), ("hipgraph", True)):
                     hl.use_graph(g)
-                    for _ in range(60):
+                    for _ in range(50):                      # >= 1000 synchronous calls after 50 warm-up
                         hl.infer(xl, ol)
                     stream.synchronize()
                     lat = []
-                    for _ in range(300):
+                    for _ in range(args.latency_calls):
                         t1 = time.perf_counter()
                         hl.infer(xl, ol)
                         stream.synchronize()
                         lat.append((time.perf_counter() - t1) * 1e3)
                     lat.sort()
-                    ent[tag] = {"p50_ms": round(lat[len(lat) // 2], 4), "p99_ms": round(lat[int(len(lat) * 0.99)], 4), "calls": len(lat)}
+                    ent[tag] = {"p50_ms": round(lat[len(lat) // 2], 4), "p99_ms": round(lat[int(len(lat) * 0.99)], 4), "calls": len(lat), "warmup": 50}
                 latency["%dx%d" % (LS, LS)] = ent
                 hl.close()
     rig.use_graph(False)
@@ -612,6 +725,7 @@ def main():
             extras["infer_608_bs32"] = side_workload(args, dev, rank, world, dist, 608, 32, "1.0x", 60, 24, ns)                 # north_star: "416x416 and 608x608"
         if (S, B, args.backbone) != (416, 128, "0.5x"):
             extras["infer_0.5x_416_bs128"] = side_workload(args, dev, rank, world, dist, 416, 128, "0.5x", 60, 24, ns)          # BASELINE configs[3]
+        extras["infer_exact_f32_%s_%d_bs%d" % (args.backbone, S, B)] = side_workload(args, dev, rank, world, dist, S, B, args.backbone, 40, 12, ns, exact=True)   # the headline workload on the f32 MFMA only
         targs = argparse.Namespace(**vars(args))
         targs.size, targs.batch, targs.steps, targs.warmup, targs.backbone = 608, 32, 12, 3, "1.0x"
         for dt in ("f16", "f32"):                                                                                               # BASELINE configs[2]
@@ -627,11 +741,16 @@ def main():
             "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS + host delivery)" % (args.backbone, S, S, B),
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (split-f16 MFMA x3, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1]); inputs resident in HBM, "
                                    "kept detections delivered to pinned host memory inside the timed region" % (args.backbone, S, S, B, args.classes),
+                       "arithmetic": "fp32 storage and fp32 accumulation everywhere; the GEMM-shaped convs multiply on the f16 MFMA with every fp32 operand split "
+                                     "x = hi + lo*2^-11 (three MFMAs per product, error <= ~3*2^-22 per product: measured closer to float64 than the f32 MFMA; "
+                                     "operands must stay below 65504 - checked on the device, yn_range_status); depthwise / stem / decode / NMS in plain fp32. "
+                                     "extras.infer_exact_f32_* is the same workload on the f32 MFMA only (yn_exact_f32)",
                        "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
-                       "parallelism": "image-sharded x%d, no collective" % world, "rccl_ranks": world, "backend": backend if world > 1 else None,
+                       "parallelism": "image-sharded x%d, no collective" % world, "rccl_ranks": world, "backend": backend if dist is not None else None,
+                       "per_rank_images_per_s": [round(B * args.steps / t, 1) for t in rank_seconds],
                        "hipgraph": bool(use_graph), "launch_mode": mode, "launch_calibration_rank0": calib,
                        "streams_per_gpu": ns, "ms_per_step_is": "inverse throughput with %d batches in flight per GPU" % ns,
                        "detections_per_step_rank0": kept},

@@ -68,6 +68,17 @@ int  yn_multi_stream(yn_handle* h, int enable);
  * x = hi + lo*2^-11, three f16 MFMAs per product into fp32 accumulators: fp32-class results (per-product error <= ~3*2^-22; the
  * f32 MFMA of gfx950 runs at 1/16 of the f16 rate and there is no TF32).  enable != 0 pins every conv to the f32 MFMA. */
 int  yn_exact_f32(yn_handle* h, int enable);
+/* RANGE of the split-f16 family, and its guard.  hi = (f16)x is finite only for |x| < 65520, so the default path needs every folded
+ * GEMM weight and every activation that enters a GEMM-shaped conv below 65504 (normalised inputs, BatchNorm-folded weights and the
+ * activations they produce are O(1)..O(100); the reference's fp32 has no such limit).  Checked, not assumed:
+ *   - weights: yn_fold_bn tests every folded pointwise / dense-3x3 weight on the device; if one is >= 65504 (or not finite) the handle
+ *     runs the f32-MFMA family from then on, exactly as under yn_exact_f32(1)  (*weights_exceed_f16 = 1);
+ *   - activations: every kernel that splits activations tracks the largest |x| it split and raises a flag in HBM when it reached
+ *     65504; *activation_overflow returns that flag for everything issued since the last call and clears it.  The call synchronises
+ *     the handle's stream.  A set flag means the results of those calls are NOT valid: re-run them after yn_exact_f32(h, 1)
+ *     (the host shim yolo_nano_amd.YOLONano does this by itself, once, and stays on the f32-MFMA family).
+ * Tiny values need no guard: below the f16 normal range lo = (x - hi) * 2^11 still carries x. */
+int  yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow);
 /* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's
  * candidates (:308-330, 362-367) run as ONE kernel, so the raw head tensors are neither written nor re-read (default on; needs
  * the split-f16 family and A(5+C) <= 256, otherwise yn_infer runs head GEMM + decode kernel as before).  Outputs are bit-identical
@@ -100,6 +111,11 @@ int  yn_autotune(yn_handle* h, int enable);
 /* Testing aid: pin every pointwise GEMM of this handle to tile configuration `index` (0 <= index < yn_pw_config_count();
  * a configuration that does not cover a layer's strides falls back to the heuristic one); index < 0 restores the autotuner. */
 int  yn_set_pw_config(yn_handle* h, int index);
+/* The process-wide autotune table (layer shape -> tile configuration) of `device` to / from a small text file, the device ordinal
+ * left out: the ranks of a multi-GPU job adopt ONE rank's choices instead of each timing the same shapes at once (bench.py).
+ * yn_tune_load returns the number of entries adopted (existing ones are kept), -1 if the file cannot be read. */
+int  yn_tune_save(const char* path, int device);
+int  yn_tune_load(const char* path, int device);
 int  yn_pw_config_count(void);
 /* Configurations [0, yn_pw_f32_config_count()) are the f32-MFMA family (LDS-tiled, then register-direct), the rest the split-f16
  * family (gemm_split_kernel); results are bit-identical INSIDE a family. */
@@ -248,6 +264,13 @@ int  yn_train_bind(yn_handle* h, float* params_dev, float* grads_dev, float* mom
 int  yn_train_step(yn_handle* h, const float* x_dev, const float* target_dev, int B, float lr, float momentum,
                    float weight_decay, float grad_scale, int do_update, float* losses_dev);
 int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_t numel);
+/* The gradient exchange of the data-parallel step (train.py:13-14 imports DistributedDataParallel; BASELINE configs[2]: "DDP grad
+ * all-reduce over xGMI") for callers WITHOUT torch: all-reduce(sum), in place, of the bound flat gradient buffer over an RCCL
+ * communicator the caller owns (`nccl_comm` is an ncclComm_t), enqueued on the handle's stream — after yn_train_step(do_update = 0),
+ * before yn_sgd_step(grad_scale = 1/world).  One 5.3 MB bucket per step: no bucketing, no overlap needed at this model size.
+ * The library does not link RCCL: ncclAllReduce is resolved at run time from the librccl already loaded in the process (the one
+ * that created the communicator), else from librccl.so.1.  torch users keep torch.distributed (parallel.dp_train_step). */
+int  yn_allreduce_grads(yn_handle* h, void* nccl_comm);
 /* The forward half of yn_train_step on its own — `model.train(); model.backbone/neck/heads(x)` (models/yolo_nano.py:284-301 with
  * BatchNorm batch statistics; the running statistics ARE updated) in the precision selected by yn_train_precision: the three
  * raw NHWC head tensors as dense float32 [B,S/8,S/8,A(5+C)], [B,S/16,..], [B,S/32,..].  Parity hook for the train-mode network. */

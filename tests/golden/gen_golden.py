@@ -337,6 +337,9 @@ def gen_nms():
         a["pp_%s_boxes" % k], a["pp_%s_conf" % k] = boxes, conf
         a["pp_%s_out_boxes" % k], a["pp_%s_out_scores" % k] = bb, ss
         a["pp_%s_out_cls" % k] = np.asarray(cc, dtype=np.int64)
+        bb, ss, cc = md.postprocess(boxes, conf)           # the diou_nms=True model: postprocess with nms_processor = diou_nms (models/yolo_nano.py:21,265-272)
+        a["ppd_%s_out_boxes" % k], a["ppd_%s_out_scores" % k] = bb, ss
+        a["ppd_%s_out_cls" % k] = np.asarray(cc, dtype=np.int64)
     a["pp_cases"] = np.array(sorted(pcases))
     a["conf_thresh"], a["nms_thresh"] = np.float64(0.001), np.float64(0.5)
     save("nms.npz", **a)

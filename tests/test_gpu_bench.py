@@ -76,7 +76,7 @@ def _run_single(extra):
 def test_single_gpu_contract_line():
     """The driver's contract for the default mode: one JSON line with the required keys, the roofline and cpu_baseline blocks and
     the bs=1 latency block (small workload here to keep the test short)."""
-    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2", "--no-extras"])
+    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2", "--no-extras", "--latency-calls", "60"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -85,6 +85,8 @@ def test_single_gpu_contract_line():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["latency_bs1"]["224x224"]["eager"]["p50_ms"] > 0 and d["latency_bs1"]["608x608"]["hipgraph"]["p50_ms"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"].startswith("f32") and "split-f16" in d["dtype"] and "arithmetic" in d["config"]      # the arithmetic is disclosed
+    assert d["latency_bs1"]["224x224"]["eager"]["calls"] == 60 and d["latency_bs1"]["224x224"]["eager"]["warmup"] == 50
     assert d["device_only_images_per_s"] >= 0.9 * d["value"] and d["config"]["detections_per_step_rank0"] > 0
 
 
@@ -93,3 +95,39 @@ def test_preprocess_and_latency_modes():
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
     d = _run_single(["--latency", "50", "--batch", "1", "--size", "224", "--no-cpu-baseline"])
     assert d["unit"] == "ms" and d["higher_is_better"] is False and d["value"] > 0
+
+
+def test_spawn_path_probes_and_runs_rccl_at_world_one():
+    """`python bench.py --gpus 1 --spawn` with NO test hook in the environment: the parent probes the GPU count without touching HIP
+    (sysfs), starts ONE rank as a child torch.distributed.run, and that rank builds a real RCCL process group (world size 1) —
+    barrier, max-over-ranks and, in --train, the all-reduce of the flat gradient bucket all go through RCCL on the hardware."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "YN_BENCH_ONE_GPU", "YN_BENCH_BACKEND", "YN_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    d = run(["--steps", "8", "--warmup", "2", "--batch", "4", "--size", "224", "--no-cpu-baseline", "--no-latency", "--no-extras"])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["backend"] == "nccl" and d["value"] > 0
+    assert len(d["config"]["per_rank_images_per_s"]) == 1
+    for dt in ("f16", "f32"):
+        t = run(["--train", "--dtype", dt, "--size", "224", "--batch", "4", "--steps", "4", "--warmup", "2"])
+        assert t["finite"] and t["config"]["process_group"] == "nccl" and t["config"]["allreduce_us_per_step"] > 0
+        assert t["config"]["allreduce_bytes"] == 4 * t["config"]["parameters"]
+
+
+def test_gpu_probe_does_not_initialise_hip():
+    """visible_gpu_count() reads sysfs / the environment only (the parent of the ranks must never touch the GPU)."""
+    code = ("import sys; sys.argv=['bench.py']; import bench, torch; n = bench.visible_gpu_count(); "
+            "assert not torch.cuda.is_initialized(); print('COUNT', n)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n = r.stdout.split("COUNT")[1].strip()
+    assert n == "None" or int(n) >= 1
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split("COUNT")[1].strip() in ("None", "1")

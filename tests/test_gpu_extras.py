@@ -29,8 +29,9 @@ def test_ema_update_bit_exact_vs_reference_fixture(golden):
 
 
 def test_model_ema_shim_follows_the_training_loop():
-    """yolo_nano_amd.ModelEMA on the trainable shim: flat fast path for the parameters, per-tensor for the BN statistics;
-    every entry equals the numpy restatement of utils/misc.py:76-86."""
+    """yolo_nano_amd.ModelEMA on the trainable shim: ONE launch over the flat parameter buffer and ONE over the flat buffer of the
+    148 BatchNorm statistics tensors; every entry equals the numpy restatement of utils/misc.py:76-86, over three updates
+    (the model keeps training in between, so the re-homed statistics buffers must stay the ones the training step syncs into)."""
     import yolo_nano_amd
     S, C, B = 128, 20, 2
     model = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=True, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
@@ -43,15 +44,25 @@ def test_model_ema_shim_follows_the_training_loop():
     sum(model(x, target=t)).backward(); opt.step(); opt.zero_grad()          # binds the flat buffers
     ema = yolo_nano_amd.ModelEMA(model)
     assert ema._flat_of(model) is not None and ema._flat_of(ema.ema) is not None
-    before = {k: v.detach().cpu().numpy().copy() for k, v in ema.ema.state_dict().items()}
-    sum(model(x, target=t)).backward(); opt.step(); opt.zero_grad()
-    ema.update(model)
-    msd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    for k, v in ema.ema.state_dict().items():
-        if not v.dtype.is_floating_point:
-            continue
-        np.testing.assert_array_equal(v.cpu().numpy(), otg.ema_update(before[k], msd[k], 1), err_msg=k)
-    assert any(np.abs(msd[k] - before[k]).max() > 0 for k in msd if k.endswith("running_mean"))
+    from yolo_nano_amd import capi
+    launches = []
+    real = capi.Handle.ema_update
+    capi.Handle.ema_update = lambda self, e, mm, d: (launches.append(e.numel()), real(self, e, mm, d))[1]
+    try:
+        for step in range(1, 4):
+            before = {k: v.detach().cpu().numpy().copy() for k, v in ema.ema.state_dict().items()}
+            sum(model(x, target=t)).backward(); opt.step(); opt.zero_grad()
+            del launches[:]
+            ema.update(model)
+            assert len(launches) == 2, launches                                   # parameters, BatchNorm statistics
+            msd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+            for k, v in ema.ema.state_dict().items():
+                if not v.dtype.is_floating_point:
+                    continue
+                np.testing.assert_array_equal(v.cpu().numpy(), otg.ema_update(before[k], msd[k], step), err_msg="%s step %d" % (k, step))
+            assert any(np.abs(msd[k] - before[k]).max() > 0 for k in msd if k.endswith("running_mean"))
+    finally:
+        capi.Handle.ema_update = real
     # the EMA copy is a working eval model
     ema.ema.trainable = False
     boxes, scores, cls = ema.ema(x)

@@ -289,6 +289,70 @@ def test_postprocess_bit_exact(golden, hvoc):
     hvoc.nms_prefilter(1)
 
 
+def test_postprocess_diou_batched_bit_exact(golden, capi, hvoc):
+    """DIoU-NMS through the BATCHED per-class pipeline (models/yolo_nano.py:21,191-242,265-272: diou_nms=True swaps the
+    nms_processor inside postprocess): yn_postprocess on a handle with diou_nms=1 against the reference's own detections,
+    one image and a ragged batch, prefilter modes 0 / 1 / 2 (the prefilter is an IoU shortcut and must stand aside)."""
+    g = golden("nms.npz")
+    hd = capi.Handle(320, 20, arch.MULTI_ANCHOR_SIZE, "1.0x", float(g["conf_thresh"]), float(g["nms_thresh"]), diou_nms=True, max_batch=4)
+    try:
+        for mode in (0, 1, 2):
+            hd.nms_prefilter(mode)
+            for k in g["pp_cases"]:
+                b, s, c, _ = _pp(hd, g["pp_%s_boxes" % k], g["pp_%s_conf" % k])
+                assert np.array_equal(b, g["ppd_%s_out_boxes" % k]), (k, mode)
+                assert np.array_equal(s, g["ppd_%s_out_scores" % k]), (k, mode)
+                assert np.array_equal(c, g["ppd_%s_out_cls" % k]), (k, mode)
+            # a batch of five images (>= 4: the size from which mode 1 would prefilter) with different survivor counts
+            boxes, conf = g["pp_random_boxes"], g["pp_random_conf"]
+            N = conf.shape[0]
+            half = conf.copy(); half[N // 2:] = 0
+            one = np.zeros_like(conf); one[:, 7] = g["pp_one_class_conf"][:N, 7]
+            confs = [conf, np.zeros_like(conf), half, one, conf[::-1].copy()]
+            bxs = [boxes, boxes, boxes, boxes, boxes[::-1].copy()]
+            out = hd.postprocess(dev(np.stack(bxs)), dev(np.stack(confs)))
+            counts = out[4].cpu().tolist()
+            for bi in range(5):
+                rb, rs, rc = orc.postprocess(bxs[bi], confs[bi], float(g["conf_thresh"]), float(g["nms_thresh"]), diou=True)
+                kk = counts[bi]
+                assert kk == len(rs), (bi, mode)
+                assert np.array_equal(out[0][bi, :kk].cpu().numpy(), rb) and np.array_equal(out[1][bi, :kk].cpu().numpy(), rs)
+                assert np.array_equal(out[2][bi, :kk].cpu().numpy().astype(np.int64), rc)
+        # switching the flag on a live handle (yn_set_thresholds) gives the same result as building with it
+        hvoc.set_thresholds(float(g["conf_thresh"]), float(g["nms_thresh"]), diou=True)
+        b, s, c, _ = _pp(hvoc, g["pp_random_boxes"], g["pp_random_conf"])
+        assert np.array_equal(s, g["ppd_random_out_scores"]) and np.array_equal(c, g["ppd_random_out_cls"])
+    finally:
+        hvoc.set_thresholds(0.001, 0.5, diou=False)
+        hd.close()
+
+
+def test_infer_diou_vs_oracle(capi):
+    """yn_infer (network + fused decode + NMS) on a diou_nms=1 handle: kept indices bit-exact against the oracle's DIoU
+    postprocess of the same float32 scores; batch of 5 (prefilter-eligible size) and one image."""
+    hd = capi.Handle(320, 20, arch.MULTI_ANCHOR_SIZE, "1.0x", 0.001, 0.5, diou_nms=True, max_batch=5)
+    try:
+        hd.load_state_dict(weights.make_state_dict("1.0x", 20))
+        hd.fold_bn()
+        for B, mode in ((5, 1), (5, 2), (1, 0)):
+            hd.nms_prefilter(mode)
+            x = dev(weights.make_input(B, 320, seed=3))
+            out = hd.infer(x)
+            bbox, cls = hd.score_full(hd.forward_raw(x))
+            counts = out[4].cpu().tolist()
+            plain = 0
+            for b in range(B):
+                rb, rs, rc, ri = orc.postprocess(bbox[b].cpu().numpy(), cls[b].cpu().numpy(), 0.001, 0.5, diou=True, return_index=True)
+                k = counts[b]
+                assert k == len(rs), (b, k, len(rs), mode)
+                assert np.array_equal(out[3][b, :k].cpu().numpy().astype(np.int64), ri)
+                assert np.array_equal(out[0][b, :k].cpu().numpy(), rb) and np.array_equal(out[1][b, :k].cpu().numpy(), rs)
+                plain += len(orc.postprocess(bbox[b].cpu().numpy(), cls[b].cpu().numpy(), 0.001, 0.5)[1])
+            assert plain != sum(counts)                     # DIoU keeps a different set than plain NMS on this input
+    finally:
+        hd.close()
+
+
 def test_postprocess_on_reference_scores(golden, hcoco):
     """The reference's own all_bbox/all_class floats in -> the reference's detections out, bit for bit."""
     case = golden("net_coco128_b2.npz")
@@ -997,3 +1061,114 @@ def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
     for a, b in zip(raw0, raw1):
         assert torch.equal(a, b)
     h.close()
+
+
+def _rel_rms(y, ref):
+    return float(np.sqrt(((y.astype(np.float64) - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+
+
+@pytest.mark.parametrize("kind", ["pw", "c3"])
+def test_split_f16_range_guard(hvoc, kind):
+    """The split x = hi + lo * 2^-11 takes hi = (f16)x: finite only below 65520, where the reference's fp32 conv has no limit.
+    (1) operands at 6e4 — inside the range: fp32-class against float64, guard silent; (2) ONE activation at 7e4: the guard flag is
+    raised (yn_range_status), and the f32-MFMA family (yn_exact_f32) gives the right answer on the same input; (3) every activation
+    below the f16 normal range (< 6e-5): still fp32-class, because lo carries what hi loses; (4) a folded weight >= 65504: the
+    operator falls back to the f32-MFMA family by itself at fold time."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(7)
+    Cin = Cout = 96
+    k = 3 if kind == "c3" else 1
+    w = (rs.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rs.standard_normal((Cout,)).astype(np.float32)
+
+    def run(x, ww=w):
+        return nchw_np(hvoc.op_conv3x3(nhwc(x), dev(ww), dev(b), 0) if kind == "c3" else hvoc.op_pwconv(nhwc(x), dev(ww), dev(b), 0))
+
+    def ref64(x, ww=w):
+        return F.conv2d(torch.as_tensor(x).double(), torch.as_tensor(ww).double(), torch.as_tensor(b).double(), padding=k // 2).numpy()
+
+    hvoc.exact_f32(False)
+    hvoc.range_status()                                             # clear whatever earlier tests left
+    # (1) large but in range
+    x = rs.uniform(-6.0e4, 6.0e4, (2, Cin, 19, 23)).astype(np.float32)
+    y = run(x)
+    assert np.isfinite(y).all() and _rel_rms(y, ref64(x)) < 2e-6
+    assert hvoc.range_status() == (False, False)
+    # (2) one activation beyond the range
+    x2 = x.copy()
+    x2[1, 17, 9, 11] = 7.0e4
+    y2 = run(x2)
+    assert hvoc.range_status() == (False, True)                    # raised ...
+    assert hvoc.range_status() == (False, False)                   # ... and cleared by the read
+    assert (not np.isfinite(y2).all()) or _rel_rms(y2, ref64(x2)) > 1e-4      # the split result really is unusable
+    hvoc.exact_f32(True)
+    y3 = run(x2)
+    hvoc.exact_f32(False)
+    assert np.isfinite(y3).all() and _rel_rms(y3, ref64(x2)) < 2e-6
+    assert hvoc.range_status() == (False, False)
+    # +inf in the input is flagged as well (a NaN input is NaN in the reference too: not the guard's business)
+    x2[1, 17, 9, 11] = np.inf
+    run(x2)
+    assert hvoc.range_status()[1]
+    # (3) everything below the f16 normal range (and a zero bias, so that the output is small too)
+    xt = rs.uniform(-5.0e-5, 5.0e-5, (2, Cin, 19, 23)).astype(np.float32)
+    b0 = b.copy(); b[:] = 0.0
+    try:
+        yt = run(xt)
+        assert _rel_rms(yt, ref64(xt)) < 1e-5, _rel_rms(yt, ref64(xt))
+        assert hvoc.range_status() == (False, False)
+    finally:
+        b[:] = b0
+    # (4) a weight outside the range: the operator's fold notices and runs the f32-MFMA kernels
+    xs = rs.standard_normal((1, Cin, 11, 13)).astype(np.float32)
+    w4 = w.copy()
+    w4.reshape(-1)[12345 % w4.size] = 7.0e4
+    y4 = run(xs, w4)
+    assert np.isfinite(y4).all() and _rel_rms(y4, ref64(xs, w4)) < 2e-6
+    assert hvoc.range_status() == (False, False)
+
+
+def test_range_guard_whole_network_and_shim(capi):
+    """The guard end to end.  (a) BatchNorm gains that make a folded weight >= 65504: yn_fold_bn reports it (weights_exceed_f16) and
+    the handle runs on the f32-MFMA family; (b) a stem gain of 3e5 makes the activations of stage 2 overflow the split: the C ABI
+    raises activation_overflow, and the YOLONano shim notices, warns, switches to yn_exact_f32 and returns the right heads."""
+    import warnings
+    import yolo_nano_amd
+    S, C = 128, 20
+    sd = weights.make_state_dict("1.0x", C)
+    x_np = weights.make_input(1, S, seed=4)
+    # (a) weights
+    sda = {k: v.copy() for k, v in sd.items()}
+    sda["smooth_1.convs.1.weight"] = sda["smooth_1.convs.1.weight"] * np.float32(3.0e6)
+    ha = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE, "1.0x", max_batch=1)
+    ha.load_state_dict(sda); ha.fold_bn()
+    assert ha.range_status() == (True, False)
+    heads = [t.permute(0, 3, 1, 2).cpu().numpy() for t in ha.forward_raw(dev(x_np))]
+    ref = orc.Net(sda, "1.0x", C, fold=True).forward_raw(x_np)
+    for a, r in zip(heads, ref):
+        assert np.isfinite(a).all() and float(np.abs(a - r).max()) <= 1e-4 * max(1.0, float(np.abs(r).max()))
+    ha.load_state_dict(sd); ha.fold_bn()
+    assert ha.range_status() == (False, False)                     # folding in-range weights again lifts the fallback
+    ha.close()
+    # (b) activations
+    sdb = {k: v.copy() for k, v in sd.items()}
+    sdb["backbone.conv1.1.weight"] = sdb["backbone.conv1.1.weight"] * np.float32(3.0e5)
+    hb = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE, "1.0x", max_batch=1)
+    hb.load_state_dict(sdb); hb.fold_bn()
+    hb.forward_raw(dev(x_np))
+    assert hb.range_status() == (False, True)
+    hb.close()
+    refb = orc.Net(sdb, "1.0x", C, fold=True).forward_raw(x_np)
+    m = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, anchor_size=arch.MULTI_ANCHOR_SIZE)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sdb.items()})
+    m = m.to("cuda").eval()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = [t.cpu().numpy() for t in m.forward_raw(dev(x_np))]
+    assert m._exact_f32 and any("split-f16 range" in str(w_.message) for w_ in rec)
+    for a, r in zip(got, refb):
+        assert np.isfinite(a).all() and float(np.abs(a - r).max()) <= 1e-4 * max(1.0, float(np.abs(r).max())), (float(np.abs(a - r).max()), float(np.abs(r).max()))
+    with warnings.catch_warnings(record=True) as rec2:              # later forwards: already exact, no second warning
+        warnings.simplefilter("always")
+        m(dev(x_np))
+    assert not any("split-f16 range" in str(w_.message) for w_ in rec2)

@@ -159,6 +159,19 @@ def test_postprocess_bit_exact(golden):
     assert len(g["pp_empty_out_scores"]) == 0
 
 
+def test_postprocess_diou_bit_exact(golden):
+    """postprocess of the reference model built with diou_nms=True (nms_processor = diou_nms, models/yolo_nano.py:21,265-272)."""
+    g = golden("nms.npz")
+    differs = False
+    for k in g["pp_cases"]:
+        b, s, c = orc.postprocess(g["pp_%s_boxes" % k], g["pp_%s_conf" % k], float(g["conf_thresh"]), float(g["nms_thresh"]), diou=True)
+        assert np.array_equal(b, g["ppd_%s_out_boxes" % k]), k
+        assert np.array_equal(s, g["ppd_%s_out_scores" % k]), k
+        assert np.array_equal(c, g["ppd_%s_out_cls" % k]), k
+        differs = differs or len(s) != len(g["pp_%s_out_scores" % k])
+    assert differs                                          # the fixture does tell DIoU-NMS from plain NMS
+
+
 def test_nms_tie_rule_is_pinned():
     """numpy's argsort tie order is unpinned in the reference; the build's rule: equal scores -> higher index first."""
     boxes = np.array([[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3]], dtype=np.float32)

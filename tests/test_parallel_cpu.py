@@ -24,6 +24,7 @@ def _worker(rank, world, port, q):
     local = [(np.full((i + 1, 4), i, np.float32), np.full((i + 1,), i, np.float32), np.full((i + 1,), i, np.int64)) for i in range(lo, hi)]
     parallel.barrier()
     t = parallel.max_over_ranks(1.0 + rank)
+    assert parallel.all_ranks(10.0 + rank) == [10.0, 11.0]      # every rank's own time, in rank order, on every rank (bench.py's per-rank spread)
     merged = parallel.gather_results(local)
     q.put((rank, lo, hi, t, None if merged is None else [int(m[1][0]) for m in merged]))
     parallel.barrier()
@@ -208,3 +209,47 @@ def test_bn_buffers_rank0_policy_at_save(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), "ckpt.pth"))
     for k in a0:
         np.testing.assert_array_equal(ck[k].numpy(), a0[k])
+
+
+def test_forced_process_group_at_world_one(tmp_path):
+    """bench.py --spawn: a ONE-rank job still builds its process group (on the GPU box: RCCL at world size 1), and the data-parallel
+    helpers then take the collective path."""
+    import subprocess
+    import sys
+    code = ("import os, torch; from yolo_nano_amd import parallel; import torch.distributed as dist\n"
+            "r = parallel.init('gloo', force=True)\n"
+            "assert r == (0, 0, 1) and dist.is_initialized() and dist.get_world_size() == 1\n"
+            "assert parallel.all_ranks(3.5) == [3.5] and parallel.max_over_ranks(2.0) == 2.0\n"
+            "dist.destroy_process_group(); print('OK')")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+    # without the launcher environment `force` is a no-op: a plain single-process run never builds a group
+    env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    code2 = ("from yolo_nano_amd import parallel; import torch.distributed as dist\n"
+             "parallel.init('gloo', force=True); assert not dist.is_initialized(); print('OK')")
+    r = subprocess.run([sys.executable, "-c", code2], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_gpu_count_probe_is_pure_sysfs(monkeypatch, tmp_path):
+    """bench.visible_gpu_count(): KFD topology nodes with SIMDs, narrowed by *_VISIBLE_DEVICES; None without sysfs."""
+    import glob as _glob
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):                   # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    real = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: real(str(nodes / "*" / "properties")) if "kfd" in pat else real(pat))
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [] if "kfd" in pat else real(pat))
+    assert bench.visible_gpu_count() is None

@@ -43,11 +43,15 @@ SIGNATURES = {
     "yn_synchronize": (_i32, [_vp]),
     "yn_autotune": (_i32, [_vp, _i32]),
     "yn_set_pw_config": (_i32, [_vp, _i32]),
+    "yn_tune_save": (_i32, [ctypes.c_char_p, _i32]),
+    "yn_tune_load": (_i32, [ctypes.c_char_p, _i32]),
+    "yn_allreduce_grads": (_i32, [_vp, _vp]),
     "yn_pw_config_count": (_i32, []),
     "yn_pw_f32_config_count": (_i32, []),
     "yn_unit_chain": (_i32, [_vp, _i32]),
     "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_exact_f32": (_i32, [_vp, _i32]),
+    "yn_range_status": (_i32, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "yn_fuse_decode": (_i32, [_vp, _i32]),
     "yn_group_launch": (_i32, [_vp, _i32]),
     "yn_down_fuse": (_i32, [_vp, _i32]),
@@ -130,6 +134,17 @@ def _ptr(t):
     return t
 
 
+def tune_save(path, device=0):
+    """Write the process-wide autotune table of `device` to `path` (yn_tune_save)."""
+    if load_library().yn_tune_save(str(path).encode(), int(device)):
+        raise YnError("yn_tune_save(%s) failed" % path)
+
+
+def tune_load(path, device=0):
+    """Adopt the entries of `path` for `device` (yn_tune_load) -> number adopted, -1 if unreadable."""
+    return int(load_library().yn_tune_load(str(path).encode(), int(device)))
+
+
 class Handle:
     """One yn_handle = one device + one stream.  Thin, 1:1 with the C ABI."""
 
@@ -177,6 +192,23 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def _torch_stream(self):
+        """The stream the handle launches on, as a torch stream object (for record_stream)."""
+        if getattr(self, "_ts_ptr", None) != self._stream_ptr or getattr(self, "_ts", None) is None:
+            self._ts = torch.cuda.ExternalStream(self._stream_ptr, device=self.device) if self._stream_ptr else torch.cuda.default_stream(self.device)
+            self._ts_ptr = self._stream_ptr
+        return self._ts
+
+    def _in(self, t, dtype=torch.float32):
+        """`t` as a contiguous `dtype` tensor that is safe to hand to the library as a bare pointer.  A converted / compacted COPY would go
+        back to torch's caching allocator as soon as the caller's expression ends, while the kernels that read it are still queued on
+        the handle's stream (which need not be torch's current one): the copy is tied to that stream with record_stream."""
+        c = t if t.dtype == dtype else t.to(dtype)
+        c = c.contiguous()
+        if c.is_cuda and c.data_ptr() != t.data_ptr():
+            c.record_stream(self._torch_stream())
+        return c
 
     def _ck(self, rc, what):
         if rc:
@@ -229,6 +261,14 @@ class Handle:
     def exact_f32(self, on=True):
         """Pin every GEMM-shaped conv to the f32 MFMA (default off: the MFMA-bound layers use split-f16 operands, fp32-class)."""
         self._ck(self.lib.yn_exact_f32(self.h, int(bool(on))), "yn_exact_f32")
+
+    def range_status(self):
+        """(weights_exceed_f16, activation_overflow) of the split-f16 range guard (yn_range_status): the first says the handle fell
+        back to the f32-MFMA family at fold time; the second that an activation >= 65504 was split since the last call — the
+        results of those calls are invalid, re-run them with exact_f32(True).  Synchronises the stream, clears the second flag."""
+        w, a = _i32(0), _i32(0)
+        self._ck(self.lib.yn_range_status(self.h, ctypes.byref(w), ctypes.byref(a)), "yn_range_status")
+        return bool(w.value), bool(a.value)
 
     def fuse_decode(self, on=True):
         """infer(): last head conv + candidate decode as one kernel (default on; bit-identical outputs either way)."""
@@ -304,7 +344,7 @@ class Handle:
         """x: cuda float32 NCHW [B,3,S,S] -> three NHWC head tensors."""
         B = x.shape[0]
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape[1:]) == (3, self.S, self.S), (x.shape, self.S)
-        x = x.contiguous()
+        x = self._in(x)
         if out is None:
             out = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.head_shapes(B)]
         self._ck(self.lib.yn_forward_raw(self.h, x.data_ptr(), B, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()), "yn_forward_raw")
@@ -315,7 +355,7 @@ class Handle:
         B, S = x.shape[0], self.S
         ch = arch.STAGE_CH[self.backbone]
         outs = [torch.empty((B, S // st, S // st, c), dtype=torch.float32, device=x.device) for st, c in zip((8, 16, 32), ch)]
-        self._ck(self.lib.yn_forward_taps(self.h, x.contiguous().data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_forward_taps")
+        self._ck(self.lib.yn_forward_taps(self.h, self._in(x).data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_forward_taps")
         return outs
 
     def score_full(self, heads):
@@ -327,7 +367,7 @@ class Handle:
         return bbox, cls
 
     def decode_boxes(self, txtytwth):
-        t = txtytwth.contiguous().float()
+        t = self._in(txtytwth)
         B = t.shape[0]
         out = torch.empty((B, self.N, 4), dtype=torch.float32, device=t.device)
         self._ck(self.lib.yn_decode_boxes(self.h, t.data_ptr(), B, out.data_ptr()), "yn_decode_boxes")
@@ -347,7 +387,7 @@ class Handle:
         n = int(scores.shape[0])
         keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dets.device)
         cnt = torch.zeros((1,), dtype=torch.int32, device=dets.device)
-        self._ck(self.lib.yn_nms(self.h, _ptr(dets.contiguous()), _ptr(scores.contiguous()), n, float(thresh), int(bool(diou)),
+        self._ck(self.lib.yn_nms(self.h, _ptr(self._in(dets)), _ptr(self._in(scores)), n, float(thresh), int(bool(diou)),
                                  keep.data_ptr(), cnt.data_ptr()), "yn_nms")
         return keep[: int(cnt.item())]
 
@@ -364,14 +404,14 @@ class Handle:
         """all_local [B,N,4], all_conf [B,N,C] cuda float32 -> (boxes, scores, cls, index, count) device buffers"""
         B, N, C = all_conf.shape
         out = self.alloc_outputs(B, N, all_conf.device) if out is None else out
-        self._ck(self.lib.yn_postprocess(self.h, _ptr(all_local.contiguous()), _ptr(all_conf.contiguous()), B, N, C,
+        self._ck(self.lib.yn_postprocess(self.h, _ptr(self._in(all_local)), _ptr(self._in(all_conf)), B, N, C,
                                          *[o.data_ptr() for o in out]), "yn_postprocess")
         return out
 
     def infer(self, x, out=None):
         B = x.shape[0]
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape[1:]) == (3, self.S, self.S), (x.shape, self.S)
-        x = x.contiguous()
+        x = self._in(x)
         out = self.alloc_outputs(B, device=x.device) if out is None else out
         self._ck(self.lib.yn_infer(self.h, x.data_ptr(), B, *[o.data_ptr() for o in out]), "yn_infer")
         return out
@@ -404,7 +444,7 @@ class Handle:
         """tools.loss + iou_score + decode on the reference's split prediction layout.
         -> (losses [4] device tensor, (g_conf, g_cls, g_txtytwth) or None)"""
         B = cls.shape[0]
-        conf, cls, t, target = (v.contiguous().float() for v in (conf, cls, txtytwth, target))
+        conf, cls, t, target = (self._in(v) for v in (conf, cls, txtytwth, target))
         losses = torch.empty((4,), dtype=torch.float32, device=cls.device)
         g = (torch.empty_like(conf), torch.empty_like(cls), torch.empty_like(t)) if grads else (None, None, None)
         self._ck(self.lib.yn_loss(self.h, conf.data_ptr(), cls.data_ptr(), t.data_ptr(), target.data_ptr(), B, losses.data_ptr(),
@@ -414,7 +454,7 @@ class Handle:
     def loss_heads(self, heads, target, grads=True):
         """Same, directly on the three raw NHWC head tensors; gradients come back in the head layout."""
         B = heads[0].shape[0]
-        target = target.contiguous().float()
+        target = self._in(target)
         losses = torch.empty((4,), dtype=torch.float32, device=target.device)
         g = [torch.empty_like(t) for t in heads] if grads else [None, None, None]
         self._ck(self.lib.yn_loss_heads(self.h, _ptr(heads[0]), _ptr(heads[1]), _ptr(heads[2]), target.data_ptr(), B, losses.data_ptr(),
@@ -462,7 +502,7 @@ class Handle:
     def nms_merge(self, boxes, scores, cls, num_classes, nms_thresh, diou=False):
         """Per-class NMS over a detection list (TTA merge, utils/misc.py:132-146) -> (boxes [K,4], scores [K], cls [K], index [K])."""
         n = int(boxes.shape[0])
-        boxes = boxes.contiguous().float(); scores = scores.contiguous().float(); cls = cls.contiguous().to(torch.int32)
+        boxes = self._in(boxes); scores = self._in(scores); cls = self._in(cls, torch.int32)
         ob = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)
         osc = torch.empty((max(n, 1),), dtype=torch.float32, device=self.device)
         oc = torch.empty((max(n, 1),), dtype=torch.int32, device=self.device)
@@ -514,6 +554,11 @@ class Handle:
         """Arithmetic of train_step: "f32" (the reference's own) or "f16" (fp16 storage + f16 MFMA, fp32 master weights, loss scaling)."""
         self._ck(self.lib.yn_train_precision(self.h, {"f32": 0, "fp32": 0, "f16": 1, "fp16": 1}[dtype]), "yn_train_precision")
 
+    def allreduce_grads(self, nccl_comm):
+        """All-reduce(sum) the flat gradient buffer in place over an RCCL communicator (an ncclComm_t as an int / c_void_p) on the
+        handle's stream: the torch-free form of the gradient exchange (yn_allreduce_grads)."""
+        self._ck(self.lib.yn_allreduce_grads(self.h, ctypes.c_void_p(nccl_comm if isinstance(nccl_comm, int) else nccl_comm.value)), "yn_allreduce_grads")
+
     def skipped_steps(self):
         n = ctypes.c_int64(0)
         self._ck(self.lib.yn_train_skipped_steps(self.h, ctypes.byref(n)), "yn_train_skipped_steps")
@@ -527,7 +572,7 @@ class Handle:
     def train_step(self, x, target, lr=1e-3, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, update=True):
         """-> losses [4] (conf, cls, bbox, iou) device tensor; gradients are left in self.flat_grads."""
         B = x.shape[0]
-        x, target = x.contiguous().float(), target.contiguous().float()
+        x, target = self._in(x), self._in(target)
         losses = torch.empty((4,), dtype=torch.float32, device=x.device)
         self._ck(self.lib.yn_train_step(self.h, x.data_ptr(), target.data_ptr(), B, float(lr), float(momentum), float(weight_decay),
                                         float(grad_scale), int(bool(update)), losses.data_ptr()), "yn_train_step")
@@ -537,7 +582,7 @@ class Handle:
         """Train-mode forward only (batch statistics; running statistics updated) -> three NHWC float32 raw heads."""
         B = x.shape[0]
         outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.head_shapes(B)]
-        self._ck(self.lib.yn_train_forward(self.h, x.contiguous().float().data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_train_forward")
+        self._ck(self.lib.yn_train_forward(self.h, self._in(x).data_ptr(), B, *[o.data_ptr() for o in outs]), "yn_train_forward")
         return outs
 
     def read_param(self, key, shape):
@@ -566,53 +611,53 @@ class Handle:
     def op_dwconv3x3(self, x, w, bias, stride=1, act=0):
         B, H, W, C = x.shape
         y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, C), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_dwconv3x3(self.h, _ptr(x.contiguous()), B, H, W, C, stride, _ptr(w.contiguous()),
-                                          _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_dwconv3x3")
+        self._ck(self.lib.yn_op_dwconv3x3(self.h, _ptr(self._in(x)), B, H, W, C, stride, _ptr(self._in(w)),
+                                          _ptr(self._in(bias)) if bias is not None else None, act, y.data_ptr()), "yn_op_dwconv3x3")
         return y
 
     def op_pwconv(self, x, w, bias, act=0):
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_pwconv(self.h, _ptr(x.contiguous()), B, H, W, Cin, Cout, _ptr(w.contiguous()),
-                                       _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_pwconv")
+        self._ck(self.lib.yn_op_pwconv(self.h, _ptr(self._in(x)), B, H, W, Cin, Cout, _ptr(self._in(w)),
+                                       _ptr(self._in(bias)) if bias is not None else None, act, y.data_ptr()), "yn_op_pwconv")
         return y
 
     def op_pwconv_shuffle(self, x, passthrough, w, bias, act=0):
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         y = torch.empty((B, H, W, 2 * Cout), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_pwconv_shuffle(self.h, x.contiguous().data_ptr(), passthrough.contiguous().data_ptr(), B, H, W, Cin, Cout,
-                                               w.contiguous().data_ptr(), _ptr(bias), act, y.data_ptr()), "yn_op_pwconv_shuffle")
+        self._ck(self.lib.yn_op_pwconv_shuffle(self.h, self._in(x).data_ptr(), self._in(passthrough).data_ptr(), B, H, W, Cin, Cout,
+                                               self._in(w).data_ptr(), _ptr(bias), act, y.data_ptr()), "yn_op_pwconv_shuffle")
         return y
 
     def op_conv3x3(self, x, w, bias, act=0, x2=None, resample=0):
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_conv3x3(self.h, _ptr(x.contiguous()), _ptr(x2.contiguous()) if x2 is not None else None, resample,
-                                        B, H, W, Cin, Cout, _ptr(w.contiguous()),
-                                        _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_conv3x3")
+        self._ck(self.lib.yn_op_conv3x3(self.h, _ptr(self._in(x)), _ptr(self._in(x2)) if x2 is not None else None, resample,
+                                        B, H, W, Cin, Cout, _ptr(self._in(w)),
+                                        _ptr(self._in(bias)) if bias is not None else None, act, y.data_ptr()), "yn_op_conv3x3")
         return y
 
     def op_stem(self, x_nchw, w, bias, act=0):
         B, _, H, W = x_nchw.shape
         Cout = w.shape[0]
         y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), dtype=torch.float32, device=x_nchw.device)
-        self._ck(self.lib.yn_op_stem(self.h, _ptr(x_nchw.contiguous()), B, H, W, Cout, _ptr(w.contiguous()),
-                                     _ptr(bias.contiguous()) if bias is not None else None, act, y.data_ptr()), "yn_op_stem")
+        self._ck(self.lib.yn_op_stem(self.h, _ptr(self._in(x_nchw)), B, H, W, Cout, _ptr(self._in(w)),
+                                     _ptr(self._in(bias)) if bias is not None else None, act, y.data_ptr()), "yn_op_stem")
         return y
 
     def op_maxpool(self, x):
         B, H, W, C = x.shape
         y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_maxpool3x3s2(self.h, _ptr(x.contiguous()), B, H, W, C, y.data_ptr()), "yn_op_maxpool3x3s2")
+        self._ck(self.lib.yn_op_maxpool3x3s2(self.h, _ptr(self._in(x)), B, H, W, C, y.data_ptr()), "yn_op_maxpool3x3s2")
         return y
 
     def op_shuffle_block(self, block, x, cout, stride):
         B, H, W, _ = x.shape
         y = torch.empty((B, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_shuffle_block(self.h, block.encode(), _ptr(x.contiguous()), B, H, W, y.data_ptr()), "yn_op_shuffle_block")
+        self._ck(self.lib.yn_op_shuffle_block(self.h, block.encode(), _ptr(self._in(x)), B, H, W, y.data_ptr()), "yn_op_shuffle_block")
         return y
 
     def op_h16_conv(self, kind, x, w, bias=None, stride=1, dy=None, gapped=False):
@@ -624,8 +669,8 @@ class Handle:
         y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x) if dy is not None else None
         dw = torch.empty_like(w) if dy is not None else None
-        self._ck(self.lib.yn_op_h16_conv(self.h, int(kind), x.contiguous().data_ptr(), B, H, W, Cin, int(bool(gapped)), w.contiguous().data_ptr(), _ptr(bias),
-                                         Cout, int(stride), _ptr(dy.contiguous() if dy is not None else None), y.data_ptr(), _ptr(dx), _ptr(dw)), "yn_op_h16_conv")
+        self._ck(self.lib.yn_op_h16_conv(self.h, int(kind), self._in(x).data_ptr(), B, H, W, Cin, int(bool(gapped)), self._in(w).data_ptr(), _ptr(bias),
+                                         Cout, int(stride), _ptr(self._in(dy) if dy is not None else None), y.data_ptr(), _ptr(dx), _ptr(dw)), "yn_op_h16_conv")
         return y, dx, dw
 
     def op_h16_bn(self, y, gamma, beta, act=0, dz=None):
@@ -634,18 +679,18 @@ class Handle:
         dy = torch.empty_like(y) if dz is not None else None
         dg = torch.empty((C,), dtype=torch.float32, device=y.device) if dz is not None else None
         db = torch.empty((C,), dtype=torch.float32, device=y.device) if dz is not None else None
-        self._ck(self.lib.yn_op_h16_bn(self.h, y.contiguous().data_ptr(), _ptr(dz.contiguous() if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
+        self._ck(self.lib.yn_op_h16_bn(self.h, self._in(y).data_ptr(), _ptr(self._in(dz) if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
                                        int(act), z.data_ptr(), _ptr(dy), _ptr(dg), _ptr(db)), "yn_op_h16_bn")
         return z, dy, dg, db
 
     def to_nhwc(self, x):
         B, C, H, W = x.shape
         y = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_nchw_to_nhwc(self.h, _ptr(x.contiguous()), B, C, H, W, y.data_ptr()), "yn_op_nchw_to_nhwc")
+        self._ck(self.lib.yn_op_nchw_to_nhwc(self.h, _ptr(self._in(x)), B, C, H, W, y.data_ptr()), "yn_op_nchw_to_nhwc")
         return y
 
     def to_nchw(self, x):
         B, H, W, C = x.shape
         y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.yn_op_nhwc_to_nchw(self.h, _ptr(x.contiguous()), B, C, H, W, y.data_ptr()), "yn_op_nhwc_to_nchw")
+        self._ck(self.lib.yn_op_nhwc_to_nchw(self.h, _ptr(self._in(x)), B, C, H, W, y.data_ptr()), "yn_op_nhwc_to_nchw")
         return y

@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
             if (g < 2 * 4 * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)g * 8) = b_reg[i];
         }
     };
+    float amax = 0.0f;                                                   // range guard (yn_device.h): largest |value| this thread has split
     auto split_store = [&](int r, int c, float v0, float v1) {           // two adjacent channels of row r -> both planes
         uch16x2 hi, lo;
+        amax = range_track(range_track(amax, v0), v1);
         hi[0] = (uch16)v0; hi[1] = (uch16)v1;
         lo[0] = (uch16)((v0 - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((v1 - (float)hi[1]) * 2048.0f);
         *reinterpret_cast<uch16x2*>(Ph + r * PS + c) = hi;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
         }
     }
     YN_TS();
-    if (!a.Wp1n) return;
+    if (!a.Wp1n) { range_report(a.ovf, amax); return; }
     // x2' = interleave(x1[bf/2:], y[bf/2:]) -> the planes (free since the first GEMM; their pad columns are still zero)
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
     GemmArgs e{};
     e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = a.M; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
     gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
+    range_report(a.ovf, amax);
 #ifdef YN_EXP_TIMING
     YN_TS();
     if (t == 0 && (blockIdx.x % 97) == 5)
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
     const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;         // input pixel of window position (0, 0)
     const int KQ1 = (a.cin + 7) >> 3, KQ2 = (bf + 7) >> 3;
+    float amax = 0.0f;                                      // range guard (yn_device.h): largest |value| this thread has split
 
 #ifdef YN_EXP_TIMING
     long long TS[8]; int tsn = 0;
@@ -796,6 +800,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
         for (int j = 0; j < 16; ++j) {
             const bool kj = 2 * j < a.cin;
             v[j] = vmask(*reinterpret_cast<const float2*>(px + (kj ? 2 * j : 0)), opaque_mask(ok && kj));
+            amax = range_track(range_track(amax, v[j].x), v[j].y);
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -896,6 +901,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 #pragma unroll
                     for (int k = 0; k < 9; ++k) vfma(acc, x1w[i][k], w1d[k]);
                     acc = vact(acc, a.dw1_act);
+                    amax = range_track(range_track(amax, acc.x), acc.y);
                     uch16x2 hi, lo;
                     hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
                     lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
@@ -917,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
                 for (int kx = 0; kx < 3; ++kx)
                     vfma(acc, *reinterpret_cast<const float2*>(T32 + ((2 * dy + ky) * WW + 2 * dx + kx) * CS + dc), wd[ky * 3 + kx]);
             acc = vact(acc, a.dw_act);
+            amax = range_track(range_track(amax, acc.x), acc.y);
             uch16x2 hi, lo;
             hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
             lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
@@ -930,6 +937,7 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
     }
     __syncthreads();
     YN_TS();
+    range_report(a.ovf, amax);                              // every split of this workgroup is done
 
     // ---- 4. branch 1's pointwise conv on wavefronts NP..2NP-1 (-> an LDS tile in the free T32 space) while wavefronts 0..NP-1 run pw2 --
     float* PT = T32;                                        // [32][BN + 1]
@@ -1104,6 +1112,7 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
     const float gbias = (wave < 3) ? a.bias[wave * 32 + l31] : 0.0f;
 
     // ---- 2. depthwise (dwconv3x3_kernel's chain) -> split planes; weights -> LDS -------------------------------------------------------
+    float amax = 0.0f;                                      // range guard (yn_device.h)
     if (worker) {
 #pragma unroll
         for (int i = 0; i < NR; ++i)
@@ -1119,10 +1128,11 @@ __device__ __forceinline__ void dwpw_block(const DwPwArgs& a, uch16* smem, unsig
             const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
             uch16x4 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
+            for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
             *reinterpret_cast<uch16x4*>(Ah + op * AST + c) = hi;
             *reinterpret_cast<uch16x4*>(Al + op * AST + c) = lo;
         }
+        range_report(a.ovf, amax);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {

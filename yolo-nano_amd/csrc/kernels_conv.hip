@@ -764,6 +764,7 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
     //      smooth_1: W = 52, one block per CU): halo 19 k cycles, nine taps 31.7 k (486 MFMAs = 15.5 k), epilogue 9 k per 128-pixel tile.
     //      The halo phase is BANDWIDTH-bound, not latency-bound: 180 KB per tile (halo factor 1.83 at W = 52 + the up2 source) at the
     //      ~10 B/clk/CU every CU gets when all of them stream at once; 24 loads in flight per thread instead of 8 changed nothing ----
+    float amax = 0.0f;                                                                // range guard (yn_device.h): largest |value| this thread has split
     auto load_halo = [&](int half) {
         constexpr int U = 8, CQ = HC / 4, PPL = 256 / CQ;
         const int cq = t % CQ, pl = t / CQ;
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
                         const float x4[4] = {v[u].x + u2[u].x, v[u].y + u2[u].y, v[u].z + u2[u].z, v[u].w + u2[u].w};
                         c3h16x4 hi, lo;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
+                        for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
                         *reinterpret_cast<c3h16x4*>(Hh + (size_t)i * CSH + 4 * cq) = hi;
                         *reinterpret_cast<c3h16x4*>(Hl + (size_t)i * CSH + 4 * cq) = lo;
                     }
@@ -863,6 +864,7 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
     }
 
     YN_TS();
+    range_report(a.ovf, amax);
     // epilogue: combine the two accumulator sets, bias + activation, quad transpose -> 16-byte stores
     const int j = lane & 3;
 #pragma unroll
@@ -1629,6 +1631,7 @@ __global__ void fold_pack_kernel(FoldArgs a)
         const int k = tap * a.Cin + ci;
         a.w_packed[((size_t)(k >> 1) * a.Npad + co) * 2 + (k & 1)] = v;
         if (a.ws_hi) {                          // the same weight as an exact-to-2^-22 pair of halves: v = hi + lo * 2^-11
+            if (a.w_ovf && !(fabsf(v) < 65504.0f)) atomicOr(a.w_ovf, 1u);      // does not fit the split (or is not finite): the caller drops to the f32-MFMA family
             const _Float16 hi = (_Float16)v, lo = (_Float16)((v - (float)hi) * 2048.0f);
             const size_t o = (((size_t)tap * ((a.Cin + 7) >> 3) + (ci >> 3)) * a.Npad + co) * 8 + (ci & 7);
             reinterpret_cast<_Float16*>(a.ws_hi)[o] = hi;

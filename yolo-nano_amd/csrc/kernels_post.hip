@@ -462,6 +462,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     for (int nt = 0; nt < 2; ++nt) { const int n = wave * 64 + nt * 32 + l31; fbias[nt] = a.fbias[n < a.Npad ? n : 0]; }
 
     // ---- 2. depthwise -> split planes; W -> LDS; 96 -> 96 GEMM on three wavefronts -----------------------------------------------------
+    float amax = 0.0f;                                      // range guard (yn_device.h): largest |value| this thread has split
     if (worker) {
 #pragma unroll
         for (int o = 0; o < R; ++o) {
@@ -475,7 +476,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
             const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
             c3h16x4 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
+            for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (c3h16)x4[j]; lo[j] = (c3h16)((x4[j] - (float)hi[j]) * 2048.0f); }
             *reinterpret_cast<c3h16x4*>(Ah + op * AST + c) = hi;
             *reinterpret_cast<c3h16x4*>(Al + op * AST + c) = lo;
         }
@@ -515,11 +516,13 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const float v = apply_act(__builtin_fmaf(m1[r], 1.0f / 2048.0f, m0[r]) + gbias, a.act);
+            amax = range_track(amax, v);
             const c3h16 hi = (c3h16)v;
             Ah[row * AST + n] = hi;
             Al[row * AST + n] = (c3h16)((v - (float)hi) * 2048.0f);
         }
     }
+    range_report(a.ovf, amax);                              // both split sites of this workgroup are behind it
     stage_b2();
     __syncthreads();
     prefetch_b2(1);

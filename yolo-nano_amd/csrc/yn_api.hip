@@ -5,6 +5,8 @@
 // Network wiring restates models/yolo_nano.py:282-301 and backbone/shufflenetv2.py:69-78,157-167.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -127,6 +129,9 @@ struct yn_handle {
     bool fuse_decode = true;               // yn_fuse_decode / YN_FUSE_DECODE=0: yn_infer's last head conv + candidate decode as one kernel
     int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
     bool exact_f32 = false;                // yn_exact_f32 / YN_EXACT_F32=1: GEMM-shaped convs on the f32 MFMA only (no split-f16 operands)
+    bool range_fallback = false;           // yn_fold_bn found a folded GEMM weight outside the split's range (|w| >= 65504): same effect as exact_f32
+    unsigned* range_flags = nullptr;       // device uint[3]: [0] weights out of range (fold_pack_kernel), [1] an activation >= 65504 was split
+                                           // (range_report, yn_device.h; read and cleared by yn_range_status), [2] the same as [0] for a yn_op_* call
     bool autotune = true;
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
@@ -171,6 +176,9 @@ DevGuard::DevGuard(const yn_handle* h)
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess && cur != h->cfg.device && hipSetDevice(h->cfg.device) == hipSuccess) prev = cur;
 }
+
+// the f32-MFMA family runs every GEMM-shaped conv when the caller asked for it or when the folded weights do not fit the split
+inline bool exact(const yn_handle* h) { return h->exact_f32 || h->range_fallback; }
 
 const int STAGE_CH[4][3] = {{48, 96, 192}, {116, 232, 464}, {176, 352, 704}, {244, 488, 976}};
 const int STAGE_REP[3] = {4, 8, 4};
@@ -277,6 +285,7 @@ size_t network_arena_bytes(yn_handle* h, int B, int S)
 // every cached hipGraphExec_t refers to the buffers it was captured with: destroy them whenever those go away
 void drop_graphs(yn_handle* h)
 {
+    if (!h->graphs.empty()) (void)hipStreamSynchronize(h->stream);     // a replay may still be in flight (the setters below reach here without draining)
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
 }
@@ -498,7 +507,8 @@ GemmArgs pw_args(yn_handle* h, const Layer& l, const float* in, int in_ld, int i
     a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     if (n_store > l.cout && n_store <= l.Npad) a.N = n_store;     // padded output row: the extra (zero-weight) columns are stored too
-    if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }      // split-f16 MFMA family (fp32-class); exact_f32: the f32-MFMA kernels
+    if (!exact(h)) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }          // split-f16 MFMA family (fp32-class); exact_f32 / range fallback: the f32-MFMA kernels
+    a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
     a.cfg = -1;
     return a;
 }
@@ -566,7 +576,7 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
         for (int first = 0; first < 2; ++first) {
             ChainArgs q{};
             q.t1_ld = bf; q.x1_ld = first ? C : bf; q.out_ld = bf; q.bf = bf; q.Npad = L(h, name(1) + ".b2.pw2").Npad; q.M = (int)M;
-            if (!h->exact_f32) q.Ws2h = L(h, name(1) + ".b2.pw2").ws_hi;
+            if (!exact(h)) q.Ws2h = L(h, name(1) + ".b2.pw2").ws_hi;
             if (!unit_chain_covers(q)) return 0;
             q.out_ld = C;
             if (!unit_chain_covers(q)) return 0;
@@ -587,16 +597,17 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
         a.x1 = x1; a.x1_ld = x1_ld; a.x1_off = 0;
         a.wdw = dw.w_packed; a.bdw = dw.b_packed; a.dw_act = dw.act;
         a.Wp2 = pw2.w_packed; a.b2 = pw2.b_packed; a.act2 = pw2.act;
-        if (!h->exact_f32) { a.Ws2h = pw2.ws_hi; a.Ws2l = pw2.ws_lo; }
+        if (!exact(h)) { a.Ws2h = pw2.ws_hi; a.Ws2l = pw2.ws_lo; }
         if (!last) {
             const Layer& pw1n = L(h, name(bi + 1) + ".b2.pw1");
             a.Wp1n = pw1n.w_packed; a.b1n = pw1n.b_packed; a.act1n = pw1n.act;
-            if (!h->exact_f32) { a.Ws1h = pw1n.ws_hi; a.Ws1l = pw1n.ws_lo; }
+            if (!exact(h)) { a.Ws1h = pw1n.ws_hi; a.Ws1l = pw1n.ws_lo; }
             a.out = pbuf[(bi - 1) & 1]; a.out_ld = bf; a.t1n = tB;
         } else {
             a.out = final_out; a.out_ld = C;
         }
         a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw2.Npad; a.M = (int)M;
+        a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
         Bracket br(h, P + (last ? ".dw+pw2" : ".dw+pw2+pw1n"), 2.0 * M * bf * (9.0 + bf + (last ? 0.0 : (double)bf)),
                    4.0 * (4.0 * M * bf + (last ? 1.0 : 2.0) * bf * bf + 10.0 * bf));
         if (dbg_skip(h, P + ".chain")) { br.cancel(); x1 = a.out; x1_ld = bf; float* tq = tA; tA = tB; tB = tq; continue; }
@@ -628,7 +639,8 @@ void run_c3(yn_handle* h, const Layer& l, const float* in, const float* in2, int
     a.Wp = l.w_packed; a.bias = l.b_packed; a.out = out; a.out_ld = l.cout; a.out_off = 0;
     a.M = B * H * W; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     a.cfg = -1;
-    if (!h->exact_f32) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }     // split-f16 MFMA path (fp32-class); exact_f32: the f32-MFMA kernel
+    if (!exact(h)) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }         // split-f16 MFMA path (fp32-class); exact_f32 / range fallback: the f32-MFMA kernel
+    a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
     if (dbg_skip(h, l.name)) return;
     const double M = (double)a.M;
     const double in2px = resample == 1 ? M / 4 : (resample == 2 ? M * 4 : 0);
@@ -744,6 +756,7 @@ static GemmArgs head_final_args(yn_handle* h, const Layer& l, const float* in, l
     a.Wp = l.w_packed; a.bias = l.b_packed;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
     a.Wsh = l.ws_hi; a.Wsl = l.ws_lo;
+    a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
     a.cfg = -1;
     return a;
 }
@@ -800,7 +813,8 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             d.wdw1 = l1d.w_packed; d.bdw1 = l1d.b_packed; d.dw1_act = l1d.act;
             d.W3h = l1p.ws_hi; d.W3l = l1p.ws_lo; d.b3 = l1p.b_packed; d.act3 = l1p.act; d.Npad3 = l1p.Npad;
             d.out = oA; d.B = B; d.H = curH; d.W = curH; d.bf = bf;
-            const bool use_down = h->down_fuse && !h->exact_f32 && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 &&
+            d.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
+            const bool use_down = h->down_fuse && !exact(h) && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 &&
                                   l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && down_unit_covers(d);
             static const int down_b1 = getenv("YN_DOWN_B1") ? atoi(getenv("YN_DOWN_B1")) : 1;      // 0: branch 1 as its own two kernels (A/B runs)
             if (use_down && !down_b1) {
@@ -854,7 +868,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     // the three laterals are independent (p3 is only needed by smooth_1): one grouped launch, or three launches with the large one
     // forked onto a side stream
     bool lat_grouped = false;
-    if (h->group_launch && !h->exact_f32) {
+    if (h->group_launch && !exact(h)) {
         const Layer* ll[3] = {&L(h, "conv1x1_0"), &L(h, "conv1x1_1"), &L(h, "conv1x1_2")};
         if (ll[0]->ws_hi && ll[1]->ws_hi && ll[2]->ws_hi) {
             // longest K first: a workgroup of the K = 464 lateral runs 15 chunk rounds against 4 for the stride-8 one, and workgroups start
@@ -881,7 +895,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     // side stream as soon as smooth_1 is enqueued, head 2 after smooth_2, head 3 stays on the main stream.
     const float* feats[3] = {p3a, p4b, p5a};
     const int Ws[3] = {W3, W4, W5};
-    bool fuse_all = fuse_decode && h->fuse_decode && !h->exact_f32;
+    bool fuse_all = fuse_decode && h->fuse_decode && !exact(h);
     for (int hd = 0; hd < 3 && fuse_all; ++hd) {
         snprintf(nm, sizeof nm, "head_det_%d.4", hd + 1);
         fuse_all = head_decode_supported(head_final_args(h, L(h, nm), nullptr, (long)B * Ws[hd] * Ws[hd]), h->grid);
@@ -919,7 +933,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
     };
     // All three heads layer by layer, each layer ONE grouped launch (5 launches instead of 15): the stride-16 / 32 heads ride along with
     // the stride-8 one instead of paying ten launches of 7-20 us for a few microseconds of work.  Needs the split-f16 family.
-    bool grouped = h->group_launch && !h->exact_f32;
+    bool grouped = h->group_launch && !exact(h);
     const Layer* hl[5][3];
     for (int k = 0; k < 5 && grouped; ++k)
         for (int hd = 0; hd < 3; ++hd) {
@@ -966,6 +980,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                 q[hd].wdw = ld.w_packed; q[hd].bdw = ld.b_packed; q[hd].dw_act = ld.act;
                 q[hd].Wh = lp.ws_hi; q[hd].Wl = lp.ws_lo; q[hd].bias = lp.b_packed; q[hd].act = lp.act; q[hd].Npad = lp.Npad;
                 q[hd].out = dst[hd]; q[hd].B = B; q[hd].H = Ws[hd]; q[hd].W = Ws[hd]; q[hd].C = ld.cout;
+                q[hd].ovf = h->range_flags ? h->range_flags + 1 : nullptr;
                 if (ld.stride != 1 || ld.cout != NECK || lp.cin != NECK || lp.cout != NECK) return false;
                 const double M = (double)B * Ws[hd] * Ws[hd];
                 fl += 2.0 * M * NECK * (9.0 + NECK);
@@ -992,6 +1007,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                 q[hd].Wh = lp.ws_hi; q[hd].Wl = lp.ws_lo; q[hd].bias = lp.b_packed; q[hd].act = lp.act;
                 q[hd].Wfh = gf.Wsh; q[hd].Wfl = gf.Wsl; q[hd].fbias = gf.bias; q[hd].Npad = gf.Npad;
                 q[hd].B = B; q[hd].H = Ws[hd]; q[hd].W = Ws[hd];
+                q[hd].ovf = h->range_flags ? h->range_flags + 1 : nullptr;
                 const double M = (double)B * Ws[hd] * Ws[hd];
                 fl += 2.0 * M * NECK * (9.0 + NECK) + 2.0 * M * lf.cin * lf.cout;
                 by += 4.0 * (M * NECK + (double)NECK * NECK + (double)lf.cin * lf.cout + 6.0 * M * h->grid.A);
@@ -1116,6 +1132,9 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
+    if (hipMalloc((void**)&h->range_flags, 3 * sizeof(unsigned)) != hipSuccess || hipMemset(h->range_flags, 0, 3 * sizeof(unsigned)) != hipSuccess) {
+        g_create_error = "yn_create: out of device memory"; delete h; return 1;
+    }
     *out = h;
     return 0;
 }
@@ -1144,6 +1163,7 @@ void yn_destroy(yn_handle* h)
     for (hipEvent_t e : h->fj_events) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
+    if (h->range_flags) (void)hipFree(h->range_flags);
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
@@ -1202,11 +1222,59 @@ int yn_set_pw_config(yn_handle* h, int index)
     h->force_pw_cfg = index < 0 ? -1 : index;
     return 0;
 }
+// The autotuner's table (layer shape -> fastest tile configuration), shared by every handle of the process, to / from a text file:
+// one line per entry, the device ordinal left out, so that the ranks of a multi-GPU job can adopt ONE rank's choices (identical
+// GPUs, identical shapes: eight ranks timing the same ~40 shapes at once only adds noise to each other's brackets and lets replicas
+// end up on different tiles).  Every configuration gives the same bits; this is a speed matter only.
+int yn_tune_save(const char* path, int device)
+{
+    if (!path) return 1;
+    FILE* f = fopen(path, "w");
+    if (!f) return 1;
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    for (const auto& kv : g_pw_tuned) {
+        if (kv.first.empty() || kv.first[0] != device) continue;
+        fprintf(f, "%d", kv.second);
+        for (size_t i = 1; i < kv.first.size(); ++i) fprintf(f, " %d", kv.first[i]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    return 0;
+}
+
+int yn_tune_load(const char* path, int device)
+{
+    if (!path) return -1;
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int n = 0;
+    char line[1024];
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    while (fgets(line, sizeof line, f)) {
+        std::vector<int> v;
+        char* p = line;
+        for (;;) {
+            char* e = nullptr;
+            const long x = strtol(p, &e, 10);
+            if (e == p) break;
+            v.push_back((int)x);
+            p = e;
+        }
+        if (v.size() < 2 || v[0] < 0 || v[0] >= pw_config_count()) continue;
+        std::vector<int> key;
+        key.push_back(device);
+        key.insert(key.end(), v.begin() + 1, v.end());
+        if (!g_pw_tuned.count(key)) { g_pw_tuned[key] = v[0]; ++n; }
+    }
+    fclose(f);
+    return n;
+}
+
 int yn_pw_config_count(void) { return pw_config_count(); }
 int yn_pw_f32_config_count(void) { return pw_f32_config_count(); }
 int yn_nms_prefilter(yn_handle* h, int mode)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if (mode < 0 || mode > 2) return fail(h, "yn_nms_prefilter: mode %d is not 0, 1 or 2", mode);
     if (mode != h->nms.prefilter) drop_graphs(h);
     h->nms.prefilter = mode;
@@ -1215,7 +1283,7 @@ int yn_nms_prefilter(yn_handle* h, int mode)
 
 int yn_down_fuse(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((enable != 0) != h->down_fuse) drop_graphs(h);
     h->down_fuse = enable != 0;
     return 0;
@@ -1223,7 +1291,7 @@ int yn_down_fuse(yn_handle* h, int enable)
 
 int yn_tail_fuse(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((enable != 0) != h->tail_fuse) drop_graphs(h);
     h->tail_fuse = enable != 0;
     return 0;
@@ -1231,7 +1299,7 @@ int yn_tail_fuse(yn_handle* h, int enable)
 
 int yn_group_launch(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((enable != 0) != h->group_launch) drop_graphs(h);
     h->group_launch = enable != 0;
     return 0;
@@ -1239,7 +1307,7 @@ int yn_group_launch(yn_handle* h, int enable)
 
 int yn_fuse_decode(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((enable != 0) != h->fuse_decode || enable != h->fuse_decode_mode) drop_graphs(h);
     h->fuse_decode = enable != 0;
     h->fuse_decode_mode = enable;
@@ -1248,7 +1316,7 @@ int yn_fuse_decode(yn_handle* h, int enable)
 
 int yn_exact_f32(yn_handle* h, int enable)
 {
-    if (!h) return 1;
+    YN_ENTER(h);
     if ((enable != 0) != h->exact_f32) drop_graphs(h);
     h->exact_f32 = enable != 0;
     return 0;
@@ -1320,6 +1388,7 @@ int yn_fold_bn(yn_handle* h)
             const Param* p = find_param(h, kv.first);
             if (p) HIPCHK(h, hipMemcpyAsync(p->dev, h->tP + kv.second, p->numel * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         }
+    HIPCHK(h, hipMemsetAsync(h->range_flags, 0, sizeof(unsigned), h->stream));
     for (Layer& l : h->layers) {
         const Param* w = find_param(h, l.conv + ".weight");
         if (!w) return fail(h, "missing parameter '%s.weight'", l.conv.c_str());
@@ -1364,14 +1433,34 @@ int yn_fold_bn(yn_handle* h)
             HIPCHK(h, hipMemsetAsync(l.ws_hi, 0, l.ws_bytes, h->stream));
             HIPCHK(h, hipMemsetAsync(l.ws_lo, 0, l.ws_bytes, h->stream));
         }
-        a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo;
+        a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo; a.w_ovf = h->range_flags;
         HIPCHK(h, hipMemsetAsync(l.w_packed, 0, packed_floats * sizeof(float), h->stream));
         HIPCHK(h, hipMemsetAsync(l.b_packed, 0, (size_t)((l.Npad + 31) & ~31) * sizeof(float), h->stream));
         a.w_ref = l.w_ref; a.b_ref = l.b_ref; a.w_packed = l.w_packed; a.b_packed = l.b_packed;
         launch_fold_pack(a, h->stream);
     }
     HIPCHK(h, hipGetLastError());
+    // Range guard of the split-f16 family (yn_device.h): a folded weight w * gamma / sqrt(var + eps) that does not fit x = hi + lo * 2^-11
+    // (|w| >= 65504) would make its hi part inf and every product NaN where the reference's fp32 conv is finite.  One flag, read once per
+    // fold: the handle then runs the f32-MFMA family as under yn_exact_f32(1) (yn_range_status reports it).
+    unsigned wflag = 0;
+    HIPCHK(h, hipMemcpyAsync(&wflag, h->range_flags, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((wflag != 0) != h->range_fallback) drop_graphs(h);
+    h->range_fallback = wflag != 0;
     h->folded = true;
+    return 0;
+}
+
+int yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow)
+{
+    YN_ENTER(h);
+    unsigned f = 0;
+    HIPCHK(h, hipMemcpyAsync(&f, h->range_flags + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (f) HIPCHK(h, hipMemsetAsync(h->range_flags + 1, 0, sizeof(unsigned), h->stream));
+    if (weights_exceed_f16) *weights_exceed_f16 = h->range_fallback ? 1 : 0;
+    if (activation_overflow) *activation_overflow = f ? 1 : 0;
     return 0;
 }
 
@@ -1673,9 +1762,16 @@ struct TmpLayer {
             if (hipMalloc(&l.ws_hi, l.ws_bytes) != hipSuccess || hipMalloc(&l.ws_lo, l.ws_bytes) != hipSuccess) { rc = 1; return; }
             (void)hipMemsetAsync(l.ws_hi, 0, l.ws_bytes, h->stream);
             (void)hipMemsetAsync(l.ws_lo, 0, l.ws_bytes, h->stream);
-            a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo;
+            a.ws_hi = l.ws_hi; a.ws_lo = l.ws_lo; a.w_ovf = h->range_flags + 2;
+            (void)hipMemsetAsync(h->range_flags + 2, 0, sizeof(unsigned), h->stream);
         }
         launch_fold_pack(a, h->stream);
+        if (l.ws_hi) {                                      // a weight outside the split's range: this operator runs on the f32-MFMA family
+            unsigned wflag = 0;
+            (void)hipMemcpyAsync(&wflag, h->range_flags + 2, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = 1; return; }
+            if (wflag) { (void)hipFree(l.ws_hi); (void)hipFree(l.ws_lo); l.ws_hi = l.ws_lo = nullptr; }
+        }
     }
     ~TmpLayer()
     {

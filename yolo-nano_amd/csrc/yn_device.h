@@ -7,6 +7,20 @@ namespace ynk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- range guard of the split-f16 family ----------------------------------------------------------------------------------
+// x = hi + lo * 2^-11 takes hi = (f16)x: finite only for |x| < 65520.  Beyond that hi = +-inf, lo = -+inf, the three-MFMA sum is
+// NaN (and a ReLU epilogue turns that NaN into 0), where the reference's fp32 conv is finite.  Every kernel that splits
+// activations keeps the running max |x| of what it splits (one v_max_f32 per element, next to the five VALU ops of the split itself)
+// and raises the handle's flag once per wavefront at its end; yn_range_status() reports it and the host shim re-runs on the f32-MFMA
+// family (yn_exact_f32).  Folded WEIGHTS are checked once, at yn_fold_bn (fold_pack_kernel).  Tiny values need no guard: below the f16
+// normal range hi loses bits (or flushes to 0) but lo = (x - hi) * 2^11 still carries x exactly to 11 bits more, i.e. an absolute
+// error <= 2^-25 * 2^-11 - far below the fp32 round-off of any accumulation that also holds O(1) terms.
+__device__ __forceinline__ float range_track(float amax, float x) { return __builtin_fmaxf(amax, __builtin_fabsf(x)); }
+__device__ __forceinline__ void range_report(unsigned* ovf, float amax)
+{
+    if (ovf && amax >= 65504.0f) atomicOr(ovf, 1u);         // +inf included; a NaN input is NaN in the reference too
+}
+
 // Activation without control flow: with a run-time `act` an if-chain compiles to branches PER VALUE in the unrolled epilogues (three
 // per accumulator register, ~250 in one pointwise-GEMM kernel).  x > 0 ? x : (act 1: +0, act 2: 0.1 x, act 0: 1.0 x = x); NaN takes
 // the second operand: the same bits as the if-chain this replaces.
@@ -162,6 +176,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
 
     float4 a_reg[A_PER][2];
     c3h16x8 b_reg[B_PER];
+    float amax = 0.0f;                                      // range guard: largest |activation| this thread has split
     auto prefetch = [&](int c) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
@@ -208,7 +223,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
                 const float x8[8] = {a_reg[i][0].x, a_reg[i][0].y, a_reg[i][0].z, a_reg[i][0].w, a_reg[i][1].x, a_reg[i][1].y, a_reg[i][1].z, a_reg[i][1].w};
                 c3h16x8 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { hi[j] = (c3h16)x8[j]; lo[j] = (c3h16)((x8[j] - (float)hi[j]) * 2048.0f); }
+                for (int j = 0; j < 8; ++j) { amax = range_track(amax, x8[j]); hi[j] = (c3h16)x8[j]; lo[j] = (c3h16)((x8[j] - (float)hi[j]) * 2048.0f); }
                 *reinterpret_cast<c3h16x8*>(Ah + (g / OQ) * AST + (g % OQ) * 8) = hi;
                 *reinterpret_cast<c3h16x8*>(Al + (g / OQ) * AST + (g % OQ) * 8) = lo;
             }
@@ -257,6 +272,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+    range_report(a.ovf, amax);
 }
 
 template <int V> struct VecT;

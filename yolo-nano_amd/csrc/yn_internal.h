@@ -21,6 +21,7 @@ struct GemmArgs {
     int dw_act;                                 // activation between the depthwise and the pointwise conv
     int dw_stride;                              // dwpw_tile_kernel: stride of the depthwise conv (H, W = its INPUT extent, M = output pixels)
     const void* Wsh; const void* Wsl;           // split-f16 packs of the same weights (hi, lo * 2^11): [taps][ceil(Cin/8)][Npad][8] halves, or null
+    unsigned* ovf;                              // split-f16 range guard (yn_device.h, range_report): set to 1 when an activation >= 65504 was split; or null
 };
 
 struct DwArgs {
@@ -42,6 +43,7 @@ struct ChainArgs {
     float* out; int out_ld;                     // next != null: first half of the shuffled output, [M][bf]; else the whole output [M][2*bf]
     float* t1n;                                 // next unit's depthwise input [M][bf]
     int B, H, W, bf, Npad, M;
+    unsigned* ovf;                              // split-f16 range guard flag or null
 };
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
 
@@ -57,6 +59,7 @@ struct DownArgs {
     const void *W3h, *W3l; const float* b3; int act3, Npad3;       // branch 1 pointwise cin -> bf
     float* out;                                 // [B][Ho][Wo][2*bf]: out[2n] = pass[n], out[2n+1] = pw2[n]
     int B, H, W, bf;
+    unsigned* ovf;                              // split-f16 range guard flag or null
 };
 // depthwise 3x3 (stride 1) + pointwise conv of a detection head as one kernel (kernels_chain.hip, dwpw_group_kernel): C = Cout = 96
 struct DwPwArgs {
@@ -65,6 +68,7 @@ struct DwPwArgs {
     const void *Wh, *Wl; const float* bias; int act, Npad;         // pointwise: split packs [C/8][Npad][8]
     float* out;                                 // [B][H][W][C] dense
     int B, H, W, C;
+    unsigned* ovf;                              // split-f16 range guard flag or null
 };
 bool dwpw_group_ok(const DwPwArgs* a, int n);
 void launch_dwpw_group(const DwPwArgs* a, int n, hipStream_t s);
@@ -98,6 +102,7 @@ struct FoldArgs {
     float* w_ref; float* b_ref;                 // folded, reference layout (for yn_get_folded) or null
     float* w_packed; float* b_packed;
     void* ws_hi; void* ws_lo;                   // GEMM kinds: split-f16 packs [kk][ceil(Cin/8)][Npad][8] (zero-initialised by the caller), or null
+    unsigned* w_ovf;                            // set to 1 when a folded GEMM weight does not fit the split (|w| >= 65504 or non-finite), or null
 };
 void launch_fold_pack(const FoldArgs& a, hipStream_t s);
 
@@ -242,6 +247,7 @@ struct HeadTailArgs {
     const void *Wh, *Wl; const float* bias; int act;    // pointwise 96 -> 96: split packs [12][96][8]
     const void *Wfh, *Wfl; const float* fbias; int Npad;   // last conv 96 -> A(5+C): split packs [12][Npad][8], bias [Npad]
     int B, H, W;
+    unsigned* ovf;                                      // split-f16 range guard flag or null
 };
 bool head_tail_ok(const HeadTailArgs* q, int n, const GridInfo& g);
 void launch_head_tail_group(const HeadTailArgs* q, int n, const GridInfo& g, float conf_thresh, float* boxes, float* scores, int32_t* cls, hipStream_t s);

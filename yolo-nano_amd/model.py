@@ -178,6 +178,7 @@ class YOLONano(nn.Module):
         self._stats_dirty = False            # handle BN statistics newer than the module's
         self.dp_average = True               # data-parallel: average gradients over ranks inside backward()
         self._train_dtype = "f32"            # arithmetic of the training step (train_precision)
+        self._exact_f32 = False              # set once an activation left the split-f16 range (_range_guarded): f32-MFMA kernels from then on
 
     def __deepcopy__(self, memo):
         """deepcopy (utils/misc.py:70 ModelEMA) must not clone the native handle; the copy builds its own."""
@@ -248,6 +249,8 @@ class YOLONano(nn.Module):
                                   self.use_diou_nms, max_batch=batch, device=first.device)
             self._handle_keys = keys
             self._handle.use_graph(self._graph)
+            if self._exact_f32:
+                self._handle.exact_f32(True)
             self._sig = None
         h = self._handle
         h.follow_current_stream()
@@ -307,15 +310,33 @@ class YOLONano(nn.Module):
                 cls[b, :k].cpu().numpy().astype(np.int64))
 
     # ---- forward ------------------------------------------------------------------------------------------
+    def _range_guarded(self, h, run):
+        """Run `run(h)` on the default (split-f16) family and check the handle's range guard (yn_range_status): if an activation
+        reached 65504 — outside x = hi + lo * 2^-11, where the reference's fp32 is still finite — switch the handle to the f32-MFMA
+        family for good and run again.  Costs one 4-byte read-back per call (the callers synchronise for their results anyway)."""
+        out = run(h)
+        if not self._exact_f32:
+            _, overflow = h.range_status()
+            if overflow:
+                import warnings
+                warnings.warn("yolo_nano_amd: an activation exceeded the split-f16 range (|x| >= 65504); re-running this and all later "
+                              "forwards of the model on the exact f32-MFMA kernels (yn_exact_f32)")
+                self._exact_f32 = True
+                h.exact_f32(True)
+                out = run(h)
+        return out
+
     def forward_raw(self, x):
         """Raw head tensors as the reference's hooks see them: three NCHW views [B, A(5+C), H, W]."""
         h = self.handle(x.shape[0])
-        return [t.permute(0, 3, 1, 2) for t in h.forward_raw(x.float())]
+        xf = x.float()
+        return [t.permute(0, 3, 1, 2) for t in self._range_guarded(h, lambda hh: hh.forward_raw(xf))]
 
     def forward_batch(self, x):
         """Eval-mode forward for EVERY image: list of (bboxes, scores, cls_inds) numpy triples."""
         h = self.handle(x.shape[0])
-        return h.detections_to_host(h.infer(x.float()))      # two device-to-host copies per batch (yn_pack_detections)
+        xf = x.float()
+        return h.detections_to_host(self._range_guarded(h, lambda hh: hh.infer(xf)))      # two device-to-host copies per batch (yn_pack_detections)
 
     # ---- training (models/yolo_nano.py:332-358, train.py:219-231) -----------------------------------------
     def _train_handle(self, batch):
@@ -398,14 +419,17 @@ class YOLONano(nn.Module):
                 raise YnError("trainable forward needs target [B, N, 11] (tools.multi_gt_creator layout)")
             return _TrainStep.apply(self, x, target, *list(self.parameters()))
         h = self.handle(x.shape[0])
-        out = h.infer(x.float())
+        xf = x.float()
+        out = self._range_guarded(h, lambda hh: hh.infer(xf))
         return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
 
 
 class ModelEMA(object):
     """utils/misc.py:67-86 with the same constructor / attributes (`ema`, `updates`, `decay`) and `update(model)`; the
-    in-place lerp of every floating-point state-dict entry runs as yn_ema_update — ONE launch over the flat parameter
-    buffer when model and EMA copy are both bound to their training buffers, one launch per tensor otherwise."""
+    in-place lerp of every floating-point state-dict entry runs as yn_ema_update — TWO launches per update: one over the flat
+    parameter buffer (model and EMA copy both bound to their training buffers) and one over the flat BatchNorm-statistics
+    buffer (the 148 running_mean / running_var tensors of model and copy are re-homed into one buffer each, same order);
+    one launch per tensor only for whatever cannot be re-homed (CPU / non-fp32 entries)."""
 
     def __init__(self, model, decay=0.9999, updates=0):
         import copy
@@ -416,31 +440,46 @@ class ModelEMA(object):
         self.decay = lambda x: decay * (1 - math.exp(-x / 2000.))
         for p in self.ema.parameters():
             p.requires_grad_(False)
-        # deepcopy gives every parameter its own storage: move the copy's parameters into one flat buffer (named_parameters
-        # order, the layout of the model's training buffers) so that update() is a single launch
-        ps = list(self.ema.parameters())
-        if ps and all(p.is_cuda and p.dtype == torch.float32 for p in ps):
-            flat = torch.empty(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
-            off = 0
-            for p in ps:
-                flat[off:off + p.numel()].copy_(p.data.reshape(-1))
-                p.data = flat[off:off + p.numel()].view(p.shape)
-                off += p.numel()
+        # deepcopy gives every tensor its own storage: move the copy's parameters / its float buffers into one flat buffer each
+        # (named_parameters / buffers order, the layout of the model's training buffers) so that update() is a single launch each
+        self._rehome(list(self.ema.parameters()))
+        self._rehome(self._float_buffers(self.ema))
+
+    @staticmethod
+    def _float_buffers(module):
+        return [b for b in module.buffers() if b.dtype.is_floating_point]
+
+    @staticmethod
+    def _rehome(tensors):
+        """Make every tensor of the list a view of ONE new flat float32 buffer (values kept); None when they cannot be."""
+        if not tensors or not all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
+            return None
+        flat = torch.empty(sum(t.numel() for t in tensors), dtype=torch.float32, device=tensors[0].device)
+        off = 0
+        for t in tensors:
+            flat[off:off + t.numel()].copy_(t.data.reshape(-1))
+            t.data = flat[off:off + t.numel()].view(t.shape)
+            off += t.numel()
+        return flat
+
+    @staticmethod
+    def _flat_view(tensors):
+        """The single contiguous buffer the tensors are consecutive views of (after _rehome / YOLONano._train_handle / a deepcopy
+        of either), else None."""
+        if not tensors or any(not t.is_cuda or t.dtype != torch.float32 for t in tensors):
+            return None
+        st = tensors[0].data.untyped_storage()
+        off = tensors[0].data.storage_offset()
+        base = off
+        for t in tensors:
+            if t.data.untyped_storage().data_ptr() != st.data_ptr() or t.data.storage_offset() != off or not t.data.is_contiguous():
+                return None
+            off += t.numel()
+        return torch.empty(0, dtype=torch.float32, device=tensors[0].device).set_(st, base, (off - base,))
 
     @staticmethod
     def _flat_of(module):
-        """The single contiguous buffer all parameters are views of (after YOLONano._train_handle / deepcopy of it), else None."""
-        ps = list(module.parameters())
-        if not ps or any(not p.is_cuda for p in ps):
-            return None
-        st = ps[0].data.untyped_storage()
-        off = ps[0].data.storage_offset()
-        base = off
-        for p in ps:
-            if p.data.untyped_storage().data_ptr() != st.data_ptr() or p.data.storage_offset() != off or not p.data.is_contiguous():
-                return None
-            off += p.numel()
-        return torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(st, base, (off - base,))
+        return ModelEMA._flat_view(list(module.parameters()))
 
     def update(self, model):
         m = model.module if hasattr(model, "module") else model
@@ -448,12 +487,24 @@ class ModelEMA(object):
             self.updates += 1
             d = self.decay(self.updates)
             h = m.handle() if getattr(m, "_handle", None) is None else m._handle
-            msd, esd = m.state_dict(), self.ema.state_dict()
-            fm, fe = self._flat_of(m), self._flat_of(self.ema)
+            msd, esd = m.state_dict(), self.ema.state_dict()           # (state_dict() first: it syncs the handle's running statistics in place)
             done = set()
+            fm, fe = self._flat_of(m), self._flat_of(self.ema)
             if fm is not None and fe is not None and fm.numel() == fe.numel():
                 h.ema_update(fe, fm, d)
                 done = {k for k, _ in m.named_parameters()}
+            # the BatchNorm statistics: one launch over the two flat buffers (the model's are re-homed on the first update)
+            mb, eb = self._float_buffers(m), self._float_buffers(self.ema)
+            if len(mb) == len(eb) and all(a.shape == b.shape for a, b in zip(mb, eb)):
+                fmb = self._flat_view(mb)
+                if fmb is None:
+                    fmb = self._rehome(mb)
+                feb = self._flat_view(eb)
+                if feb is None:
+                    feb = self._rehome(eb)
+                if fmb is not None and feb is not None and fmb.numel() == feb.numel():
+                    h.ema_update(feb, fmb, d)
+                    done |= {k for k, b in m.named_buffers() if b.dtype.is_floating_point}
             for k, v in esd.items():
                 if k in done or not v.dtype.is_floating_point:
                     continue
@@ -463,7 +514,6 @@ class ModelEMA(object):
                 else:
                     v *= d
                     v += (1. - d) * src
-            self.ema._sig = None                               # the EMA copy's folded weights are stale now
 
 
 class ValTransforms(object):

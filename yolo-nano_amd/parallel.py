@@ -16,10 +16,11 @@ def env_rank():
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run)."""
+def init(backend=None, device=None, force=False):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
+    force: build the process group for a one-rank job too (bench.py --spawn: the RCCL path at world size 1)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (force and "MASTER_PORT" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -46,6 +47,16 @@ def max_over_ranks(seconds, device="cpu"):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value, device="cpu"):
+    """Every rank's `value` (a float), in rank order, on every rank."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(v.item()) for v in out]
 
 
 def gather_results(local_results, dst=0):
@@ -135,7 +146,7 @@ def dp_train_step(handle, x, target, lr, momentum=0.9, weight_decay=5e-4):
     NaN-skip (train.py:225-226): yn_sgd_step leaves parameters and momentum untouched when the (all-reduced) gradient bucket
     holds a NaN/Inf — one rank's NaN loss makes the bucket non-finite on every rank, so all replicas skip together."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         losses = handle.train_step(x, target, lr, momentum, weight_decay, update=False)
         handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0)
         return losses
