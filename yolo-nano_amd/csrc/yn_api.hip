@@ -1132,7 +1132,10 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
-    if (hipMalloc((void**)&h->range_flags, 3 * sizeof(unsigned)) != hipSuccess || hipMemset(h->range_flags, 0, 3 * sizeof(unsigned)) != hipSuccess) {
+    // (hipMemsetAsync on the handle's stream, never hipMemset: ONE operation on the legacy null stream and every later launch of the
+    // process on torch's streams serialises against it - measured 38.2 k -> 32.6 k images/s with four handles, single-stream unchanged)
+    if (hipMalloc((void**)&h->range_flags, 3 * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(h->range_flags, 0, 3 * sizeof(unsigned), h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         g_create_error = "yn_create: out of device memory"; delete h; return 1;
     }
     *out = h;

@@ -15,11 +15,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // family (yn_exact_f32).  Folded WEIGHTS are checked once, at yn_fold_bn (fold_pack_kernel).  Tiny values need no guard: below the f16
 // normal range hi loses bits (or flushes to 0) but lo = (x - hi) * 2^11 still carries x exactly to 11 bits more, i.e. an absolute
 // error <= 2^-25 * 2^-11 - far below the fp32 round-off of any accumulation that also holds O(1) terms.
+#ifdef YN_EXP_NO_RANGE                                      // timing experiment only: the guard compiled out
+__device__ __forceinline__ float range_track(float amax, float) { return amax; }
+__device__ __forceinline__ void range_report(unsigned*, float) {}
+#else
 __device__ __forceinline__ float range_track(float amax, float x) { return __builtin_fmaxf(amax, __builtin_fabsf(x)); }
 __device__ __forceinline__ void range_report(unsigned* ovf, float amax)
 {
     if (ovf && amax >= 65504.0f) atomicOr(ovf, 1u);         // +inf included; a NaN input is NaN in the reference too
 }
+#endif
 
 // Activation without control flow: with a run-time `act` an if-chain compiles to branches PER VALUE in the unrolled epilogues (three
 // per accumulator register, ~250 in one pointwise-GEMM kernel).  x > 0 ? x : (act 1: +0, act 2: 0.1 x, act 0: 1.0 x = x); NaN takes
