@@ -617,6 +617,301 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
 #undef YN_TS
 }
 
+// -------------------------------------------------------------------------------------------------
+// unit_chain_split_kernel, second form (round 3).  What changed against the kernel above, and why (tools/chain_timing.sh: of a
+// block's ~50 k cycles only the first ~14 k move data from HBM; the rest is a chain of latency-bound phases with the memory idle):
+//   * the fp32 tile T32 and its two passes are gone.  The accumulator layout already gives every lane ONE column n and 16 rows:
+//     the lane loads x1[row][n] itself (16 * NT scalar loads at kernel start, 128-byte rows per half-wavefront), and after the
+//     first GEMM turns each accumulator value straight into its final place - out[row][2n .. 2n+1] = (x1, y) as one 8-byte
+//     store (columns n < bf/2 - or all of them in the last unit of a stage), or x2'[2(n - bf/2) ..] = split(x1, y) into the
+//     operand planes (columns n >= bf/2).  One barrier and ~9 k cycles of LDS round trips less per block; LDS 78 -> 64 KB at bf = 116.
+//   * (measured and dropped: a BALANCED launch - 96-row tiles on six wavefronts, ceil(M / CUs) = 88 live pixels each, one workgroup
+//     per CU instead of 64-pixel tiles that leave 82 CUs with two: the kernel went 25.7 -> 25.2 us, because six wavefronts sharing the
+//     LDS and matrix pipes stretch both GEMM phases from 6 k to 8.2 k cycles, and the 81 KB workgroup cost 6 % of the four-stream
+//     throughput, 39.2 k -> 36.8 k images/s)
+//   * K goes through LDS in chunks of KC = 64 instead of 32: half the barrier pairs inside the two GEMMs (two chunks at bf = 116;
+//     a chunk round costs ~2 k cycles whatever it multiplies).  Same k order (16-deep steps in sequence, zero-padded tail skipped):
+//     bit-identical to the first form and to gemm_split_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NT, int V, int KC>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void unit_chain2_kernel(ChainArgs a)
+{
+    typedef typename VecT<V>::type vec;
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN, OQ = KC / 8, NTHR = 64 * WM * WN;
+    constexpr int B_PER = (2 * OQ * BN + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float uc2_smem[];
+    const int bf = a.bf, W = a.W, H = a.H, HW = H * W;
+    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, nchunks = (bf + KC - 1) / KC;
+    uch16* Ph = reinterpret_cast<uch16*>(uc2_smem);                     // [BM][PS]
+    uch16* Pl = Ph + BM * PS;
+    uch16* Bh = Pl + BM * PS;                                           // [OQ][BN][8], then the lo plane
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
+    if (m0 >= a.M) return;
+    const int nrows = a.M - m0 < BM ? a.M - m0 : BM;                    // live rows of this tile
+
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
+    uch16x8 b_reg[B_PER];
+    auto prefetch_b = [&](const void* Wh, const void* Wl, int c) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + NTHR * i;
+            const int pl = g / (OQ * BN), r = g - pl * (OQ * BN);
+            const int o = r / BN, n = r - o * BN;
+            const int kq = c * OQ + o;
+            const bool ok = g < 2 * OQ * BN && kq < KQ && n < a.Npad;
+            uch16x8 v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? Wl : Wh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int g = t + NTHR * i;
+            if (g < 2 * OQ * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)g * 8) = b_reg[i];
+        }
+    };
+    float amax = 0.0f;                                                   // range guard (yn_device.h)
+    auto split_store = [&](int r, int c, float v0, float v1) {           // two adjacent channels of row r -> both planes
+        uch16x2 hi, lo;
+        amax = range_track(range_track(amax, v0), v1);
+        hi[0] = (uch16)v0; hi[1] = (uch16)v1;
+        lo[0] = (uch16)((v0 - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((v1 - (float)hi[1]) * 2048.0f);
+        *reinterpret_cast<uch16x2*>(Ph + r * PS + c) = hi;
+        *reinterpret_cast<uch16x2*>(Pl + r * PS + c) = lo;
+    };
+
+    float bias2[NT], bias1n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias1n[nt] = (a.Wp1n && n < bf) ? a.b1n[n] : 0.0f;
+    }
+    const int jhi = bf >> 1;
+    // the pass-through half in the ACCUMULATOR layout: x1v[nt][r] = x1[row(r)][n(nt)] (needed after the first GEMM)
+    float x1v[NT][16];
+    // wave-uniform base pointers + 32-bit lane offsets: the loads / stores below then use the saddr form instead of a 64-bit
+    // multiply-add per access
+    const char* x1_base = reinterpret_cast<const char*>(a.x1 + (size_t)m0 * a.x1_ld + a.x1_off);
+    auto x1_prefetch = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = wn * NT * 32 + nt * 32 + l31;
+            const bool nok = n < bf;
+            const unsigned mk = opaque_mask(nok);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int rr = row < nrows ? row : nrows - 1;           // clamped into the tile (idle rows are never stored)
+                const unsigned off = (unsigned)(rr * a.x1_ld + (nok ? n : 0)) * 4u;
+                x1v[nt][r] = __uint_as_float(__float_as_uint(*reinterpret_cast<const float*>(x1_base + off)) & mk);
+            }
+        }
+    };
+
+    // ---- 1. depthwise 3x3 of the block's pixels -> split planes (the same fma chain as dwconv3x3_kernel) ------------------------
+    {
+        const int cgn = bf / V, ppl = NTHR / cgn;
+        const int cg = t % cgn, pl = t / cgn, c = cg * V;
+        const bool worker = pl < ppl;
+        constexpr int R = 4;
+        auto issue = [&](int run, vec (&win)[3][R + 2]) {
+            const int q0 = m0 + run * R - 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int i = 0; i < R + 2; ++i) {
+                    int q = q0 + (dy - 1) * W + i;
+                    q = q < 0 ? 0 : (q >= a.M ? a.M - 1 : q);
+                    win[dy][i] = *reinterpret_cast<const vec*>(a.t1 + (size_t)q * a.t1_ld + a.t1_off + c);
+                }
+        };
+        vec w[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const vec*>(a.wdw + k * bf + c);
+        const vec bias = *reinterpret_cast<const vec*>(a.bdw + c);
+        auto finish = [&](int run, vec (&win)[3][R + 2]) {
+            const int mrun = m0 + run * R;
+            const int rem0 = (mrun < a.M ? mrun : m0) % HW;
+            int y = rem0 / W, x = rem0 - y * W;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int r = run * R + i;
+                const bool live = r < nrows;
+                const bool yk[3] = {live && y >= 1, live, live && y + 1 < H};
+                const bool xk[3] = {x >= 1, true, x + 1 < W};
+                vec acc = bias;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool ok = yk[ky] && xk[kx];
+                        vec v = win[ky][i + kx];
+                        if constexpr (V == 4) v = make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+                        else v = make_float2(ok ? v.x : 0.0f, ok ? v.y : 0.0f);
+                        vfma(acc, v, w[ky * 3 + kx]);
+                    }
+                acc = vact(acc, a.dw_act);
+                if constexpr (V == 4) { split_store(r, c, acc.x, acc.y); split_store(r, c + 2, acc.z, acc.w); }
+                else split_store(r, c, acc.x, acc.y);
+                if (++x == W) { x = 0; if (++y == H) y = 0; }
+            }
+        };
+        vec win[3][R + 2];
+        const int nruns = (nrows + R - 1) / R;
+        if (worker && pl < nruns) issue(pl, win);
+        prefetch_b(a.Ws2h, a.Ws2l, 0);
+        stage_b();
+        if (worker) {
+            for (int run = pl; run < nruns; run += ppl) {
+                finish(run, win);
+                if (run + ppl < nruns) issue(run + ppl, win);
+            }
+        }
+        // requested only now: the window registers are free again, and these loads (x1 is a quarter of the unit's traffic) fly during
+        // the first GEMM, when the memory system would otherwise sit idle
+        if (nchunks > 1) prefetch_b(a.Ws2h, a.Ws2l, 1);
+        x1_prefetch();
+        // K tail: the columns [bf, PS) of both planes are zero (they meet zero weight rows, but must not be NaN bit patterns)
+        const int padn = PS - bf;
+        for (int i = t; i < BM * padn; i += NTHR) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (uch16)0.0f; Pl[r * PS + c2] = (uch16)0.0f; }
+    }
+    __syncthreads();
+    YN_TS();
+
+    f32x16 acc0[NT], acc1[NT];
+    // entry state: chunk 0 staged (visible), chunk 1 requested into b_reg
+    auto gemm = [&](const void* Wh, const void* Wl) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+        for (int c = 0; c < nchunks; ++c) {
+            const uch16* Ahb = Ph + (wm * 32 + l31) * PS + c * KC + h * 8;
+            const uch16* Alb = Pl + (wm * 32 + l31) * PS + c * KC + h * 8;
+            const uch16* Bhb = Bh + (size_t)(h * BN + wn * NT * 32 + l31) * 8;
+            const uch16* Blb = Bhb + OQ * BN * 8;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                if (c * OQ + ks * 2 >= KQ) break;                       // wave-uniform: this 16-deep step lies beyond the (zero-padded) K
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                    const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nchunks) {
+                __syncthreads();                                        // every wave is done with this chunk's weights
+                stage_b();
+                __syncthreads();
+                if (c + 2 < nchunks) prefetch_b(Wh, Wl, c + 2);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+    };
+    gemm(a.Ws2h, a.Ws2l);
+    YN_TS();
+    if (a.Wp1n) prefetch_b(a.Ws1h, a.Ws1l, 0);
+    __syncthreads();                                                    // all waves are done reading the planes and the weights
+#ifdef YN_EXP_TIMING
+    const long long t_bar = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_x1 = __builtin_readcyclecounter();
+#endif
+
+    // ---- 2. y = act(acc + b2) straight to its final place: (x1, y) pairs -> global, or split into the planes as x2' ---------------
+    const bool last = a.Wp1n == nullptr;
+    const bool uniform8 = (nrows & 7) == 0;                             // wave-uniform: a row group of 8 is live or idle as a whole
+    char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * a.out_ld);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        const float bias = bias2[nt];
+        const bool to_global = n < (last ? bf : jhi);
+        const bool to_plane = !last && n >= jhi && n < bf;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = apply_act(acc0[nt][r] + bias, a.act2);
+        // ONE exec region per destination, scalar branches per row group (a per-value `if` compiles to a branch + waits around every
+        // store: measured 200 cycles each)
+        if (uniform8) {
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+                if (wm * 32 + 8 * g8 < nrows) {                         // scalar condition
+                    if (to_global) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = wm * 32 + q + 8 * g8 + 4 * h;
+                            *reinterpret_cast<float2*>(out_base + (unsigned)(row * a.out_ld + 2 * n) * 4u) = make_float2(x1v[nt][4 * g8 + q], y[4 * g8 + q]);
+                        }
+                    }
+                    if (to_plane) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) split_store(wm * 32 + q + 8 * g8 + 4 * h, 2 * (n - jhi), x1v[nt][4 * g8 + q], y[4 * g8 + q]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < nrows) {
+                    if (to_global) *reinterpret_cast<float2*>(out_base + (unsigned)(row * a.out_ld + 2 * n) * 4u) = make_float2(x1v[nt][r], y[r]);
+                    if (to_plane) split_store(row, 2 * (n - jhi), x1v[nt][r], y[r]);
+                }
+            }
+        }
+    }
+    YN_TS();
+    if (last) { range_report(a.ovf, amax); return; }
+    stage_b();
+    if (nchunks > 1) prefetch_b(a.Ws1h, a.Ws1l, 1);
+    __syncthreads();
+
+    // ---- 3. the next unit's pw1 on x2' -> global -------------------------------------------------------------------------------
+    YN_TS();
+    gemm(a.Ws1h, a.Ws1l);
+    YN_TS();
+    GemmArgs e{};
+    e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = m0 + nrows; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;      // rows beyond the tile's live ones are not stored
+    gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, (bf & 3) == 0, lane, bias1n);
+    range_report(a.ovf, amax);
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && (blockIdx.x % 97) == 5)
+        printf("chain2 bf %d blk %d dw %lld gemm1 %lld fused-epi %lld (barrier %lld x1wait %lld work %lld) stage %lld gemm2 %lld epi %lld total %lld\n", bf, (int)blockIdx.x, TS[1] - TS[0], TS[2] - TS[1],
+               TS[3] - TS[2], t_bar - TS[2], t_x1 - t_bar, TS[3] - t_x1, TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5], TS[6] - TS[0]);
+#endif
+#undef YN_TS
+}
+
+static size_t unit_chain2_lds(int bf, int BM, int BN, int KC)
+{
+    const int PS = ((bf + 7) / 8) * 8 + 8;
+    return ((size_t)2 * BM * PS + (size_t)2 * (KC / 8) * BN * 8) * 2;
+}
+
 static size_t unit_chain_split_lds(int bf, int BM, int BN)
 {
     const int PS = ((bf + 7) / 8) * 8 + 8;
@@ -659,6 +954,30 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
         hipLaunchKernelGGL((unit_chain_split_kernel<WMv, WNv, NTv, Vv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(256), lds, s, a); \
         return true;                                                                                                   \
     }
+#define YN_UC2(WMv, WNv, NTv, Vv, KCv)                                                                                 \
+    {                                                                                                                  \
+        constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
+        const size_t lds = unit_chain2_lds(a.bf, BM, BN, KCv);                                                         \
+        if (lds > 160 * 1024) return false;                                                                            \
+        if (dry) return true;                                                                                          \
+        static unsigned long long attr = 0;                                                                            \
+        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_chain2_kernel<WMv, WNv, NTv, Vv, KCv>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }              \
+        set_last_kernel_name("unit_chain2_kernel<" #WMv "," #WNv "," #NTv "," #Vv "," #KCv ">");                        \
+        hipLaunchKernelGGL((unit_chain2_kernel<WMv, WNv, NTv, Vv, KCv>), dim3(xcd_grid((a.M + BM - 1) / BM)), dim3(64 * WMv * WNv), lds, s, a); \
+        return true;                                                                                                   \
+    }
+    static const int chain_v = getenv("YN_CHAIN_V") ? atoi(getenv("YN_CHAIN_V")) : 2;      // 1: the round-2 kernel (A/B runs); 2: unit_chain2_kernel
+    if (a.Ws2h && chain_v >= 2) {
+        if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 64)
+        if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 64)
+        if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 64)
+        if (a.Npad == 256 && v4) YN_UCS(2, 2, 4, 4)             // NT = 4: 128 accumulator + 64 pass-through registers do not fit the second form
+        if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 32)
+        if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 32)
+        return false;
+    }
+#undef YN_UC2
     if (a.Ws2h) {                                            // split-f16 family
         if (a.Npad == 64 && !v4) YN_UCS(2, 2, 1, 2)
         if (a.Npad == 64 && v4) YN_UCS(2, 2, 1, 4)
