@@ -972,7 +972,7 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
         if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 64)
         if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 64)
         if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 64)
-        if (a.Npad == 256 && v4) YN_UCS(2, 2, 4, 4)             // NT = 4: 128 accumulator + 64 pass-through registers do not fit the second form
+        if (a.Npad == 256 && v4) YN_UC2(1, 4, 2, 4, 32)          // 32-row tiles, four wavefronts x 64 columns (NT = 4 would need 128 accumulator + 64 pass-through registers)
         if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 32)
         if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 32)
         return false;
