@@ -189,6 +189,18 @@ def train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
     """Secondary line (not BASELINE's headline metric): images/s of the full training step, data-parallel over ranks.
     -> the JSON line as a dict (brief: the few keys the default run embeds)."""
     from yolo_nano_amd import arch, capi, parallel, weights
+    if not os.environ.get("YN_TRAIN_NULL_STREAM"):
+        # a stream of its own, never the legacy null stream (its implicit synchronisation with every other stream of the process slows
+        # the step's side-stream overlap; the same effect cost the inference bench 15 %)
+        own = torch.cuda.Stream(device=dev)
+        own.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(own):
+            return _train_bench(args, rank, world, dev, dist, dtype, brief)
+    return _train_bench(args, rank, world, dev, dist, dtype, brief)
+
+
+def _train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
+    from yolo_nano_amd import arch, capi, parallel, weights
     B, S = args.batch, args.size
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if args.classes == 80 else arch.MULTI_ANCHOR_SIZE
     sd = weights.make_state_dict(args.backbone, args.classes)
@@ -271,9 +283,16 @@ def train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
                    "parallelism": "data-parallel x%d, one flat %.1f MB gradient all-reduce per step" % (world, n_param * 4 / 1e6)},
         "label_assigner": assign,
         "losses_last_step_rank0": lv, "finite": all(v == v and abs(v) < 1e30 for v in lv)}
+    # HBM floor of the step, layer-wise: every conv output written once in the forward pass and (with its gradient) read / written
+    # twice in the backward pass - 3 x activation bytes (weights and the 5.3 MB parameter traffic are noise beside it)
+    act_bytes = arch.activation_elements(S, args.backbone, args.classes) * (2 if dtype == "f16" else 4) * B
+    floor_ms = 3.0 * act_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
+    line["roofline"] = {"bound": "hbm", "alg_bytes_per_step": int(3 * act_bytes), "hbm_floor_ms": round(floor_ms, 4), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "achieved": round(3.0 * act_bytes / (elapsed / args.steps) / 1e9, 1), "frac": round(floor_ms / (elapsed / args.steps * 1e3), 4),
+                        "traffic": None, "kernel": "whole step (per-kernel table: profiles/r03_kernel_stats_train_608_bs32_%s.csv)" % dtype}
     h.close()
     if brief:
-        out = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite")}
+        out = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite", "roofline")}
         out["allreduce_us_per_step"] = allreduce_us
         out["per_rank_images_per_s"] = line["config"]["per_rank_images_per_s"]
         return out

@@ -1172,3 +1172,33 @@ def test_range_guard_whole_network_and_shim(capi):
         warnings.simplefilter("always")
         m(dev(x_np))
     assert not any("split-f16 range" in str(w_.message) for w_ in rec2)
+
+
+@pytest.mark.parametrize("B,S", [(5, 416), (1, 320)])
+def test_decode_skip_below_conf_is_exact(capi, B, S):
+    """The decode skips the class softmax of a wavefront whose four candidates all have sigmoid(obj) < conf_thresh (score = p * obj <= obj
+    in float arithmetic too).  With the objectness biases at YOLONano.init_bias's -4.595 (sigmoid = 0.01, models/yolo_nano.py:77-83) and
+    thresholds around 0.01 roughly half of the wavefronts skip: the kept sets, scores and boxes must still equal the oracle's postprocess
+    of the FULL score tensor (yn_score_full never skips), through the fused kernels (tail fusion / head+decode) and the stand-alone decode
+    kernel alike."""
+    sd = weights.make_state_dict("1.0x", 80)
+    for hd in (1, 2, 3):
+        sd["head_det_%d.4.bias" % hd][:3] = -4.595
+    h = capi.Handle(S, 80, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", 0.01, 0.5, max_batch=B)
+    try:
+        h.load_state_dict(sd); h.fold_bn()
+        x = dev(weights.make_input(B, S, seed=17))
+        bbox, cls = h.score_full(h.forward_raw(x))
+        obj_like = cls.sum(-1)                                            # = sigmoid(obj) (softmax sums to 1)
+        for conf_t in (0.0095, 0.0105, 0.02):
+            frac_below = float((obj_like < conf_t).float().mean())
+            if conf_t == 0.0105:
+                assert 0.2 < frac_below < 0.98, frac_below                # the skip really has something to skip, and not everything
+            for tail, fuse in ((True, 2), (False, 2), (False, 0)):        # head_tail kernel / head_decode kernel / decode_kernel
+                h.tail_fuse(tail); h.fuse_decode(fuse)
+                _, counts = _infer_vs_oracle(h, x, conf_t, 0.5)
+            if conf_t <= 0.0105:
+                assert sum(counts) > 0
+        h.tail_fuse(True); h.fuse_decode(1)
+    finally:
+        h.close()

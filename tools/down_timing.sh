@@ -1,4 +1,4 @@
 # phase cycle counts of down_unit_kernel (debug build with printf)
 YN_EXTRA_FLAGS=-DYN_EXP_TIMING python3 -c "from yolo_nano_amd import build; build.build(force=True)" > /dev/null 2>&1
-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extras --streams 1 --launch eager --profile-steps 0 2>/dev/null | grep "^downunit" | sort -k3,3n | awk 'NR%6==1' | tail -10
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extras --streams 1 --launch eager --profile-steps 1 2>&1 | grep "^downunit" | sort -k3,3n | awk 'NR%6==1' | tail -10
 python3 -c "from yolo_nano_amd import build; build.build(force=True)" > /dev/null 2>&1

@@ -150,6 +150,16 @@ def conv_flops(input_size, backbone="1.0x", num_classes=80):
     return total
 
 
+def activation_elements(input_size, backbone="1.0x", num_classes=80):
+    """Elements every convolution reads (its input, once) plus writes (its output, once), per image: the layer-wise activation
+    traffic behind the HBM floors of DESIGN 4 / 9 - 20.5 M at 416x416, 43.7 M at 608x608 (1.0x, COCO head)."""
+    total = 0
+    for sp in conv_specs(backbone, num_classes):
+        po = _out_pixels(sp, input_size)
+        total += sp.cout * po + sp.cin * po * sp.stride * sp.stride
+    return total
+
+
 def _out_pixels(sp, S):
     n = sp.name
     if n == "stem":

@@ -162,6 +162,17 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
     return false;
 }
 
+// models/yolo_nano.py:253-261 keeps a candidate only when score >= conf_thresh, and score = p_class * sigmoid(obj) with p_class <= 1:
+// in float arithmetic too, because e_c <= 1 <= sum and rounding is monotone, fl(fl(e_c / sum) * obj) <= obj.  So a candidate with
+// sigmoid(obj) < conf_thresh is out whatever its classes are, and when that holds for all (four) candidates of a wavefront the class
+// softmax - 80 exponentials, two row reductions, the arg-max - is skipped: score 0, class -1, exactly what the threshold would make of
+// it.  (A NaN objectness compares false and takes the full path; conf_thresh <= 0 never skips.)  With a trained model at the usual
+// deployment thresholds (0.1 ... 0.3) that is nearly every wavefront; with the benchmark's 0.001 on random weights none.
+__device__ __forceinline__ bool wave_below_conf(float obj_raw, float conf_thresh)
+{
+    return __all(sigmoid_f(obj_raw) < conf_thresh) != 0;
+}
+
 template <bool FULL, int KMAX>
 __device__ __forceinline__ void decode_candidate(const GridInfo& g, const float* row, int i, int s, int gx, int gy, int a, int j, float conf_thresh,
                                                  float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls,
@@ -172,7 +183,8 @@ __device__ __forceinline__ void decode_candidate(const GridInfo& g, const float*
     const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
     float sum, sc;
     int cbest;
-    if (!cand_class<FULL, KMAX>(g, row, i, a, j, obj_raw, sum, sc, cbest, all_class)) sc = 1.0f / sum * sigmoid_f(obj_raw);
+    if (!FULL && wave_below_conf(obj_raw, conf_thresh)) { sc = 0.0f; cbest = 0; }
+    else if (!cand_class<FULL, KMAX>(g, row, i, a, j, obj_raw, sum, sc, cbest, all_class)) sc = 1.0f / sum * sigmoid_f(obj_raw);
     // lane j evaluates coordinate j & 3 from box values (j & 1) and 2 + (j & 1) of its row (row_newbcast: lane n of the row to all)
     const float tc = (j & 1) ? dpp_f<0x151>(tbox) : dpp_f<0x150>(tbox), ts = (j & 1) ? dpp_f<0x153>(tbox) : dpp_f<0x152>(tbox);
     const float coord = decode_coord(g, s, gx, gy, a, tc, ts, (float)g.S, j & 3);
@@ -263,6 +275,7 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
         float sum, sc;
         int cbest;
         const float* rp = raw + row * LD;
+        if (wave_below_conf(rp[an], conf_thresh)) { if (j == 0) { st_sum[c] = 0.0f; st_cls[c] = (int)0x80000000; } continue; }
         const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
         if (j == 0) { st_sum[c] = fin ? sc : sum; st_cls[c] = fin ? (cbest | (int)0x80000000) : cbest; }
     }
@@ -587,6 +600,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
         float sum, sc;
         int cbest;
         const float* rp = raw + row * LD;
+        if (wave_below_conf(rp[an], conf_thresh)) { if (j == 0) { st_sum[cnd] = 0.0f; st_cls[cnd] = (int)0x80000000; } continue; }
         const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
         if (j == 0) { st_sum[cnd] = fin ? sc : sum; st_cls[cnd] = fin ? (cbest | (int)0x80000000) : cbest; }
     }
@@ -711,7 +725,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
                                                        int32_t* __restrict__ seg_count, int32_t* __restrict__ seg_off,
                                                        int32_t* __restrict__ tile_off, int32_t* __restrict__ bucket,
                                                        int32_t* __restrict__ keep, int32_t* __restrict__ large_list,
-                                                       int large_cap, int large_thresh)
+                                                       int large_cap, int large_thresh, int32_t* __restrict__ seg_order)
 {
     extern __shared__ int32_t lds[];            // hist[C], cursor[C]
     int32_t* hist = lds;
@@ -742,6 +756,15 @@ __global__ __launch_bounds__(1024) void bucket_kernel(const int32_t* __restrict_
         tile_off[(size_t)b * (C + 1) + C] = tiles;
         large_list[(size_t)b * (large_cap + 1)] = nlarge;
     }
+    // the image's classes by segment size, largest first (seg_order[rank] = class): per-segment kernels whose workgroups take as long
+    // as their segment is large start the long ones FIRST instead of wherever the class id puts them (C is small: rank by counting)
+    if (seg_order)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const int h = hist[c];
+            int rank = 0;
+            for (int o = 0; o < C; ++o) { const int ho = hist[o]; rank += (ho > h || (ho == h && o < c)) ? 1 : 0; }
+            seg_order[(size_t)b * C + rank] = c;
+        }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const int c = c_in[n];
@@ -908,15 +931,18 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
                                                     const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                     int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C,
                                                     int n_lo, int n_hi, u64* __restrict__ gscratch, size_t gscratch_stride,
-                                                    const int32_t* __restrict__ large_list, int large_cap)
+                                                    const int32_t* __restrict__ large_list, int large_cap, const int32_t* __restrict__ seg_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    const int b = blockIdx.y;
+    int b = blockIdx.y;
     int c = blockIdx.x;
     if (large_list) {                                       // grid.x indexes the image's list of large segments
         const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
         if (c >= ll[0]) return;
         c = ll[1 + c];
+    } else if (seg_order) {                                 // grid (B, C): largest segments of every image first (bucket_kernel's order)
+        b = blockIdx.x;
+        c = seg_order[(size_t)b * C + blockIdx.y];
     }
     const int n = seg_count[(size_t)b * C + c];
     if (n <= n_lo || n > n_hi) return;
@@ -1258,10 +1284,12 @@ __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, 
 
 __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                        const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
-                                                       int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep, int n_max)
+                                                       int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep, int n_max,
+                                                       const int32_t* __restrict__ seg_order)
 {
     __shared__ ResolveLds L;
-    const int c = blockIdx.x, b = blockIdx.y;
+    const int b = blockIdx.x;                               // grid (B, C): largest segments of every image first
+    const int c = seg_order ? seg_order[(size_t)b * C + blockIdx.y] : (int)blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
     if (n == 0 || n > n_max) return;                        // n > n_max: resolve_large_kernel's
     resolve_segment<0>(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
@@ -1306,10 +1334,14 @@ struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u6
 __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
                                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, float thresh, int32_t* __restrict__ keep,
-                                                             float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2)
+                                                             float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2,
+                                                             const int32_t* __restrict__ seg_order)
 {
     __shared__ PrefilterLds L;
-    const int c = blockIdx.x, b = blockIdx.y;
+    // grid (B, C): workgroups start in id order, x fastest - every image's LARGEST segment first (seg_order), then the second largest ...:
+    // the few 2 000-box segments of a batch, whose workgroups run 10x longer than the rest, no longer start behind 2 000 short ones
+    const int b = blockIdx.x;
+    const int c = seg_order ? seg_order[(size_t)b * C + blockIdx.y] : (int)blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
     if (n == 0) { if (threadIdx.x == 0) seg_count2[(size_t)b * C + c] = 0; return; }
     const int off = seg_off[(size_t)b * C + c];
@@ -1335,6 +1367,10 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
         }
         if ((alive >> lane) & 1ull) keep[(size_t)b * N + ids[lane]] = 1;
         if (lane == 0) L.keepm = alive;
+    }
+    if (T == 1) {                                           // nothing beyond chunk 0: no band, no scan, no survivors (most segments of a batch)
+        if (tid == 0) seg_count2[(size_t)b * C + c] = 0;
+        return;
     }
     __syncthreads();
     const u64 keepm = L.keepm;
@@ -1581,7 +1617,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     static const int skip = getenv("YN_DBG_NMS_SKIP") ? atoi(getenv("YN_DBG_NMS_SKIP")) : 0;
     mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
-                       wk.large_list, large_cap, YN_SORT_SMALL);
+                       wk.large_list, large_cap, YN_SORT_SMALL, wk.seg_order);
     float4* sbox = reinterpret_cast<float4*>(wk.sbox);
     u64* M = reinterpret_cast<u64*>(wk.matrix);
     mark("sort_kernel");
@@ -1589,18 +1625,18 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     if ((long)B * C <= 256) {
         // few segments (bs <= 3 at 80 classes): every one gets a 1024-thread / 128 KB-LDS workgroup, all resident at once - one launch
         // whose duration is the largest segment's sort instead of the small launch followed by the large one (64 -> 35 us at bs = 1)
-        hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                           N, C, 0, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0);
+        hipLaunchKernelGGL(sort_kernel, dim3(B, C), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, 0, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0, (const int32_t*)wk.seg_order);
     } else {
-    hipLaunchKernelGGL(sort_kernel, dim3(C, B), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                       N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(sort_kernel, dim3(B, C), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                       N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0, (const int32_t*)wk.seg_order);
     if (N > YN_SORT_SMALL)                                  // only the (few) listed large segments get a 128 KB-LDS workgroup
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                           N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)wk.large_list, large_cap);
+                           N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)wk.large_list, large_cap, (const int32_t*)nullptr);
     }
     if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
-                           N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap);
+                           N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, (const int32_t*)nullptr);
     }
     const int32_t* m_count = wk.seg_count;
     const int32_t* m_toff = wk.tile_off;
@@ -1610,8 +1646,8 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     // (small batches: the prefilter is two more launches in a serial chain - bs = 1 latency 0.69 -> 0.72 ms - for chip time nobody else wants)
     if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
-        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(C, B), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
-                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2);
+        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, wk.seg_order);
         hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2);
         m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
     }
@@ -1630,8 +1666,8 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
         hipLaunchKernelGGL(resolve_large_kernel, dim3(C, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
                            wk.keep, (const int32_t*)nullptr, 0, 0);
     } else if (!(skip & 4)) {
-        hipLaunchKernelGGL(resolve_kernel, dim3(C, B), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
-                           split ? YN_SORT_SMALL : 1 << 30);
+        hipLaunchKernelGGL(resolve_kernel, dim3(B, C), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
+                           split ? YN_SORT_SMALL : 1 << 30, (const int32_t*)wk.seg_order);
         if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
                                       wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
