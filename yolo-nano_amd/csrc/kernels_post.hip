@@ -166,11 +166,18 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
 // in float arithmetic too, because e_c <= 1 <= sum and rounding is monotone, fl(fl(e_c / sum) * obj) <= obj.  So a candidate with
 // sigmoid(obj) < conf_thresh is out whatever its classes are, and when that holds for all (four) candidates of a wavefront the class
 // softmax - 80 exponentials, two row reductions, the arg-max - is skipped: score 0, class -1, exactly what the threshold would make of
-// it.  (A NaN objectness compares false and takes the full path; conf_thresh <= 0 never skips.)  With a trained model at the usual
-// deployment thresholds (0.1 ... 0.3) that is nearly every wavefront; with the benchmark's 0.001 on random weights none.
-__device__ __forceinline__ bool wave_below_conf(float obj_raw, float conf_thresh)
+// it.  The test runs in LOGIT space so that the hot path pays one compare, not an exponential and a division per candidate:
+// obj_raw < logit(conf_thresh) - 0.01 implies sigmoid(obj_raw) < conf_thresh * (1 - ~1 %), a margin five orders of magnitude above the
+// float error of either side; candidates inside the margin simply take the full path.  (A NaN objectness compares false; conf_thresh
+// outside (0, 1) never skips.)  With a trained model at the usual deployment thresholds (0.1 ... 0.3) that is nearly every wavefront;
+// with the benchmark's 0.001 on random weights none.
+__device__ __forceinline__ float conf_skip_logit(float conf_thresh)
 {
-    return __all(sigmoid_f(obj_raw) < conf_thresh) != 0;
+    return (conf_thresh > 0.0f && conf_thresh < 1.0f) ? logf(conf_thresh / (1.0f - conf_thresh)) - 0.01f : -INFINITY;
+}
+__device__ __forceinline__ bool wave_below_conf(float obj_raw, float skip_logit)
+{
+    return __all(obj_raw < skip_logit) != 0;
 }
 
 template <bool FULL, int KMAX>
@@ -183,7 +190,7 @@ __device__ __forceinline__ void decode_candidate(const GridInfo& g, const float*
     const float tbox = row[g.A * (1 + g.C) + a * 4 + (j & 3)];
     float sum, sc;
     int cbest;
-    if (!FULL && wave_below_conf(obj_raw, conf_thresh)) { sc = 0.0f; cbest = 0; }
+    if (!FULL && wave_below_conf(obj_raw, conf_skip_logit(conf_thresh))) { sc = 0.0f; cbest = 0; }
     else if (!cand_class<FULL, KMAX>(g, row, i, a, j, obj_raw, sum, sc, cbest, all_class)) sc = 1.0f / sum * sigmoid_f(obj_raw);
     // lane j evaluates coordinate j & 3 from box values (j & 1) and 2 + (j & 1) of its row (row_newbcast: lane n of the row to all)
     const float tc = (j & 1) ? dpp_f<0x151>(tbox) : dpp_f<0x150>(tbox), ts = (j & 1) ? dpp_f<0x153>(tbox) : dpp_f<0x152>(tbox);
@@ -270,12 +277,13 @@ __device__ __forceinline__ void head_decode_block(const GemmArgs& a, const GridI
     int* st_cls = reinterpret_cast<int*>(st_sum + BM * g.A);              // [BM * A] class, bit 31 = st_sum holds the final score
     const int j = t & 15;
     const int ncand = min(BM, a.M - m0) * g.A;
+    const float skip_logit = conf_skip_logit(conf_thresh);
     for (int c = t >> 4; c < ncand; c += 16) {
         const int row = (int)(((unsigned)c * magicA) >> 16), an = c - row * g.A;
         float sum, sc;
         int cbest;
         const float* rp = raw + row * LD;
-        if (wave_below_conf(rp[an], conf_thresh)) { if (j == 0) { st_sum[c] = 0.0f; st_cls[c] = (int)0x80000000; } continue; }
+        if (wave_below_conf(rp[an], skip_logit)) { if (j == 0) { st_sum[c] = 0.0f; st_cls[c] = (int)0x80000000; } continue; }
         const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
         if (j == 0) { st_sum[c] = fin ? sc : sum; st_cls[c] = fin ? (cbest | (int)0x80000000) : cbest; }
     }
@@ -412,6 +420,13 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     const int b = tile / (ty_n * tx_n), trem = tile - b * (ty_n * tx_n);
     const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
 
+#ifdef YN_EXP_TIMING
+    long long TS[10]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
     // ---- 1. loads -----------------------------------------------------------------------------------------------------------------
     const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs of 4 pixels = 192 workers
     const bool worker = run < 8;
@@ -501,6 +516,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     }
     prefetch_b2(0);
     __syncthreads();
+    YN_TS();
     f32x16 m0, m1;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { m0[k] = 0.0f; m1[k] = 0.0f; }
@@ -521,6 +537,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
         }
     }
     __syncthreads();                                        // every operand read of the first GEMM is done: planes and weight space are free
+    YN_TS();
 
     // ---- 3. layer .3's output tile -> the planes (the last conv's A operand); its first weight chunk -> LDS ------------------------------
     if (wave < 3) {
@@ -538,6 +555,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     range_report(a.ovf, amax);                              // both split sites of this workgroup are behind it
     stage_b2();
     __syncthreads();
+    YN_TS();
     prefetch_b2(1);
 
     // ---- 4. the last conv: 32 x 256, wavefront = 64 columns ---------------------------------------------------------------------------
@@ -573,6 +591,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
         }
     }
 
+    YN_TS();
     // ---- 5. raw tile, per-row candidate index, decode ------------------------------------------------------------------------------------
     float* raw = reinterpret_cast<float*>(Bs);
 #pragma unroll
@@ -591,20 +610,23 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     }
     const unsigned magicA = (65536u + (unsigned)g.A - 1u) / (unsigned)g.A;     // c / A == (c * magicA) >> 16 for c < 32 * A <= 256
     __syncthreads();
+    YN_TS();
     float* st_sum = raw + NO * LD;                          // [32 * A] sum of exponentials, or the final score (general path)
     int* st_cls = reinterpret_cast<int*>(st_sum + NO * g.A);
     const int j = t & 15;
     const int ncand = NO * g.A;
+    const float skip_logit = conf_skip_logit(conf_thresh);
     for (int cnd = t >> 4; cnd < ncand; cnd += 16) {
         const int row = (int)(((unsigned)cnd * magicA) >> 16), an = cnd - row * g.A;
         float sum, sc;
         int cbest;
         const float* rp = raw + row * LD;
-        if (wave_below_conf(rp[an], conf_thresh)) { if (j == 0) { st_sum[cnd] = 0.0f; st_cls[cnd] = (int)0x80000000; } continue; }
+        if (wave_below_conf(rp[an], skip_logit)) { if (j == 0) { st_sum[cnd] = 0.0f; st_cls[cnd] = (int)0x80000000; } continue; }
         const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
         if (j == 0) { st_sum[cnd] = fin ? sc : sum; st_cls[cnd] = fin ? (cbest | (int)0x80000000) : cbest; }
     }
     __syncthreads();
+    YN_TS();
     for (int q = t; q < 5 * ncand; q += 256) {
         const bool is_score = q < ncand;
         const int cnd = is_score ? q : (q - ncand) >> 2, k = (q - ncand) & 3;
@@ -623,6 +645,13 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
             boxes[(size_t)i * 4 + k] = decode_coord(g, scale, ri.y, ri.z, an, tb[k & 1], tb[2 + (k & 1)], (float)g.S, k);
         }
     }
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && scale == 0 && (bid % 401) == 7)
+        printf("headtail blk %u loads+dw %lld gemm1 %lld split+stage %lld gemm2 %lld rawtile %lld passA %lld passBC %lld total %lld\n", bid, TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2],
+               TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5], TS[7] - TS[6], TS[7] - TS[0]);
+#endif
+#undef YN_TS
 }
 
 constexpr int HEAD_TAIL_HALVES = 2 * 32 * 104 + 2 * 12 * 96 * 8;        // planes + the larger of {W 96x96, a chunk of the last conv, the raw tile}
