@@ -264,6 +264,12 @@ int  yn_train_bind(yn_handle* h, float* params_dev, float* grads_dev, float* mom
 int  yn_train_step(yn_handle* h, const float* x_dev, const float* target_dev, int B, float lr, float momentum,
                    float weight_decay, float grad_scale, int do_update, float* losses_dev);
 int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_t numel);
+/* The fp16 step's dynamic loss scale (initial 1024; halved on an overflowing step, doubled after 2000 clean ones; all on the device).
+ * The decision is taken by yn_sgd_step from the finite-scan of the bucket it applies - after the data-parallel all-reduce that bucket is
+ * the same on every rank, so the replicas' scales move together.  get / set (both synchronise) let a checkpoint carry the scale and its
+ * clean-step counter across a resume; set before the first fp16 step replaces the default start value. */
+int  yn_train_get_loss_scale(yn_handle* h, float* scale, float* clean_steps);
+int  yn_train_set_loss_scale(yn_handle* h, float scale, float clean_steps);
 /* The gradient exchange of the data-parallel step (train.py:13-14 imports DistributedDataParallel; BASELINE configs[2]: "DDP grad
  * all-reduce over xGMI") for callers WITHOUT torch: all-reduce(sum), in place, of the bound flat gradient buffer over an RCCL
  * communicator the caller owns (`nccl_comm` is an ncclComm_t), enqueued on the handle's stream — after yn_train_step(do_update = 0),

@@ -261,3 +261,49 @@ def test_shim_trains_in_f16_with_the_reference_loop(golden):
     assert model._bound.skipped_steps() == 0
     with pytest.raises(yolo_nano_amd.YnError):
         model.train_precision("bf16")
+
+
+def test_h16_loss_scale_is_decided_by_the_reduced_bucket_and_can_be_restored(golden, monkeypatch):
+    """Data-parallel consistency of the dynamic loss scale: the decision to halve belongs to yn_sgd_step's finite-scan of the bucket
+    it applies - after the all-reduce that bucket is the same on every rank - not to the rank that overflowed.  Two handles stand in for
+    two ranks (the all-reduce is done by hand): only "rank 0" overflows, BOTH skip the update and BOTH halve.  A caller that never runs
+    yn_sgd_step (another optimiser on the flat buffers) still gets the back-off, from the local flag, at its next step.  The scale and its
+    clean-step counter can be read and restored (checkpoint resume)."""
+    g = golden("train.npz")
+    x = torch.as_tensor(weights.make_input(4, 128, seed=3)).cuda()
+    t = torch.as_tensor(_targets(128, 20, 4)).cuda()
+    monkeypatch.setenv("YN_LOSS_SCALE", str(2.0 ** 26))
+    h0, _ = _handle(128, 20, 4, float(g["init_bias_value"]))
+    h0.train_precision("f16")
+    h0.train_step(x, t, update=False)                           # creates the scale state at 2^26: overflows
+    monkeypatch.delenv("YN_LOSS_SCALE")
+    h1, _ = _handle(128, 20, 4, float(g["init_bias_value"]))
+    h1.train_precision("f16")
+    h1.set_loss_scale(512.0, 7.0)                               # restored before the first fp16 step
+    assert h1.loss_scale() == (512.0, 7.0)
+    h1.train_step(x, t, update=False)
+    assert not torch.isfinite(h0.flat_grads).all() and torch.isfinite(h1.flat_grads).all()
+    p0, p1 = h0.flat_params.clone(), h1.flat_params.clone()
+    red = h0.flat_grads + h1.flat_grads                         # all-reduce(sum) by hand
+    h0.flat_grads.copy_(red); h1.flat_grads.copy_(red)
+    for h in (h0, h1):
+        h.sgd_step(h.flat_params, h.flat_grads, h.flat_momentum, 1e-3, grad_scale=0.5)
+    assert torch.equal(h0.flat_params, p0) and torch.equal(h1.flat_params, p1)       # both skipped ...
+    assert h0.loss_scale() == (2.0 ** 25, 0.0) and h1.loss_scale() == (256.0, 0.0)   # ... and both backed off
+    assert h0.skipped_steps() == 1 and h1.skipped_steps() == 1
+    # a clean reduced bucket: both count a clean step, nobody halves
+    h1.train_step(x, t, update=False)
+    g1 = h1.flat_grads.clone()
+    h0.flat_grads.copy_(g1)
+    for h in (h0, h1):
+        h.sgd_step(h.flat_params, h.flat_grads, h.flat_momentum, 1e-3, grad_scale=0.5)
+    assert h1.loss_scale() == (256.0, 1.0) and not torch.equal(h1.flat_params, p1)
+    # no yn_sgd_step at all (torch.optim.SGD on the flat buffers): the next step settles the pending one from the local flag
+    h1.set_loss_scale(2.0 ** 26, 0.0)
+    h1.train_step(x, t, update=False)                           # overflows, stays pending
+    assert h1.loss_scale()[0] == 2.0 ** 26
+    h1.train_step(x, t, update=False)                           # settles the previous step first: halved
+    assert h1.loss_scale()[0] == 2.0 ** 25
+    with pytest.raises(Exception):
+        h1.set_loss_scale(0.5)
+    h0.close(); h1.close()

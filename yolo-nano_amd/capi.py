@@ -80,6 +80,8 @@ SIGNATURES = {
     "yn_train_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_train_skipped_steps": (_i32, [_vp, _i64p]),
     "yn_train_precision": (_i32, [_vp, _i32]),
+    "yn_train_get_loss_scale": (_i32, [_vp, ctypes.POINTER(_f32), ctypes.POINTER(_f32)]),
+    "yn_train_set_loss_scale": (_i32, [_vp, _f32, _f32]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "yn_preprocess": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "yn_preprocess_batch": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
@@ -558,6 +560,16 @@ class Handle:
         """All-reduce(sum) the flat gradient buffer in place over an RCCL communicator (an ncclComm_t as an int / c_void_p) on the
         handle's stream: the torch-free form of the gradient exchange (yn_allreduce_grads)."""
         self._ck(self.lib.yn_allreduce_grads(self.h, ctypes.c_void_p(nccl_comm if isinstance(nccl_comm, int) else nccl_comm.value)), "yn_allreduce_grads")
+
+    def loss_scale(self):
+        """(scale, clean steps) of the fp16 step's dynamic loss scale (yn_train_get_loss_scale; synchronises)."""
+        s, c = _f32(0), _f32(0)
+        self._ck(self.lib.yn_train_get_loss_scale(self.h, ctypes.byref(s), ctypes.byref(c)), "yn_train_get_loss_scale")
+        return float(s.value), float(c.value)
+
+    def set_loss_scale(self, scale, clean_steps=0.0):
+        """Restore the loss scale (and its clean-step counter) of a checkpoint (yn_train_set_loss_scale)."""
+        self._ck(self.lib.yn_train_set_loss_scale(self.h, float(scale), float(clean_steps)), "yn_train_set_loss_scale")
 
     def skipped_steps(self):
         n = ctypes.c_int64(0)

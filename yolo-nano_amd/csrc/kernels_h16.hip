@@ -1431,10 +1431,15 @@ void launch_rows_to_f32(const void* src, int is_h16, int src_ld, float* dst, int
 
 // =================================================================================================
 // Loss-scale bookkeeping, all on the device (no host round trip, capture-friendly).
-//   state[0] = current scale S, state[1] = 1/S, state[2] = clean steps since the last change (as float), state[3] = overflow flag
-// hgrad_finish_kernel: g = (g + sum of the atomics slots) / S, and raises the overflow flag when a value is not finite;
-// hscale_update_kernel (one thread, after it): overflow -> S /= 2 (>= 1), counter = 0; else counter++, and S *= 2 (<= 65536)
-// after 2000 clean steps.  The overflowed step's gradients stay non-finite in the bucket, so yn_sgd_step skips it.
+//   state[0] = current scale S, state[1] = 1/S, state[2] = clean steps since the last change (as float), state[3] = overflow flag of
+//   THIS rank's last backward pass, state[4] = 1 while that pass has not been accounted for yet.
+// hgrad_finish_kernel: g = (g + sum of the atomics slots) / S, raises the overflow flag when a value is not finite and marks the step
+// pending.  The scale itself moves in hscale_update_kernel: overflow -> S /= 2 (>= 1), counter = 0; else counter++, and S *= 2 (<= 65536)
+// after 2000 clean steps.  WHO decides "overflow": yn_sgd_step, from the finite-scan of the bucket it is about to apply (global != null)
+// - under data parallelism that is the ALL-REDUCED bucket, non-finite on every rank as soon as one rank overflowed, so every replica
+// halves (or grows) its scale on the same step and the scales never drift apart; a caller that applies the gradients with another
+// optimiser (torch.optim.SGD on the flat buffers) never reaches yn_sgd_step, and the next fp16 step then settles the pending one from
+// the local flag.  The overflowed step's gradients stay non-finite in the bucket, so yn_sgd_step skips it.
 // =================================================================================================
 __global__ __launch_bounds__(256) void hgrad_finish_kernel(float* __restrict__ g, const float* __restrict__ slots, long n, size_t stride, float* __restrict__ state)
 {
@@ -1449,17 +1454,21 @@ __global__ __launch_bounds__(256) void hgrad_finish_kernel(float* __restrict__ g
         g[i] = v;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned*>(state + 3), 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[4] = 1.0f;
 }
 
-__global__ void hscale_update_kernel(float* __restrict__ state)
+// global: the bucket-wide non-finite flag of yn_sgd_step (int[2], [0]) or null = settle a still-pending step from the local flag
+__global__ void hscale_update_kernel(float* __restrict__ state, const int* __restrict__ global)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[4] == 0.0f) return;                          // nothing pending (already settled, or no fp16 step since)
     float S = state[0], clean = state[2];
-    const unsigned over = *reinterpret_cast<unsigned*>(state + 3);
+    const unsigned over = global ? (unsigned)global[0] : *reinterpret_cast<unsigned*>(state + 3);
     if (over) { S = S > 1.0f ? S * 0.5f : 1.0f; clean = 0.0f; }
     else { clean += 1.0f; if (clean >= 2000.0f) { S = S < 65536.0f ? S * 2.0f : S; clean = 0.0f; } }
     state[0] = S; state[1] = 1.0f / S; state[2] = clean;
     *reinterpret_cast<unsigned*>(state + 3) = 0u;
+    state[4] = 0.0f;
 }
 
 void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, float* state, hipStream_t s)
@@ -1467,7 +1476,11 @@ void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, fl
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(hgrad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, slots, n, stride, state);
-    hipLaunchKernelGGL(hscale_update_kernel, dim3(1), dim3(64), 0, s, state);
+}
+
+void launch_hscale_update(float* state, const int* global_flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(hscale_update_kernel, dim3(1), dim3(64), 0, s, state, global_flag);
 }
 
 }  // namespace ynk

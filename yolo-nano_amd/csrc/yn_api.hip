@@ -115,7 +115,8 @@ struct yn_handle {
     std::vector<ynk::HPackDesc> hpack_jobs;   // recorded while the first fp16 step packs layer by layer; later steps pack everything in one launch
     ynk::HPackDesc* hpack_table = nullptr;     // device copy
     int hpack_table_n = 0;
-    float* scale_state = nullptr;         // device float[4]: loss scale, its inverse, clean-step counter, overflow flag (kernels_h16.hip)
+    float* scale_state = nullptr;         // device float[8]: loss scale, its inverse, clean-step counter, local overflow flag, step-pending mark (kernels_h16.hip)
+    float loss_scale_init = 0.0f, loss_scale_clean = 0.0f;   // yn_train_set_loss_scale before the first fp16 step (checkpoint resume)
     std::vector<hipEvent_t> train_events;
     char* train_arena = nullptr;
     size_t train_arena_bytes = 0;
@@ -1737,7 +1738,35 @@ int yn_sgd_step(yn_handle* h, float* params, const float* grads, float* momentum
         HIPCHK(h, hipMemsetAsync(h->skip_flag, 0, 2 * sizeof(int), h->stream));
     }
     launch_sgd(params, grads, momentum_buf, (long)n, lr, momentum, weight_decay, grad_scale, first_step, h->skip_flag, h->stream);
+    // the fp16 step's loss scale follows the finite-scan of THIS bucket (after a data-parallel all-reduce: the same decision on every rank)
+    if (h->scale_state && grads == h->tG) launch_hscale_update(h->scale_state, h->skip_flag, h->stream);
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int yn_train_get_loss_scale(yn_handle* h, float* scale, float* clean_steps)
+{
+    YN_ENTER(h);
+    float v[3] = {h->loss_scale_init >= 1.0f ? h->loss_scale_init : 1024.0f, 0.0f, h->loss_scale_clean};
+    if (h->scale_state) {
+        HIPCHK(h, hipMemcpyAsync(v, h->scale_state, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (scale) *scale = v[0];
+    if (clean_steps) *clean_steps = v[2];
+    return 0;
+}
+
+int yn_train_set_loss_scale(yn_handle* h, float scale, float clean_steps)
+{
+    YN_ENTER(h);
+    if (!(scale >= 1.0f) || !(scale <= 65536.0f) || !(clean_steps >= 0.0f)) return fail(h, "yn_train_set_loss_scale: scale must lie in [1, 65536], clean_steps >= 0");
+    h->loss_scale_init = scale; h->loss_scale_clean = clean_steps;
+    if (h->scale_state) {
+        const float v[3] = {scale, 1.0f / scale, clean_steps};
+        HIPCHK(h, hipMemcpyAsync(h->scale_state, v, sizeof v, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 

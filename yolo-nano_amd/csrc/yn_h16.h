@@ -85,6 +85,8 @@ void launch_hstage(const float* src, int C, h16* dst, int ld, int half, int gap,
 void launch_hunstage(const h16* src, int ld, int half, int gap, float* dst, int C, long M, hipStream_t s);
 void launch_rows_to_f32(const void* src, int is_h16, int src_ld, float* dst, int n, long M, hipStream_t s);
 void launch_hgrad_finish(float* g, const float* slots, long n, size_t stride, float* state, hipStream_t s);
+// settle the pending fp16 step's loss-scale decision: from yn_sgd_step's bucket-wide non-finite flag, or (null) from the local one
+void launch_hscale_update(float* state, const int* global_flag, hipStream_t s);
 // the loss on fp16 head tensors (kernels_train.hip): gradients are multiplied by the loss scale state[0] read on the device
 void launch_loss_h16(const h16* const head[3], h16* const ghead[3], const float* target, const GridInfo& g, int B, float* partial, float* losses,
                      const float* scale_state, hipStream_t s);
