@@ -1760,7 +1760,7 @@ int yn_train_get_loss_scale(yn_handle* h, float* scale, float* clean_steps)
 int yn_train_set_loss_scale(yn_handle* h, float scale, float clean_steps)
 {
     YN_ENTER(h);
-    if (!(scale >= 1.0f) || !(scale <= 65536.0f) || !(clean_steps >= 0.0f)) return fail(h, "yn_train_set_loss_scale: scale must lie in [1, 65536], clean_steps >= 0");
+    if (!(scale >= 1.0f) || !(scale <= 1073741824.0f) || !(clean_steps >= 0.0f)) return fail(h, "yn_train_set_loss_scale: scale must lie in [1, 2^30], clean_steps >= 0");
     h->loss_scale_init = scale; h->loss_scale_clean = clean_steps;
     if (h->scale_state) {
         const float v[3] = {scale, 1.0f / scale, clean_steps};
