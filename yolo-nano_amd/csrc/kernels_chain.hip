@@ -971,7 +971,12 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
     if (a.Ws2h && chain_v >= 2) {
         if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 64)
         if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 64)
+        // small maps (one image): 32-row tiles - twice the workgroups, and a workgroup's serial chain (one depthwise round instead of two,
+        // half the epilogue rows) is what a launch of a few dozen workgroups costs
+        static const int small_m = getenv("YN_CHAIN_SMALL_M") ? atoi(getenv("YN_CHAIN_SMALL_M")) : 4096;
+        if (a.Npad == 128 && v4 && a.M <= small_m) YN_UC2(1, 4, 1, 4, 64)
         if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 64)
+        if (a.Npad == 256 && v4 && a.M <= small_m / 2) YN_UC2(1, 4, 2, 4, 64)
         if (a.Npad == 256 && v4) YN_UC2(1, 4, 2, 4, 32)          // 32-row tiles, four wavefronts x 64 columns (NT = 4 would need 128 accumulator + 64 pass-through registers)
         if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 32)
         if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 32)

@@ -563,12 +563,12 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
     if (!h->unit_chain) return 0;
     const int bf = C / 2;
     const long M = (long)B * H * W;
-    // A chain kernel's block runs its phases back to back (17 / 26 / 35 us for bf = 58 / 116 / 232) whatever M is, so on small maps
-    // three latency-bound kernels with many small blocks win: bs=1 608x608 stage 3, M = 5 776: 29 vs 27 us.  Stage 4 at bs=32
-    // 416x416 (M = 5 408) chains since the 32-row tile of unit_chain2_kernel: 36 + 34 + 22 us against 3 x 40.
-    // unit_chain == 2 (tests) skips the size rule.
+    // Stages 2 and 3 (bf <= 128) chain at every size: on one image's maps the 32-row tiles of unit_chain2_kernel run a unit in 12 - 16 us
+    // against 8 + 6 + 8 for its three kernels (bs = 1: 0.620 -> 0.585 ms at 416 x 416, 0.757 -> 0.719 ms at 608 x 608).  Stage 4 (bf = 232: eight
+    // weight chunks per GEMM) chains from M = 4 096 pixels: 36 + 34 + 22 us against 3 x 40 at bs = 32 416 x 416 (M = 5 408), but 32 + 30 + 19
+    // against 3 x 29 on one image.  unit_chain == 2 (tests) skips the size rule.
     static const long min4 = getenv("YN_CHAIN_MIN4") ? atol(getenv("YN_CHAIN_MIN4")) : 4096;       // A/B: smallest M that chains the bf > 128 stage
-    if (h->unit_chain != 2 && M < (bf <= 64 ? 8192 : (bf <= 128 ? 16384 : min4))) return 0;
+    if (h->unit_chain != 2 && bf > 128 && M < min4) return 0;
     char nm[96];
     auto name = [&](int bi) { snprintf(nm, sizeof nm, "backbone.stage%d.%d", stage, bi); return std::string(nm); };
     {
