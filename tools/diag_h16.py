@@ -1,5 +1,5 @@
 """Diagnostic (not a test): per-parameter relative L2 error of the HIP fp16 / fp32 training step, of the fp32 oracle and of the
-fp16-storage emulation against the fp64 oracle.  python tests/diag_h16.py [S C B backbone]"""
+fp16-storage emulation against the fp64 oracle.  python tools/diag_h16.py [S C B backbone]"""
 import sys
 import numpy as np
 import torch

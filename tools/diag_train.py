@@ -1,5 +1,5 @@
 """Diagnostic (not a test): per-parameter gradient error of the HIP training step and of the fp32 torch port, both
-against the fp64 oracle.  python tests/diag_train.py [backbone S C B]"""
+against the fp64 oracle.  python tools/diag_train.py [backbone S C B]"""
 import sys, os
 import numpy as np
 import torch

@@ -23,7 +23,7 @@ namespace ynk {
 //   4. GEMM t_{i+1} = relu(T * W1' + b1') -> global.
 // Per unit: 1 launch instead of 3, 4 tensors of [M][bf] through memory instead of 8, no halo recompute.  All sums run in the
 // order of the separate kernels (same fma chain in the depthwise conv, same k order in the GEMMs): bit-identical results.
-// Measured (tools/chain_timing.sh, stage 3, M = 21 632, bf = 116; cycles per block): depthwise phase 20 k, GEMM 13.1 k each (two
+// Measured (tools/phase_timing.sh chain2, stage 3, M = 21 632, bf = 116; cycles per block): depthwise phase 20 k, GEMM 13.1 k each (two
 // co-resident blocks share the MFMA pipe: 2 x 7.4 k of MFMA issue), y->T 5.5 k, interleave 3.2 k, epilogue 5.6 k = 39 us per unit
 // against 46 us for the three kernels (stage 2: 42 vs 66, stage 4: 47 vs 45).  All blocks of the launch are resident at once and run their phases in lockstep, so the depthwise phase is the
 // whole chip fetching its ~35 MB at the same time (bandwidth-bound, MFMAs idle) and the GEMM phases leave the memory system
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
-// unit_chain_split_kernel, second form (round 3).  What changed against the kernel above, and why (tools/chain_timing.sh: of a
+// unit_chain_split_kernel, second form (round 3).  What changed against the kernel above, and why (tools/phase_timing.sh chain2: of a
 // block's ~50 k cycles only the first ~14 k move data from HBM; the rest is a chain of latency-bound phases with the memory idle):
 //   * the fp32 tile T32 and its two passes are gone.  The accumulator layout already gives every lane ONE column n and 16 rows:
 //     the lane loads x1[row][n] itself (16 * NT scalar loads at kernel start, 128-byte rows per half-wavefront), and after the

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
     };
     prefetch_b(0);
 
-    // ---- halo: 16-byte global loads (+ the fused resample-add), split, two 8-byte LDS stores per item.  Phase timing (tools/c3_timing.sh,
+    // ---- halo: 16-byte global loads (+ the fused resample-add), split, two 8-byte LDS stores per item.  Phase timing (tools/phase_timing.sh c3split,
     //      smooth_1: W = 52, one block per CU): halo 19 k cycles, nine taps 31.7 k (486 MFMAs = 15.5 k), epilogue 9 k per 128-pixel tile.
     //      The halo phase is BANDWIDTH-bound, not latency-bound: 180 KB per tile (halo factor 1.83 at W = 52 + the up2 source) at the
     //      ~10 B/clk/CU every CU gets when all of them stream at once; 24 loads in flight per thread instead of 8 changed nothing ----
