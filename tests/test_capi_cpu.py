@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
     exported = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (yn_[a-z0-9_]+)", exported))
     assert exported == set(declared)
-    assert lib.yn_abi_version() == 1
+    assert lib.yn_abi_version() == 2
 
 
 def test_library_is_gfx950_only():

@@ -633,8 +633,11 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
 //     a chunk round costs ~2 k cycles whatever it multiplies).  Same k order (16-deep steps in sequence, zero-padded tail skipped):
 //     bit-identical to the first form and to gemm_split_kernel.
 // -------------------------------------------------------------------------------------------------
+#ifndef YN_UC2_OCC_NARROW
+#define YN_UC2_OCC_NARROW 3                                 // workgroups per CU the 58-channel (stage 2) instantiation is compiled for
+#endif
 template <int WM, int WN, int NT, int V, int KC>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void unit_chain2_kernel(ChainArgs a)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V == 2) ? YN_UC2_OCC_NARROW : 2))) void unit_chain2_kernel(ChainArgs a)
 {
     typedef typename VecT<V>::type vec;
     constexpr int BM = 32 * WM, BN = 32 * NT * WN, OQ = KC / 8, NTHR = 64 * WM * WN;
@@ -976,7 +979,6 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
         static const int small_m = getenv("YN_CHAIN_SMALL_M") ? atoi(getenv("YN_CHAIN_SMALL_M")) : 4096;
         if (a.Npad == 128 && v4 && a.M <= small_m) YN_UC2(1, 4, 1, 4, 64)
         if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 64)
-        if (a.Npad == 256 && v4 && a.M <= small_m / 2) YN_UC2(1, 4, 2, 4, 64)
         if (a.Npad == 256 && v4) YN_UC2(1, 4, 2, 4, 32)          // 32-row tiles, four wavefronts x 64 columns (NT = 4 would need 128 accumulator + 64 pass-through registers)
         if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 32)
         if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 32)

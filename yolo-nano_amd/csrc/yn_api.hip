@@ -1101,7 +1101,7 @@ int run_maybe_graph(yn_handle* h, const std::vector<uintptr_t>& key, F body)
 #pragma GCC visibility push(default)
 extern "C" {
 
-int yn_abi_version(void) { return 1; }
+int yn_abi_version(void) { return 2; }       // 2: + yn_range_status, yn_allreduce_grads, yn_tune_save / yn_tune_load, yn_train_get / set_loss_scale
 
 const char* yn_last_error(yn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
