@@ -985,6 +985,98 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
                            reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
 }
 
+// ---- bucket + sort in ONE launch, for the few-segment case (B * C <= 256: one to three images) ---------------------------------------
+// bucket_kernel's histogram and scatter are LDS atomics, and with a skewed class distribution (the benchmark's random weights put a
+// quarter of an image's 10 647 candidates into one class) they serialise on ONE address at ~16 cycles each: 25 us for a kernel that
+// moves 40 KB - a fifth of the whole per-image NMS.  Here every (class, image) workgroup scans the image's class labels itself and
+// takes its own members with ballots (no atomics, ascending candidate order), reserves its place in the id / sorted-box arrays with ONE
+// atomic (segments may lie in any order: every consumer goes through seg_off), sorts (sort_segment), and the LAST workgroup of an image to
+// finish writes the tile offsets - the one prefix over the classes the matrix / resolve kernels need - and resets the counters.
+// ctr: [B][2] ints (position cursor, finished workgroups), zero on entry, zero on exit.
+__global__ __launch_bounds__(1024) void bucket_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ cls,
+                                                           int N, int C, int32_t* __restrict__ seg_count, int32_t* __restrict__ seg_off,
+                                                           int32_t* __restrict__ tile_off, int32_t* __restrict__ bucket, int32_t* __restrict__ keep,
+                                                           float4* __restrict__ sbox, u64* __restrict__ gscratch, size_t gscratch_stride, int32_t* __restrict__ ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    __shared__ int wcnt[16], s_n, s_off, s_last;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t* c_in = cls + (size_t)b * N;
+    for (int n = tid * C + c; n < N; n += 1024 * C) keep[(size_t)b * N + n] = 0;          // this workgroup's share of the keep flags: n = c (mod C)
+    // Each wavefront owns a contiguous range of the candidates (ascending ranges => ascending ids across wavefronts): pass 1 counts its
+    // members there, one barrier hands out the wavefronts' start positions, pass 2 compacts with ballots - no barrier inside either pass.
+    const int R = (((N + 15) >> 4) + 63) & ~63;             // candidates per wavefront, a multiple of 64
+    const int r0 = wave * R, r1 = min(N, r0 + R);
+    // (batches of eight labels per lane requested together: one load after the other is a memory round trip per 64 candidates)
+    int mine = 0;
+    for (int n0 = r0; n0 < r1; n0 += 512) {
+        int lab[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int n = n0 + 64 * q + lane; lab[q] = c_in[n < r1 ? n : r1 - 1]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) mine += (n0 + 64 * q + lane < r1 && lab[q] == c) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) wcnt[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < 16; ++w) { const int v = wcnt[w]; wcnt[w] = n; n += v; }      // exclusive prefix: the wavefronts' start positions
+        s_n = n;
+        s_off = n ? atomicAdd(&ctr[b * 2], n) : 0;
+        seg_count[(size_t)b * C + c] = n;
+        seg_off[(size_t)b * C + c] = s_off;
+    }
+    __syncthreads();
+    const int n_c = s_n, off = s_off;
+    if (n_c) {
+        int32_t* ids = bucket + (size_t)b * N + off;
+        int pos = wcnt[wave];
+        for (int n0 = r0; n0 < r1; n0 += 512) {
+            int lab[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int n = n0 + 64 * q + lane; lab[q] = c_in[n < r1 ? n : r1 - 1]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int n = n0 + 64 * q + lane;
+                const bool hit = n < r1 && lab[q] == c;
+                const u64 m = __ballot(hit);
+                if (hit) ids[pos + __popcll(m & ((1ull << lane) - 1ull))] = n;
+                pos += __popcll(m);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int P = nms_pow2(n_c);
+        if (n_c > YN_SORT_LARGE) sort_segment<false>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, ids, true, n_c, P, gscratch + (size_t)b * gscratch_stride, sbox + (size_t)b * N + off);
+        else sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, ids, true, n_c, P, reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
+    }
+    // the last workgroup of the image: tile offsets (prefix over the classes), counters back to zero
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&ctr[b * 2 + 1], 1) == C - 1 ? 1 : 0;
+    __syncthreads();
+    if (s_last) {                                           // (block-uniform)
+        __threadfence();
+        // the C counts with all loads in flight (one agent-scope load after the other is a memory round trip each: 80 x 0.6 us), then the prefix
+        int* cnt = reinterpret_cast<int*>(sort_lds);
+        for (int cc = tid; cc < C; cc += 1024) cnt[cc] = __hip_atomic_load(&seg_count[(size_t)b * C + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) {
+            int tiles = 0;
+            for (int cc = 0; cc < C; ++cc) {
+                tile_off[(size_t)b * (C + 1) + cc] = tiles;
+                const int T = (cnt[cc] + 63) >> 6;
+                tiles += T * (T + 1) / 2;
+            }
+            tile_off[(size_t)b * (C + 1) + C] = tiles;
+            ctr[b * 2] = 0; ctr[b * 2 + 1] = 0;
+        }
+    }
+}
+
 // ---- suppression bit-matrix ------------------------------------------------------------------------
 // Segment with T = ceil(n/64) chunks owns T(T+1)/2 tiles, stored by bands: band ri holds 64 rows x (T-ri) words,
 // word (row, ci-ri) at  band_off(ri) + row*(T-ri) + (ci-ri),  band_off(ri) = 64*(ri*T - ri*(ri-1)/2).
@@ -1644,14 +1736,25 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     auto mark = [&](const char* k) { if (hook && hook->fn) hook->fn(hook->ctx, k); };
     // YN_DBG_NMS_SKIP (timing ablation only, outputs are wrong): bit0 sort, bit1 matrix, bit2 resolve
     static const int skip = getenv("YN_DBG_NMS_SKIP") ? atoi(getenv("YN_DBG_NMS_SKIP")) : 0;
+    float4* sbox = reinterpret_cast<float4*>(wk.sbox);
+    u64* M = reinterpret_cast<u64*>(wk.matrix);
+    static const int fuse_bs = getenv("YN_NMS_FUSE_BUCKET") ? atoi(getenv("YN_NMS_FUSE_BUCKET")) : 1;       // A/B: 0 = bucket_kernel + sort_kernel also for few segments
+    const bool few = (long)B * C <= 256;
+    const int32_t* seg_order = wk.seg_order;                // bucket_kernel's size ranking; the fused kernel does not produce one (few segments: nothing to order)
+    if (few && fuse_bs && wk.ctr && !(skip & 1)) {
+        seg_order = nullptr;
+        static unsigned long long attr_bs = 0;
+        if (attr_pending(attr_bs)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
+        mark("bucket_sort_kernel");
+        hipLaunchKernelGGL(bucket_sort_kernel, dim3(C, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket,
+                           wk.keep, sbox, M, wk.matrix_stride, wk.ctr);
+    } else {
     mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
                        wk.large_list, large_cap, YN_SORT_SMALL, wk.seg_order);
-    float4* sbox = reinterpret_cast<float4*>(wk.sbox);
-    u64* M = reinterpret_cast<u64*>(wk.matrix);
     mark("sort_kernel");
     if (!(skip & 1)) {
-    if ((long)B * C <= 256) {
+    if (few) {
         // few segments (bs <= 3 at 80 classes): every one gets a 1024-thread / 128 KB-LDS workgroup, all resident at once - one launch
         // whose duration is the largest segment's sort instead of the small launch followed by the large one (64 -> 35 us at bs = 1)
         hipLaunchKernelGGL(sort_kernel, dim3(B, C), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
@@ -1667,6 +1770,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, (const int32_t*)nullptr);
     }
+    }
     const int32_t* m_count = wk.seg_count;
     const int32_t* m_toff = wk.tile_off;
     const int32_t* m_ids = wk.bucket;
@@ -1676,7 +1780,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
         hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
-                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, wk.seg_order);
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order);
         hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2);
         m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
     }
@@ -1696,7 +1800,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                            wk.keep, (const int32_t*)nullptr, 0, 0);
     } else if (!(skip & 4)) {
         hipLaunchKernelGGL(resolve_kernel, dim3(B, C), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
-                           split ? YN_SORT_SMALL : 1 << 30, (const int32_t*)wk.seg_order);
+                           split ? YN_SORT_SMALL : 1 << 30, seg_order);
         if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
                                       wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }

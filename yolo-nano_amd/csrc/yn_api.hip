@@ -338,7 +338,7 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off, (void**)&h->nms.large_list,
-                         (void**)&h->nms.seg_count2, (void**)&h->nms.tile_off2, (void**)&h->nms.seg_order};
+                         (void**)&h->nms.seg_count2, (void**)&h->nms.tile_off2, (void**)&h->nms.seg_order, (void**)&h->nms.ctr};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
@@ -347,6 +347,8 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_order, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.ctr, need_seg * sizeof(int32_t)));          // >= 2 * B ints
+        HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, need_seg * sizeof(int32_t), h->stream));
         h->nms_seg_cap = need_seg;
         drop_graphs(h);
     }
@@ -1162,7 +1164,7 @@ void yn_destroy(yn_handle* h)
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
-                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order};
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);

@@ -139,6 +139,7 @@ struct NmsWork {                                // per-handle scratch, sized for
     int32_t* bucket2; float* sbox2;             // [B][N], [B][N][4]: the candidates that survive the first-chunk prefilter, per segment at seg_off
     int32_t* seg_count2; int32_t* tile_off2;    // [B][C], [B][C+1] of that list
     int32_t* seg_order;                         // [B][C]  the image's class ids by segment size, largest first (bucket_kernel)
+    int32_t* ctr;                               // [B][2]  bucket_sort_kernel's position cursor / finished-workgroup count (zero between launches)
     int      prefilter;                         // 0 off, 1 for batches of >= 4 images, 2 always
     int      large_cap;
 };
