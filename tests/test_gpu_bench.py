@@ -131,3 +131,35 @@ def test_gpu_probe_does_not_initialise_hip():
     env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.split("COUNT")[1].strip() in ("None", "1")
+
+
+def test_tune_table_round_trip(tmp_path):
+    """yn_tune_save / yn_tune_load: the autotuner's choices of one process adopted by another (bench.py: one timing pass per multi-GPU
+    job) — the second process runs the same forward without timing anything, and the results are bit-identical (every tile
+    configuration of a family is)."""
+    path = str(tmp_path / "tune.txt")
+    code = r"""
+import sys, torch
+from yolo_nano_amd import arch, capi, weights
+h = capi.Handle(224, 20, arch.MULTI_ANCHOR_SIZE, "1.0x", max_batch=2)
+mode, path = sys.argv[1], sys.argv[2]
+if mode == "load":
+    n = capi.tune_load(path, 0)
+    assert n > 10, n
+    assert capi.tune_load(path, 0) == 0          # already present: nothing adopted twice
+h.load_state_dict(weights.make_state_dict("1.0x", 20)); h.fold_bn()
+x = torch.as_tensor(weights.make_input(2, 224, seed=5)).cuda()
+heads = [t.cpu() for t in h.forward_raw(x)]
+if mode == "save":
+    capi.tune_save(path, 0)
+torch.save(heads, path + "." + mode)
+assert capi.tune_load("/nonexistent/file", 0) == -1
+"""
+    for mode in ("save", "load"):
+        r = subprocess.run([sys.executable, "-c", code, mode, path], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    lines = open(path).read().strip().splitlines()
+    assert len(lines) > 10 and all(len(l.split()) >= 3 for l in lines)
+    import torch
+    a, b = torch.load(path + ".save"), torch.load(path + ".load")
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
