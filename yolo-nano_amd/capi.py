@@ -99,6 +99,8 @@ SIGNATURES = {
     "yn_op_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "yn_op_h16_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "yn_op_h16_bn": (_i32, [_vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yn_op_h16_bn_unit": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "yn_train_bn_fuse": (_i32, [_vp, _i32, _i32]),
     "yn_profile_enable": (_i32, [_vp, _i32]),
     "yn_profile_count": (_i32, [_vp]),
     "yn_profile_get": (_i32, [_vp, _i32, ctypes.c_char_p, _i32, ctypes.c_char_p, _i32, ctypes.POINTER(_f32),
@@ -694,6 +696,21 @@ class Handle:
         self._ck(self.lib.yn_op_h16_bn(self.h, self._in(y).data_ptr(), _ptr(self._in(dz) if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
                                        int(act), z.data_ptr(), _ptr(dy), _ptr(dg), _ptr(db)), "yn_op_h16_bn")
         return z, dy, dg, db
+
+    def op_h16_bn_unit(self, y, passthrough, gamma, beta, act=0, dunit=None):
+        """BatchNorm as the last layer of a ShuffleV2 unit: -> unit [M][2C] (and dy, deven, dgamma, dbeta when dunit [M][2C] is given)."""
+        M, C = y.shape
+        unit = torch.empty((M, 2 * C), dtype=torch.float32, device=y.device)
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=y.device) if dunit is not None else None
+        dy, dev, dg, db = mk(M, C), mk(M, C), mk(C), mk(C)
+        yc, pc, dc = self._in(y), self._in(passthrough), (self._in(dunit) if dunit is not None else None)
+        self._ck(self.lib.yn_op_h16_bn_unit(self.h, yc.data_ptr(), pc.data_ptr(), _ptr(dc), M, C, gamma.data_ptr(), beta.data_ptr(), int(act),
+                                            unit.data_ptr(), _ptr(dy), _ptr(dev), _ptr(dg), _ptr(db)), "yn_op_h16_bn_unit")
+        return unit, dy, dev, dg, db
+
+    def train_bn_fuse(self, enable=True, max_workgroups=0):
+        """One launch per BatchNorm and direction in the fp16 step (default) or the two-launch form; max_workgroups caps the fused grid (tests)."""
+        self._ck(self.lib.yn_train_bn_fuse(self.h, int(bool(enable)), int(max_workgroups)), "yn_train_bn_fuse")
 
     def to_nhwc(self, x):
         B, C, H, W = x.shape

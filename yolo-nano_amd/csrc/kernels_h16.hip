@@ -507,20 +507,21 @@ void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H,
 // the straddling octet and the ragged last one through 8 scalar loads per row, issued where they were needed: a full memory latency per
 // row for every wavefront holding such a lane — the reduce over a 10 MB stage-3 tensor took 23 us against 9 us for the statistics pass).
 struct DzOdd { int o0, o1, oe, sv, cut; bool load1, vec; };
-__device__ __forceinline__ DzOdd dz_odd_map(const HRedArgs& a, int p0)
+__device__ __forceinline__ DzOdd dz_odd_map_g(int C, int dz_ld, int half, int gap, int p0)
 {
     DzOdd m;
-    const int l0 = 2 * p0, half = a.dz_half, gap = a.dz_gap;
+    const int l0 = 2 * p0;
     m.o0 = l0 + (l0 >= half ? gap : 0);
     m.o1 = l0 + 8 + (l0 + 8 >= half ? gap : 0);
     m.sv = (l0 < half && half < l0 + 8) ? 0 : ((l0 + 8 < half && half < l0 + 16) ? 1 : -1);
     m.oe = m.sv >= 0 ? l0 + 8 * m.sv + gap : m.o0;
     m.cut = m.sv >= 0 ? half - (l0 + 8 * m.sv) : 8;
-    m.load1 = p0 + 4 < a.C;
-    m.vec = m.o0 + 8 <= a.dz_ld && (!m.load1 || m.o1 + 8 <= a.dz_ld) && m.oe + 8 <= a.dz_ld;
+    m.load1 = p0 + 4 < C;
+    m.vec = m.o0 + 8 <= dz_ld && (!m.load1 || m.o1 + 8 <= dz_ld) && m.oe + 8 <= dz_ld;
     if (!m.load1) m.o1 = m.o0;                              // pad channels only: any valid address, the values are never used
     return m;
 }
+__device__ __forceinline__ DzOdd dz_odd_map(const HRedArgs& a, int p0) { return dz_odd_map_g(a.C, a.dz_ld, a.dz_half, a.dz_gap, p0); }
 __device__ __forceinline__ void dz_odd_pick(const DzOdd& m, const h16x8& d0, const h16x8& d1, const h16x8& e, float (&g)[8])
 {
 #pragma unroll
@@ -699,6 +700,46 @@ void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
     else hipLaunchKernelGGL(hcol_reduce_kernel<3>, grid, dim3(256), 0, s, a);
 }
 
+// one row-octet of the BatchNorm forward output: dense (out has y's map, pads zero) or shuffle (out = the gapped unit output:
+// out[2c] = pass[c], out[2c+1] = z[c], pads zeroed) — shared by hbn_apply_kernel and hbn_fused_kernel<0>
+__device__ __forceinline__ void bn_apply_emit(h16* __restrict__ out, int out_ld, int out_off, bool shuffle, int out_half, int out_gap, int C, int act, long m, int p0, int ol,
+                                              const int (&lc)[8], const float (&mu)[8], const float (&is)[8], const float (&ga)[8], const float (&be)[8],
+                                              const h16x8& v, const h16x8& pv)
+{
+    float z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = lc[j] >= 0 ? hact(hbn_value((float)v[j], mu[j], is[j], ga[j], be[j]), act) : 0.0f;
+    if (!shuffle) {
+        h16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (h16)z[j];
+        sth8(out + (size_t)m * out_ld + out_off + p0, r);
+    } else {
+        h16* o = out + (size_t)m * out_ld;
+        const int l0 = 2 * p0;                                      // logical position of the octet's first output pair (y dense: physical == logical)
+        if (p0 + 8 <= C && (l0 + 16 <= out_half || l0 >= out_half)) {      // the 16 interleaved values do not straddle the plane boundary: two 16-byte stores
+            const int pp = l0 + (l0 >= out_half ? out_gap : 0);
+            h16x8 r0, r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { r0[2 * j] = pv[j]; r0[2 * j + 1] = (h16)z[j]; r1[2 * j] = pv[4 + j]; r1[2 * j + 1] = (h16)z[4 + j]; }
+            sth8(o + pp, r0); sth8(o + pp + 8, r1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = p0 + j;
+                if (c >= C) continue;
+                const int l = 2 * c;
+                const int pp = l + (l >= out_half ? out_gap : 0);
+                h16x2 w2; w2[0] = pv[j]; w2[1] = (h16)z[j];
+                *reinterpret_cast<h16x2*>(o + pp) = w2;
+            }
+        }
+        if (ol == 0 && out_gap > 0) {                               // the two pad runs of the gapped row
+            for (int q = 0; q < out_gap; ++q) { o[out_half + q] = (h16)0.0f; o[2 * out_half + out_gap + q] = (h16)0.0f; }
+        }
+    }
+}
+
 // ---- BatchNorm forward apply (batch statistics): z = act((y - mean) * invstd * gamma + beta), h16 in / out.
 //      Dense mode: out has y's channel map (pads written as zero).  Shuffle mode (pass != null): y dense [M][*] with C = bf
 //      channels, out = the gapped 2*bf-channel unit output: out[2c] = pass[c], out[2c+1] = z[c]  (concat + channel_shuffle,
@@ -742,38 +783,7 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
         mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c];
     }
     auto emit = [&](long m, h16x8 v, h16x8 pv) {
-        float z[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = lc[j] >= 0 ? hact(hbn_value((float)v[j], mu[j], is[j], ga[j], be[j]), a.act) : 0.0f;
-        if (!a.pass) {
-            h16x8 r;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (h16)z[j];
-            sth8(a.out + (size_t)m * a.out_ld + a.out_off + p0, r);
-        } else {
-            h16* o = a.out + (size_t)m * a.out_ld;
-            const int l0 = 2 * p0;                                      // logical position of the octet's first output pair (y dense: physical == logical)
-            if (p0 + 8 <= a.C && (l0 + 16 <= a.out_half || l0 >= a.out_half)) {      // the 16 interleaved values do not straddle the plane boundary: two 16-byte stores
-                const int pp = l0 + (l0 >= a.out_half ? a.out_gap : 0);
-                h16x8 r0, r1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { r0[2 * j] = pv[j]; r0[2 * j + 1] = (h16)z[j]; r1[2 * j] = pv[4 + j]; r1[2 * j + 1] = (h16)z[4 + j]; }
-                sth8(o + pp, r0); sth8(o + pp + 8, r1);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = p0 + j;
-                    if (c >= a.C) continue;
-                    const int l = 2 * c;
-                    const int pp = l + (l >= a.out_half ? a.out_gap : 0);
-                    h16x2 w2; w2[0] = pv[j]; w2[1] = (h16)z[j];
-                    *reinterpret_cast<h16x2*>(o + pp) = w2;
-                }
-            }
-            if (ol == 0 && a.out_gap > 0) {                             // the two pad runs of the gapped row
-                for (int q = 0; q < a.out_gap; ++q) { o[a.out_half + q] = (h16)0.0f; o[2 * a.out_half + a.out_gap + q] = (h16)0.0f; }
-            }
-        }
+        bn_apply_emit(a.out, a.out_ld, a.out_off, a.pass != nullptr, a.out_half, a.out_gap, a.C, a.act, m, p0, ol, lc, mu, is, ga, be, v, pv);
     };
     constexpr int U = 4;
     const long step = (long)gridDim.x * rowsPer;
@@ -871,6 +881,335 @@ void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hi
     HRedArgs a = a0;
     a.lanes = hlanes_for(a.Cp);
     hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a, dy, dgamma, dbeta);
+}
+
+// =================================================================================================
+// One launch per BatchNorm and direction (round 3): statistics + apply, or backward sums + dy, in ONE kernel around a grid-wide
+// barrier.  The two-launch form reads y twice forward and (dz, y) twice backward; here a workgroup keeps the rows it summed —
+// the first RH of a thread in registers, the next `hold` in LDS — and only rows beyond that are read again after the barrier, so a
+// tensor up to CUs x 256 threads x (RH + hold) x 16 B (about 20 MB forward, 12 MB backward: stages 3-4, the 38x38 / 19x19 pyramid
+// levels and most of stage 2) crosses the memory system once per direction, and 148 launches per step disappear.
+// Grid: at most one workgroup per CU, 256 threads, <= 70 KB of LDS — all workgroups are co-resident by construction (two such
+// kernels from two processes on one GPU still fit side by side; anything else on the chip finishes without waiting for us).
+// Barrier: two-level arrival counters (32 groups -> one top-level count) so that no address takes more than 32 serial device-scope
+// atomics, spin on the top-level count with s_sleep; a 200 ms timeout sets a.err instead of hanging the GPU.
+// Sums: fp32 inside a thread (two levels: per batch of <= 8 rows, then across batches), double from the first cross-lane step on.
+// =================================================================================================
+constexpr int BNF_T = 256;
+template <int MODE> struct BnfCfg;
+template <> struct BnfCfg<0> { static constexpr int RH = 8, U = 4, HOLD = 12; };
+template <> struct BnfCfg<1> { static constexpr int RH = 4, U = 2, HOLD = 6; };
+
+__device__ __forceinline__ double ld_agent_f64(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// every thread of every workgroup of the grid calls this once; false = timed out (results are garbage, *err is set)
+__device__ __forceinline__ bool bnf_grid_barrier(unsigned* bar, int* err)
+{
+    __shared__ int ok_s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned G = gridDim.x, NG = G < 32u ? G : 32u;
+        const unsigned grp = blockIdx.x % NG, gsize = (G - grp + NG - 1) / NG;
+        __threadfence();
+        const unsigned prev = __hip_atomic_fetch_add(bar + 8 + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < NG) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 20000000ull) { ok = 0; if (err) atomicOr(err, 1); break; }     // 100 MHz: 200 ms
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+// this layer's gradient octet (channels p0..p0+7) of row `row`, as stored halves; `ev` (dz_odd only) gets the EVEN logical channels of
+// the same 16 values — the pass-through half of the unit gradient (backbone/shufflenetv2.py:70-74 backwards)
+__device__ __forceinline__ h16x8 bnf_load_g(const HBnFusedArgs& a, const DzOdd& dm, size_t row, int p0, h16x8& ev)
+{
+    if (!a.dz_odd) { ev = zero8(); return ldh8(a.dz + row * a.dz_ld + a.dz_off + p0); }
+    h16x8 g;
+    if (dm.vec) {
+        const h16* q = a.dz + row * a.dz_ld;
+        const h16x8 d0 = ldh8(q + dm.o0), d1 = ldh8(q + dm.o1), e = ldh8(q + dm.oe);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 2 * j + 1, k = 2 * j;
+            g[j] = (dm.sv == 0 && i >= dm.cut) ? e[i] : d0[i];
+            ev[j] = p0 + j < a.C ? ((dm.sv == 0 && k >= dm.cut) ? e[k] : d0[k]) : (h16)0.0f;
+            g[4 + j] = dm.load1 ? ((dm.sv == 1 && i >= dm.cut) ? e[i] : d1[i]) : (h16)0.0f;
+            ev[4 + j] = (dm.load1 && p0 + 4 + j < a.C) ? ((dm.sv == 1 && k >= dm.cut) ? e[k] : d1[k]) : (h16)0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = p0 + j;
+            const int l = 2 * c + 1, k = 2 * c;
+            g[j] = c < a.C ? a.dz[row * a.dz_ld + l + (l >= a.dz_half ? a.dz_gap : 0)] : (h16)0.0f;
+            ev[j] = c < a.C ? a.dz[row * a.dz_ld + k + (k >= a.dz_half ? a.dz_gap : 0)] : (h16)0.0f;
+        }
+    }
+    return g;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BNF_T) void hbn_fused_kernel(HBnFusedArgs a)
+{
+    constexpr int RH = BnfCfg<MODE>::RH, U = BnfCfg<MODE>::U;
+    extern __shared__ __align__(16) unsigned char bnf_lds[];
+    h16x8* held = reinterpret_cast<h16x8*>(bnf_lds);                   // [hold][T] of y, then (MODE 1) [hold][T] of the gradient
+    __shared__ double red[4][32][16];
+    __shared__ float cst[6][256];
+    const int tid = threadIdx.x;
+    const int OL = a.lanes, rowsPer = BNF_T / OL;
+    const int ol = tid & (OL - 1), rl = tid / OL;
+    const int OC = a.Cp >> 3;
+    const bool live = ol < OC;
+    const int p0 = live ? ol * 8 : 0;
+    const int hold = a.hold;
+    int lc[8];
+    float mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lc[j] = live ? logical_of(p0 + j, a.C, a.half, a.gap) : -1;
+        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
+        if (MODE == 1 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
+    }
+    DzOdd dm{};
+    if (MODE == 1 && a.dz_odd) dm = dz_odd_map_g(a.C, a.dz_ld, a.dz_half, a.dz_gap, p0);
+    const long step = (long)gridDim.x * rowsPer;
+    const long first = (long)blockIdx.x * rowsPer;
+    const long rbase = first + rl;
+    const int nsweep = first < a.M ? (int)((a.M - first + step - 1) / step) : 0;       // uniform over the workgroup
+
+    // ---------------- phase 1: load, keep, sum ----------------
+    float s0[8], s1[8], t0[8], t1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = s1[j] = t0[j] = t1[j] = 0.0f; }
+    auto accum = [&](const h16x8& v, const h16x8& g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float yv = (float)v[j];
+            if (MODE == 0) { t0[j] += yv; t1[j] = __fmaf_rn(yv, yv, t1[j]); }
+            else {
+                const float d = hact_grad((float)g[j], hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+                const float xh = (yv - mu[j]) * is[j];
+                t0[j] += d; t1[j] = __fmaf_rn(d, xh, t1[j]);
+            }
+        }
+    };
+    auto fold = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += t0[j]; s1[j] += t1[j]; t0[j] = 0.0f; t1[j] = 0.0f; }
+    };
+    h16x8 rv[RH], rg[RH], rev[RH];
+#pragma unroll
+    for (int u = 0; u < RH; ++u) {
+        const long r = rbase + u * step;
+        const bool ok = live && r < a.M;
+        const size_t row = (size_t)(ok ? r : 0);
+        rv[u] = keep8(ldh8(a.y + row * a.y_ld + a.y_off + p0), ok);
+        if (MODE == 1) { rg[u] = keep8(bnf_load_g(a, dm, row, p0, rev[u]), ok); }
+    }
+    for (int k = RH; k < nsweep; k += U) {
+        h16x8 v[U], g[U], ev[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = rbase + (long)(k + u) * step;
+            const bool ok = live && r < a.M;
+            const size_t row = (size_t)(ok ? r : 0);
+            v[u] = keep8(ldh8(a.y + row * a.y_ld + a.y_off + p0), ok);
+            if (MODE == 1) g[u] = keep8(bnf_load_g(a, dm, row, p0, ev[u]), ok);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = k + u - RH;
+            if (slot < hold) {
+                held[(size_t)slot * BNF_T + tid] = v[u];
+                if (MODE == 1) {
+                    held[(size_t)(hold + slot) * BNF_T + tid] = g[u];
+                    if (a.even) held[(size_t)(2 * hold + slot) * BNF_T + tid] = ev[u];
+                }
+            }
+            accum(v[u], g[u]);
+        }
+        fold();
+    }
+#pragma unroll
+    for (int u = 0; u < RH; ++u) accum(rv[u], rg[u]);
+    fold();
+
+    // ---------------- combine: row-lanes of a wave by shuffles (double), waves through LDS, one atomic per channel and sum ----------------
+    double d0[8], d1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d0[j] = (double)s0[j]; d1[j] = (double)s1[j]; }
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int off = 32; off >= OL; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { d0[j] += __shfl_xor(d0[j], off); d1[j] += __shfl_xor(d1[j], off); }
+    }
+    if (lane < OL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[wave][lane][j] = d0[j]; red[wave][lane][8 + j] = d1[j]; }
+    }
+    __syncthreads();
+    if (tid < OL && live) {
+        double* acc = a.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * a.C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (lc[j] < 0) continue;
+            atomicAdd(acc + lc[j], (red[0][ol][j] + red[1][ol][j]) + (red[2][ol][j] + red[3][ol][j]));
+            atomicAdd(acc + a.C + lc[j], (red[0][ol][8 + j] + red[1][ol][8 + j]) + (red[2][ol][8 + j] + red[3][ol][8 + j]));
+        }
+        __threadfence();
+    }
+    if (!bnf_grid_barrier(a.bar, a.err)) return;
+
+    // ---------------- per-channel constants from the complete sums ----------------
+    const double invM = 1.0 / (double)a.M;
+    for (int c = tid; c < a.C; c += BNF_T) {
+        double m = 0.0, q = 0.0;
+#pragma unroll 8
+        for (int sl = 0; sl < HACC_SLOTS; ++sl) { m += ld_agent_f64(a.acc + ((size_t)sl * 2) * a.C + c); q += ld_agent_f64(a.acc + ((size_t)sl * 2 + 1) * a.C + c); }
+        if (MODE == 0) {
+            m *= invM;
+            double var = q * invM - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mu_c = (float)m, is_c = (float)(1.0 / sqrt(var + (double)a.eps));
+            cst[0][c] = mu_c; cst[1][c] = is_c; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+            if (blockIdx.x == 0) {
+                a.mean_out[c] = mu_c; a.invstd_out[c] = is_c;
+                if (a.rmean) {
+                    const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
+                    a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu_c;
+                    a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+                }
+            }
+        } else {
+            cst[4][c] = (float)(m * invM); cst[5][c] = (float)(q * invM);
+            if (blockIdx.x == 0) { a.dbeta[c] = (float)m; a.dgamma[c] = (float)q; }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float m0[8], m1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lc[j] >= 0 ? lc[j] : 0;
+        if (MODE == 0) { mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c]; m0[j] = m1[j] = 0.0f; }
+        else { m0[j] = cst[4][c]; m1[j] = cst[5][c]; }
+    }
+
+    // ---------------- phase 2: apply to what was kept, re-read only what was not ----------------
+    auto emit = [&](long m, const h16x8& v, const h16x8& g, const h16x8& ev, const h16x8& pv) {
+        if (MODE == 0) {
+            bn_apply_emit(a.out, a.out_ld, a.out_off, a.pass != nullptr, a.out_half, a.out_gap, a.C, a.act, m, p0, ol, lc, mu, is, ga, be, v, pv);
+        } else {
+            h16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float yv = (float)v[j];
+                const float d = hact_grad((float)g[j], hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
+                const float xh = (yv - mu[j]) * is[j];
+                r[j] = lc[j] >= 0 ? (h16)((ga[j] * is[j]) * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
+            }
+            sth8(a.dy + (size_t)m * a.Cp + p0, r);
+            if (a.even) sth8(a.even + (size_t)m * a.even_ld + p0, ev);
+        }
+    };
+    {
+        h16x8 pv[RH];
+#pragma unroll
+        for (int u = 0; u < RH; ++u) {
+            const long r = rbase + u * step;
+            pv[u] = (MODE == 0 && a.pass && r < a.M) ? ldh8(a.pass + (size_t)r * a.pass_ld + a.pass_off + p0) : zero8();
+        }
+#pragma unroll
+        for (int u = 0; u < RH; ++u) {
+            const long r = rbase + u * step;
+            if (r < a.M) emit(r, rv[u], rg[u], rev[u], pv[u]);
+        }
+    }
+    const int kh = nsweep < RH + hold ? nsweep : RH + hold;
+    for (int k = RH; k < kh; ++k) {
+        const long r = rbase + (long)k * step;
+        if (r >= a.M) break;
+        const int slot = k - RH;
+        const h16x8 v = held[(size_t)slot * BNF_T + tid];
+        h16x8 g = zero8(), ev = zero8(), pv = zero8();
+        if (MODE == 1) { g = held[(size_t)(hold + slot) * BNF_T + tid]; if (a.even) ev = held[(size_t)(2 * hold + slot) * BNF_T + tid]; }
+        if (MODE == 0 && a.pass) pv = ldh8(a.pass + (size_t)r * a.pass_ld + a.pass_off + p0);
+        emit(r, v, g, ev, pv);
+    }
+    for (int k = RH + hold; k < nsweep; k += U) {
+        h16x8 v[U], g[U], ev[U], pv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = rbase + (long)(k + u) * step;
+            ok[u] = r < a.M;
+            const size_t row = (size_t)(ok[u] ? r : 0);
+            v[u] = ldh8(a.y + row * a.y_ld + a.y_off + p0);
+            g[u] = ev[u] = pv[u] = zero8();
+            if (MODE == 1) g[u] = bnf_load_g(a, dm, row, p0, ev[u]);
+            if (MODE == 0 && a.pass) pv[u] = ldh8(a.pass + row * a.pass_ld + a.pass_off + p0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) emit(rbase + (long)(k + u) * step, v[u], g[u], ev[u], pv[u]);
+    }
+}
+
+static int bnf_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+// false: this layer cannot take the fused form (the caller launches the two-kernel form)
+bool launch_hbn_fused(const HBnFusedArgs& a0, int mode, hipStream_t s)
+{
+    static const int enabled = getenv("YN_BN_FUSED") ? atoi(getenv("YN_BN_FUSED")) : 1;
+    static const int gcap = getenv("YN_BNF_G") ? atoi(getenv("YN_BNF_G")) : 0;
+    static const int rows_min = getenv("YN_BNF_ROWS") ? atoi(getenv("YN_BNF_ROWS")) : 4;
+    if (!enabled || a0.C > 256 || a0.Cp > 256 || !a0.bar) return false;
+    HBnFusedArgs a = a0;
+    a.lanes = hlanes_for(a.Cp);
+    const int rowsPer = BNF_T / a.lanes;
+    int cap = bnf_cus();
+    if (gcap > 0 && gcap < cap) cap = gcap;
+    if (a.gcap > 0 && a.gcap < cap) cap = a.gcap;
+    long G = ((long)a.M + (long)rowsPer * rows_min - 1) / ((long)rowsPer * rows_min);
+    if (G > cap) G = cap;
+    if (G < 1) G = 1;
+    const long sweeps = ((long)a.M + G * rowsPer - 1) / (G * rowsPer);
+    const int RH = mode ? BnfCfg<1>::RH : BnfCfg<0>::RH, HOLD = mode ? BnfCfg<1>::HOLD : BnfCfg<0>::HOLD;
+    const int planes = mode ? (a.even ? 3 : 2) : 1;
+    long hold = sweeps - RH;
+    if (hold < 0) hold = 0;
+    const int hmax = mode ? (HOLD * 2) / planes : HOLD;
+    if (hold > hmax) hold = hmax;
+    a.hold = (int)hold;
+    const size_t lds = (size_t)hold * planes * BNF_T * sizeof(h16x8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, BnfCfg<0>::HOLD * BNF_T * (int)sizeof(h16x8));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BnfCfg<1>::HOLD * BNF_T * (int)sizeof(h16x8));
+        attr_set = true;
+    }
+    if (mode == 0) hipLaunchKernelGGL(hbn_fused_kernel<0>, dim3((unsigned)G), dim3(BNF_T), lds, s, a);
+    else hipLaunchKernelGGL(hbn_fused_kernel<1>, dim3((unsigned)G), dim3(BNF_T), lds, s, a);
+    return true;
 }
 
 // =================================================================================================
