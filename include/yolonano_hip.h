@@ -328,14 +328,9 @@ int  yn_op_h16_bn(yn_handle* h, const float* y, const float* dz, int64_t M, int 
 /* The same BatchNorm as the last layer of a ShuffleV2 unit (backbone/shufflenetv2.py:69-78 with :14-28): forward writes the unit
  * output unit[m][2c] = pass[m][c], unit[m][2c+1] = act(BN(y))[m][c]  ([M][2C]: concat + channel_shuffle(2));  backward takes the unit
  * output's gradient dunit [M][2C] and returns dy [M][C] (through activation and BatchNorm), deven [M][C] = dunit[:, 0::2] (the
- * pass-through half, written by the same kernel), dgamma, dbeta [C].  C <= 128. */
+ * pass-through half, written by the backward kernel on its way: it loads those values anyway), dgamma, dbeta [C].  C <= 128. */
 int  yn_op_h16_bn_unit(yn_handle* h, const float* y, const float* pass, const float* dunit, int64_t M, int C, const float* gamma, const float* beta,
                        int act, float* unit, float* dy, float* deven, float* dgamma, float* dbeta);
-/* The fp16 step runs every BatchNorm as ONE launch per direction (statistics + apply / sums + dy around a grid-wide barrier, at most
- * one workgroup per CU: hbn_fused_kernel).  enable = 0 selects the two-launch form (A/B measurements; required when more than two
- * processes train on ONE GPU at the same time — the barrier needs its grid co-resident and reports a timeout as an error otherwise).
- * max_workgroups > 0 caps the fused kernels' grid (tests: makes small tensors take the kept-in-LDS and re-read paths); 0 = one per CU. */
-int  yn_train_bn_fuse(yn_handle* h, int enable, int max_workgroups);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, every kernel launch of yn_forward_raw / yn_infer is bracketed by a pair of HIP

@@ -357,7 +357,7 @@ def test_multi_scale_training_through_set_grid(golden, precision):
     The size of such a jump is not bounded by any precision argument (soak runs: 5.0e-2 - 7.9e-2 on every layer upstream of the
     flip on one run in two, nothing on the other), so the per-gradient bar against the oracle is a gross-error bar only: max(8x the
     fp32 oracle's own error, 0.25) for f32 and 2.5x the fp16-storage emulation's error + 0.25 for f16, plus a cosine >= 0.98 between
-    the whole flat gradient and the oracle's.  The sharp statements are the other three: losses to 1e-4 (f32), the fresh-handle
+    the whole flat gradient and the oracle's (f16: no more than 0.1 below the emulation's own cosine).  The sharp statements are the other three: losses to 1e-4 (f32), the fresh-handle
     identity to 1e-5 at each size change, and the un-updated first step against train.npz in test_train_step_matches_reference_fixture."""
     from yolo_nano_amd import capi
     from oracle.torch_port import TrainNet
@@ -414,7 +414,9 @@ def test_multi_scale_training_through_set_grid(golden, precision):
             assert not bad, "phase %d (S=%d) step %d: (name, err, yardstick) %s" % (phase, S, it, bad[:8])
             va = np.concatenate([_grad(h, n, g64[n].shape).astype(np.float64).ravel() for n in live])
             ve = np.concatenate([g64[n].ravel() for n in live])
-            assert float(va @ ve / (np.linalg.norm(va) * np.linalg.norm(ve))) >= 0.98, (phase, it)
+            cos = lambda u, w: float(u @ w / (np.linalg.norm(u) * np.linalg.norm(w)))
+            vy = np.concatenate([gy[n].ravel() for n in live])                 # the yardstick's own direction error (fp16 storage: 0.85-0.9 on this network)
+            assert cos(va, ve) >= (0.98 if precision == "f32" else min(0.98, cos(vy, ve) - 0.1)), (phase, it, cos(va, ve), cos(vy, ve))
             assert not torch.equal(h.flat_params, before)                        # the update was applied
     assert seen_N[0] == seen_N[2] != seen_N[1]
     # and the eval path after the size changes: fold the trained weights, infer at a third size

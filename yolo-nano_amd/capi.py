@@ -100,7 +100,6 @@ SIGNATURES = {
     "yn_op_h16_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "yn_op_h16_bn": (_i32, [_vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "yn_op_h16_bn_unit": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "yn_train_bn_fuse": (_i32, [_vp, _i32, _i32]),
     "yn_profile_enable": (_i32, [_vp, _i32]),
     "yn_profile_count": (_i32, [_vp]),
     "yn_profile_get": (_i32, [_vp, _i32, ctypes.c_char_p, _i32, ctypes.c_char_p, _i32, ctypes.POINTER(_f32),
@@ -707,10 +706,6 @@ class Handle:
         self._ck(self.lib.yn_op_h16_bn_unit(self.h, yc.data_ptr(), pc.data_ptr(), _ptr(dc), M, C, gamma.data_ptr(), beta.data_ptr(), int(act),
                                             unit.data_ptr(), _ptr(dy), _ptr(dev), _ptr(dg), _ptr(db)), "yn_op_h16_bn_unit")
         return unit, dy, dev, dg, db
-
-    def train_bn_fuse(self, enable=True, max_workgroups=0):
-        """One launch per BatchNorm and direction in the fp16 step (default) or the two-launch form; max_workgroups caps the fused grid (tests)."""
-        self._ck(self.lib.yn_train_bn_fuse(self.h, int(bool(enable)), int(max_workgroups)), "yn_train_bn_fuse")
 
     def to_nhwc(self, x):
         B, C, H, W = x.shape

@@ -556,6 +556,25 @@ __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, 
     }
 }
 
+// Two channels per instruction: the streaming BatchNorm kernels are instruction-bound at one wavefront per SIMD (16 VALU operations per
+// element in the first form: 2.1 ms per 608 / bs-32 step for the backward sums alone), and gfx950 has packed fp32 multiply / add / fma.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pair_of(const h16x8& v, int p) { f32x2 r; r.x = (float)v[2 * p]; r.y = (float)v[2 * p + 1]; return r; }
+__device__ __forceinline__ f32x2 splat2(float x) { f32x2 r; r.x = x; r.y = x; return r; }
+// xhat and the BatchNorm value with exactly hbn_value's operation sequence (sub, mul, fma): the sign of z decides the activation's branch
+// and has to come out the same in the forward apply, the backward sums and the backward apply
+__device__ __forceinline__ f32x2 bn_xhat2(f32x2 y, f32x2 mu, f32x2 is) { return (y - mu) * is; }
+__device__ __forceinline__ f32x2 bn_value2(f32x2 xh, f32x2 ga, f32x2 be) { return __builtin_elementwise_fma(xh, ga, be); }
+// d = g * act'(z): g where z > 0, else g * negslope (0 / 0.1 / 1 for ReLU / LeakyReLU(0.1) / none)
+__device__ __forceinline__ f32x2 act_grad2(f32x2 g, f32x2 z, float negslope)
+{
+    f32x2 m;
+    m.x = z.x > 0.0f ? 1.0f : negslope;
+    m.y = z.y > 0.0f ? 1.0f : negslope;
+    return g * m;
+}
+__device__ __forceinline__ float act_negslope(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.1f : 1.0f); }
+
 template <int MODE>
 __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
 {
@@ -568,17 +587,22 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
     int lc[8];
-    float mu[8], is[8], ga[8], be[8];
+    f32x2 mu[4], is[4], ga[4], be[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lc[j] = live ? logical_of(p0 + j, a.C, a.half, a.gap) : -1;
-        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
-        if (MODE == 2 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
+    for (int j = 0; j < 8; ++j) lc[j] = live ? logical_of(p0 + j, a.C, a.half, a.gap) : -1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        mu[p] = is[p] = ga[p] = be[p] = splat2(0.0f);
+        if (MODE == 2) {
+            if (lc[2 * p] >= 0) { mu[p].x = a.mean[lc[2 * p]]; is[p].x = a.invstd[lc[2 * p]]; ga[p].x = a.gamma[lc[2 * p]]; be[p].x = a.beta[lc[2 * p]]; }
+            if (lc[2 * p + 1] >= 0) { mu[p].y = a.mean[lc[2 * p + 1]]; is[p].y = a.invstd[lc[2 * p + 1]]; ga[p].y = a.gamma[lc[2 * p + 1]]; be[p].y = a.beta[lc[2 * p + 1]]; }
+        }
     }
+    const float negslope = act_negslope(a.act);
     if (live) {
-        // Software pipeline: the next batch of U rows is requested before the current one is reduced.  One workgroup per CU means one
-        // wavefront per SIMD, so nothing else hides a batch's load latency behind the ~2.5 k cycles of fp64 accumulation of the
-        // previous one (the reductions ran at 1.3-2 TB/s with the loads and the arithmetic strictly alternating).
+        // Software pipeline: the next batch of U rows is requested before the current one is reduced (one workgroup per CU means one
+        // wavefront per SIMD: nothing else hides a batch's load latency).  A batch is summed in fp32, two channels per instruction, and
+        // enters the double accumulators once (4 rows: the partial carries 2-3 ulps of fp32 at most).
         constexpr int U = 4;
         const long step = (long)gridDim.x * rowsPer;
         DzOdd dm{};
@@ -599,39 +623,62 @@ __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
             }
         };
         auto reduce = [&](const Batch& q, long r) {
+            f32x2 t0[4], t1[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { t0[p] = splat2(0.0f); t1[p] = splat2(0.0f); }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float g[8];
+                h16x8 g = zero8();
                 if (MODE == 2) {
-                    if (slowdz) load_dz8(a, (size_t)(q.ok[u] ? r + u * step : r), p0, g);
-                    else if (a.dz_odd) dz_odd_pick(dm, q.d0[u], q.d1[u], q.e[u], g);
+                    if (a.dz_odd) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = 2 * j + 1;
+                            g[j] = (dm.sv == 0 && i >= dm.cut) ? q.e[u][i] : q.d0[u][i];
+                            g[4 + j] = dm.load1 ? ((dm.sv == 1 && i >= dm.cut) ? q.e[u][i] : q.d1[u][i]) : (h16)0.0f;
+                        }
+                    } else g = q.d0[u];
+                    g = keep8(g, q.ok[u]);                       // a row past the end contributes d = 0 to both sums
+                }
+                const h16x8 v = (MODE == 2) ? q.v[u] : keep8(q.v[u], q.ok[u]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2 yv = pair_of(v, p);
+                    if (MODE == 0) { t0[p] += yv; t1[p] = __builtin_elementwise_fma(yv, yv, t1[p]); }
+                    else if (MODE == 3) { t0[p] += yv; }
                     else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) g[j] = (float)q.d0[u][j];
+                        const f32x2 xh = bn_xhat2(yv, mu[p], is[p]);
+                        const f32x2 d = act_grad2(pair_of(g, p), bn_value2(xh, ga[p], be[p]), negslope);
+                        t0[p] += d;
+                        t1[p] = __builtin_elementwise_fma(d, xh, t1[p]);
                     }
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float yv = (float)q.v[u][j];
-                    if (MODE == 0) {
-                        const float y0 = q.ok[u] ? yv : 0.0f;
-                        s0[j] += (double)y0;
-                        s1[j] += (double)y0 * (double)y0;
-                    } else if (MODE == 3) {
-                        s0[j] += q.ok[u] ? (double)yv : 0.0;
-                    } else {
-                        float d = q.ok[u] ? g[j] : 0.0f;
-                        d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
-                        const float xh = (yv - mu[j]) * is[j];
-                        s0[j] += (double)d;
-                        s1[j] += (double)d * (double)xh;
-                    }
-                }
+            for (int p = 0; p < 4; ++p) {
+                s0[2 * p] += (double)t0[p].x; s0[2 * p + 1] += (double)t0[p].y;
+                if (MODE != 3) { s1[2 * p] += (double)t1[p].x; s1[2 * p + 1] += (double)t1[p].y; }
             }
         };
         Batch A, B;
         const long bstep = U * step;
         long r = (long)blockIdx.x * rowsPer + rl;
+        if (slowdz) {                                           // ragged last octet (C = 5..7 mod 8: no layer of the networks): one row at a time
+            for (; r < a.M; r += step) {
+                float gf[8];
+                load_dz8(a, (size_t)r, p0, gf);
+                const h16x8 v = ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2 xh = bn_xhat2(pair_of(v, p), mu[p], is[p]);
+                    f32x2 gp; gp.x = gf[2 * p]; gp.y = gf[2 * p + 1];
+                    const f32x2 d = act_grad2(gp, bn_value2(xh, ga[p], be[p]), negslope);
+                    s0[2 * p] += (double)d.x; s0[2 * p + 1] += (double)d.y;
+                    s1[2 * p] += (double)(d.x * xh.x); s1[2 * p + 1] += (double)(d.y * xh.y);
+                }
+            }
+            r = a.M;
+        }
         if (r < a.M) issue(A, r);
         while (r < a.M) {
             if (r + bstep < a.M) issue(B, r + bstep);
@@ -702,13 +749,20 @@ void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
 
 // one row-octet of the BatchNorm forward output: dense (out has y's map, pads zero) or shuffle (out = the gapped unit output:
 // out[2c] = pass[c], out[2c+1] = z[c], pads zeroed) — shared by hbn_apply_kernel and hbn_fused_kernel<0>
-__device__ __forceinline__ void bn_apply_emit(h16* __restrict__ out, int out_ld, int out_off, bool shuffle, int out_half, int out_gap, int C, int act, long m, int p0, int ol,
-                                              const int (&lc)[8], const float (&mu)[8], const float (&is)[8], const float (&ga)[8], const float (&be)[8],
+__device__ __forceinline__ void bn_apply_emit(h16* __restrict__ out, int out_ld, int out_off, bool shuffle, int out_half, int out_gap, int C, float negslope, long m, int p0, int ol,
+                                              const f32x2 (&mu)[4], const f32x2 (&is)[4], const f32x2 (&ga)[4], const f32x2 (&be)[4],       // pad channels: gamma = beta = 0
                                               const h16x8& v, const h16x8& pv)
 {
     float z[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = lc[j] >= 0 ? hact(hbn_value((float)v[j], mu[j], is[j], ga[j], be[j]), act) : 0.0f;
+    for (int p = 0; p < 4; ++p) {
+        const f32x2 zz = bn_value2(bn_xhat2(pair_of(v, p), mu[p], is[p]), ga[p], be[p]);
+        f32x2 mlt;
+        mlt.x = zz.x > 0.0f ? 1.0f : negslope;
+        mlt.y = zz.y > 0.0f ? 1.0f : negslope;
+        const f32x2 r = zz * mlt + splat2(0.0f);                     // + 0: a ReLU'd negative is stored as +0, as max(z, 0) would
+        z[2 * p] = r.x; z[2 * p + 1] = r.y;
+    }
     if (!shuffle) {
         h16x8 r;
 #pragma unroll
@@ -774,16 +828,17 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
     const int OC = a.Cp >> 3;
     if (ol >= OC) return;
     const int p0 = ol * 8;
-    int lc[8];
-    float mu[8], is[8], ga[8], be[8];
+    f32x2 mu[4], is[4], ga[4], be[4];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
-        const int c = lc[j] >= 0 ? lc[j] : 0;
-        mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c];
+        const int c = logical_of(p0 + j, a.C, a.half, a.gap);
+        const float m_ = c >= 0 ? cst[0][c] : 0.0f, i_ = c >= 0 ? cst[1][c] : 0.0f, g_ = c >= 0 ? cst[2][c] : 0.0f, b_ = c >= 0 ? cst[3][c] : 0.0f;
+        if (j & 1) { mu[j >> 1].y = m_; is[j >> 1].y = i_; ga[j >> 1].y = g_; be[j >> 1].y = b_; }
+        else { mu[j >> 1].x = m_; is[j >> 1].x = i_; ga[j >> 1].x = g_; be[j >> 1].x = b_; }
     }
+    const float negslope = act_negslope(a.act);
     auto emit = [&](long m, h16x8 v, h16x8 pv) {
-        bn_apply_emit(a.out, a.out_ld, a.out_off, a.pass != nullptr, a.out_half, a.out_gap, a.C, a.act, m, p0, ol, lc, mu, is, ga, be, v, pv);
+        bn_apply_emit(a.out, a.out_ld, a.out_off, a.pass != nullptr, a.out_half, a.out_gap, a.C, negslope, m, p0, ol, mu, is, ga, be, v, pv);
     };
     constexpr int U = 4;
     const long step = (long)gridDim.x * rowsPer;
@@ -815,122 +870,9 @@ void launch_hbn_apply(const HBnApplyArgs& a0, hipStream_t s)
     hipLaunchKernelGGL(hbn_apply_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a);
 }
 
-// ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)); dy dense h16 [M][Cp] with y's map,
-//      pads zero; one thread per channel writes dgamma / dbeta (fp32, still carrying the loss scale).
-__global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta)
-{
-    __shared__ float cst[6][256];                             // mean, invstd, gamma, beta, mean(dyh), mean(dyh * xhat) per logical channel
-    const double invM = 1.0 / (double)a.M;
-    for (int c = threadIdx.x; c < a.C; c += 256) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < HACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
-        cst[0][c] = a.mean[c]; cst[1][c] = a.invstd[c]; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
-        cst[4][c] = (float)(s0 * invM); cst[5][c] = (float)(s1 * invM);
-        if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
-    }
-    __syncthreads();
-    const int OL = a.lanes, rowsPer = 256 / OL;
-    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
-    const int OC = a.Cp >> 3;
-    if (ol >= OC) return;
-    const int p0 = ol * 8;
-    int lc[8];
-    float mu[8], is[8], ga[8], be[8], kk[8], m0[8], m1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lc[j] = logical_of(p0 + j, a.C, a.half, a.gap);
-        const int c = lc[j] >= 0 ? lc[j] : 0;
-        mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c]; kk[j] = ga[j] * is[j]; m0[j] = cst[4][c]; m1[j] = cst[5][c];
-    }
-    auto emit = [&](long m, h16x8 v, const float (&g)[8]) {
-        h16x8 r;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float d = g[j];
-            const float yv = (float)v[j];
-            d = hact_grad(d, hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
-            const float xh = (yv - mu[j]) * is[j];
-            r[j] = lc[j] >= 0 ? (h16)(kk[j] * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
-        }
-        sth8(dy + (size_t)m * a.Cp + p0, r);
-    };
-    constexpr int U = 4;
-    const long step = (long)gridDim.x * rowsPer;
-    long r = (long)blockIdx.x * rowsPer + rl;
-    for (; r + (U - 1) * step < a.M; r += U * step) {
-        h16x8 v[U];
-        float g[U][8];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = ldh8(a.y + (size_t)(r + u * step) * a.y_ld + a.y_off + p0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) load_dz8(a, (size_t)(r + u * step), p0, g[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) emit(r + u * step, v[u], g[u]);
-    }
-    for (; r < a.M; r += step) {
-        float g[8];
-        load_dz8(a, (size_t)r, p0, g);
-        emit(r, ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0), g);
-    }
-}
-
-void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hipStream_t s)
-{
-    launch_hcol_reduce(a0, 2, s);
-    HRedArgs a = a0;
-    a.lanes = hlanes_for(a.Cp);
-    hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a, dy, dgamma, dbeta);
-}
-
-// =================================================================================================
-// One launch per BatchNorm and direction (round 3): statistics + apply, or backward sums + dy, in ONE kernel around a grid-wide
-// barrier.  The two-launch form reads y twice forward and (dz, y) twice backward; here a workgroup keeps the rows it summed —
-// the first RH of a thread in registers, the next `hold` in LDS — and only rows beyond that are read again after the barrier, so a
-// tensor up to CUs x 256 threads x (RH + hold) x 16 B (about 20 MB forward, 12 MB backward: stages 3-4, the 38x38 / 19x19 pyramid
-// levels and most of stage 2) crosses the memory system once per direction, and 148 launches per step disappear.
-// Grid: at most one workgroup per CU, 256 threads, <= 70 KB of LDS — all workgroups are co-resident by construction (two such
-// kernels from two processes on one GPU still fit side by side; anything else on the chip finishes without waiting for us).
-// Barrier: two-level arrival counters (32 groups -> one top-level count) so that no address takes more than 32 serial device-scope
-// atomics, spin on the top-level count with s_sleep; a 200 ms timeout sets a.err instead of hanging the GPU.
-// Sums: fp32 inside a thread (two levels: per batch of <= 8 rows, then across batches), double from the first cross-lane step on.
-// =================================================================================================
-constexpr int BNF_T = 256;
-template <int MODE> struct BnfCfg;
-template <> struct BnfCfg<0> { static constexpr int RH = 8, U = 4, HOLD = 12; };
-template <> struct BnfCfg<1> { static constexpr int RH = 4, U = 2, HOLD = 6; };
-
-__device__ __forceinline__ double ld_agent_f64(const double* p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// every thread of every workgroup of the grid calls this once; false = timed out (results are garbage, *err is set)
-__device__ __forceinline__ bool bnf_grid_barrier(unsigned* bar, int* err)
-{
-    __shared__ int ok_s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned G = gridDim.x, NG = G < 32u ? G : 32u;
-        const unsigned grp = blockIdx.x % NG, gsize = (G - grp + NG - 1) / NG;
-        __threadfence();
-        const unsigned prev = __hip_atomic_fetch_add(bar + 8 + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1 == gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < NG) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 20000000ull) { ok = 0; if (err) atomicOr(err, 1); break; }     // 100 MHz: 200 ms
-        }
-        ok_s = ok;
-    }
-    __syncthreads();
-    return ok_s != 0;
-}
-
 // this layer's gradient octet (channels p0..p0+7) of row `row`, as stored halves; `ev` (dz_odd only) gets the EVEN logical channels of
 // the same 16 values — the pass-through half of the unit gradient (backbone/shufflenetv2.py:70-74 backwards)
-__device__ __forceinline__ h16x8 bnf_load_g(const HBnFusedArgs& a, const DzOdd& dm, size_t row, int p0, h16x8& ev)
+__device__ __forceinline__ h16x8 dz_load_both(const HRedArgs& a, const DzOdd& dm, size_t row, int p0, h16x8& ev)
 {
     if (!a.dz_odd) { ev = zero8(); return ldh8(a.dz + row * a.dz_ld + a.dz_off + p0); }
     h16x8 g;
@@ -957,259 +899,106 @@ __device__ __forceinline__ h16x8 bnf_load_g(const HBnFusedArgs& a, const DzOdd& 
     return g;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(BNF_T) void hbn_fused_kernel(HBnFusedArgs a)
+// ---- BatchNorm backward: dy = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat)); dy dense h16 [M][Cp] with y's map,
+//      pads zero; one thread per channel writes dgamma / dbeta (fp32, still carrying the loss scale).
+__global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* dy /* may be a.y: in place */, float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    constexpr int RH = BnfCfg<MODE>::RH, U = BnfCfg<MODE>::U;
-    extern __shared__ __align__(16) unsigned char bnf_lds[];
-    h16x8* held = reinterpret_cast<h16x8*>(bnf_lds);                   // [hold][T] of y, then (MODE 1) [hold][T] of the gradient
-    __shared__ double red[4][32][16];
-    __shared__ float cst[6][256];
-    const int tid = threadIdx.x;
-    const int OL = a.lanes, rowsPer = BNF_T / OL;
-    const int ol = tid & (OL - 1), rl = tid / OL;
-    const int OC = a.Cp >> 3;
-    const bool live = ol < OC;
-    const int p0 = live ? ol * 8 : 0;
-    const int hold = a.hold;
-    int lc[8];
-    float mu[8], is[8], ga[8], be[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lc[j] = live ? logical_of(p0 + j, a.C, a.half, a.gap) : -1;
-        mu[j] = is[j] = ga[j] = be[j] = 0.0f;
-        if (MODE == 1 && lc[j] >= 0) { mu[j] = a.mean[lc[j]]; is[j] = a.invstd[lc[j]]; ga[j] = a.gamma[lc[j]]; be[j] = a.beta[lc[j]]; }
-    }
-    DzOdd dm{};
-    if (MODE == 1 && a.dz_odd) dm = dz_odd_map_g(a.C, a.dz_ld, a.dz_half, a.dz_gap, p0);
-    const long step = (long)gridDim.x * rowsPer;
-    const long first = (long)blockIdx.x * rowsPer;
-    const long rbase = first + rl;
-    const int nsweep = first < a.M ? (int)((a.M - first + step - 1) / step) : 0;       // uniform over the workgroup
-
-    // ---------------- phase 1: load, keep, sum ----------------
-    float s0[8], s1[8], t0[8], t1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s0[j] = s1[j] = t0[j] = t1[j] = 0.0f; }
-    auto accum = [&](const h16x8& v, const h16x8& g) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float yv = (float)v[j];
-            if (MODE == 0) { t0[j] += yv; t1[j] = __fmaf_rn(yv, yv, t1[j]); }
-            else {
-                const float d = hact_grad((float)g[j], hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
-                const float xh = (yv - mu[j]) * is[j];
-                t0[j] += d; t1[j] = __fmaf_rn(d, xh, t1[j]);
-            }
-        }
-    };
-    auto fold = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s0[j] += t0[j]; s1[j] += t1[j]; t0[j] = 0.0f; t1[j] = 0.0f; }
-    };
-    h16x8 rv[RH], rg[RH], rev[RH];
-#pragma unroll
-    for (int u = 0; u < RH; ++u) {
-        const long r = rbase + u * step;
-        const bool ok = live && r < a.M;
-        const size_t row = (size_t)(ok ? r : 0);
-        rv[u] = keep8(ldh8(a.y + row * a.y_ld + a.y_off + p0), ok);
-        if (MODE == 1) { rg[u] = keep8(bnf_load_g(a, dm, row, p0, rev[u]), ok); }
-    }
-    for (int k = RH; k < nsweep; k += U) {
-        h16x8 v[U], g[U], ev[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long r = rbase + (long)(k + u) * step;
-            const bool ok = live && r < a.M;
-            const size_t row = (size_t)(ok ? r : 0);
-            v[u] = keep8(ldh8(a.y + row * a.y_ld + a.y_off + p0), ok);
-            if (MODE == 1) g[u] = keep8(bnf_load_g(a, dm, row, p0, ev[u]), ok);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = k + u - RH;
-            if (slot < hold) {
-                held[(size_t)slot * BNF_T + tid] = v[u];
-                if (MODE == 1) {
-                    held[(size_t)(hold + slot) * BNF_T + tid] = g[u];
-                    if (a.even) held[(size_t)(2 * hold + slot) * BNF_T + tid] = ev[u];
-                }
-            }
-            accum(v[u], g[u]);
-        }
-        fold();
-    }
-#pragma unroll
-    for (int u = 0; u < RH; ++u) accum(rv[u], rg[u]);
-    fold();
-
-    // ---------------- combine: row-lanes of a wave by shuffles (double), waves through LDS, one atomic per channel and sum ----------------
-    double d0[8], d1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { d0[j] = (double)s0[j]; d1[j] = (double)s1[j]; }
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int off = 32; off >= OL; off >>= 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { d0[j] += __shfl_xor(d0[j], off); d1[j] += __shfl_xor(d1[j], off); }
-    }
-    if (lane < OL) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { red[wave][lane][j] = d0[j]; red[wave][lane][8 + j] = d1[j]; }
-    }
-    __syncthreads();
-    if (tid < OL && live) {
-        double* acc = a.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * a.C;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (lc[j] < 0) continue;
-            atomicAdd(acc + lc[j], (red[0][ol][j] + red[1][ol][j]) + (red[2][ol][j] + red[3][ol][j]));
-            atomicAdd(acc + a.C + lc[j], (red[0][ol][8 + j] + red[1][ol][8 + j]) + (red[2][ol][8 + j] + red[3][ol][8 + j]));
-        }
-        __threadfence();
-    }
-    if (!bnf_grid_barrier(a.bar, a.err)) return;
-
-    // ---------------- per-channel constants from the complete sums ----------------
+    __shared__ float cst[6][256];                             // mean, invstd, gamma, beta, mean(dyh), mean(dyh * xhat) per logical channel
     const double invM = 1.0 / (double)a.M;
-    for (int c = tid; c < a.C; c += BNF_T) {
-        double m = 0.0, q = 0.0;
-#pragma unroll 8
-        for (int sl = 0; sl < HACC_SLOTS; ++sl) { m += ld_agent_f64(a.acc + ((size_t)sl * 2) * a.C + c); q += ld_agent_f64(a.acc + ((size_t)sl * 2 + 1) * a.C + c); }
-        if (MODE == 0) {
-            m *= invM;
-            double var = q * invM - m * m;
-            if (var < 0.0) var = 0.0;
-            const float mu_c = (float)m, is_c = (float)(1.0 / sqrt(var + (double)a.eps));
-            cst[0][c] = mu_c; cst[1][c] = is_c; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
-            if (blockIdx.x == 0) {
-                a.mean_out[c] = mu_c; a.invstd_out[c] = is_c;
-                if (a.rmean) {
-                    const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
-                    a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu_c;
-                    a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
-                }
-            }
-        } else {
-            cst[4][c] = (float)(m * invM); cst[5][c] = (float)(q * invM);
-            if (blockIdx.x == 0) { a.dbeta[c] = (float)m; a.dgamma[c] = (float)q; }
-        }
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < HACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * a.C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * a.C + c]; }
+        cst[0][c] = a.mean[c]; cst[1][c] = a.invstd[c]; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+        cst[4][c] = (float)(s0 * invM); cst[5][c] = (float)(s1 * invM);
+        if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
     }
     __syncthreads();
-    if (!live) return;
-    float m0[8], m1[8];
+    const int OL = a.lanes, rowsPer = 256 / OL;
+    const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
+    const int OC = a.Cp >> 3;
+    if (ol >= OC) return;
+    const int p0 = ol * 8;
+    f32x2 mu[4], is[4], ga[4], be[4], m0[4], m1[4];              // pad channels: gamma = invstd = 0 -> dy = 0
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = lc[j] >= 0 ? lc[j] : 0;
-        if (MODE == 0) { mu[j] = cst[0][c]; is[j] = cst[1][c]; ga[j] = cst[2][c]; be[j] = cst[3][c]; m0[j] = m1[j] = 0.0f; }
-        else { m0[j] = cst[4][c]; m1[j] = cst[5][c]; }
+        const int c = logical_of(p0 + j, a.C, a.half, a.gap);
+        const bool on = c >= 0;
+        const float m_ = on ? cst[0][c] : 0.0f, i_ = on ? cst[1][c] : 0.0f, g_ = on ? cst[2][c] : 0.0f, b_ = on ? cst[3][c] : 0.0f;
+        const float a_ = on ? cst[4][c] : 0.0f, c_ = on ? cst[5][c] : 0.0f;
+        if (j & 1) { mu[j >> 1].y = m_; is[j >> 1].y = i_; ga[j >> 1].y = g_; be[j >> 1].y = b_; m0[j >> 1].y = a_; m1[j >> 1].y = c_; }
+        else { mu[j >> 1].x = m_; is[j >> 1].x = i_; ga[j >> 1].x = g_; be[j >> 1].x = b_; m0[j >> 1].x = a_; m1[j >> 1].x = c_; }
     }
-
-    // ---------------- phase 2: apply to what was kept, re-read only what was not ----------------
-    auto emit = [&](long m, const h16x8& v, const h16x8& g, const h16x8& ev, const h16x8& pv) {
-        if (MODE == 0) {
-            bn_apply_emit(a.out, a.out_ld, a.out_off, a.pass != nullptr, a.out_half, a.out_gap, a.C, a.act, m, p0, ol, lc, mu, is, ga, be, v, pv);
-        } else {
-            h16x8 r;
+    const float negslope = act_negslope(a.act);
+    DzOdd dm{};
+    if (a.dz_odd) dm = dz_odd_map(a, p0);
+    auto emit = [&](long m, const h16x8& v, const h16x8& g, const h16x8& ev) {
+        h16x8 r;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float yv = (float)v[j];
-                const float d = hact_grad((float)g[j], hbn_value(yv, mu[j], is[j], ga[j], be[j]), a.act);
-                const float xh = (yv - mu[j]) * is[j];
-                r[j] = lc[j] >= 0 ? (h16)((ga[j] * is[j]) * (d - m0[j] - xh * m1[j])) : (h16)0.0f;
-            }
-            sth8(a.dy + (size_t)m * a.Cp + p0, r);
-            if (a.even) sth8(a.even + (size_t)m * a.even_ld + p0, ev);
+        for (int p = 0; p < 4; ++p) {
+            const f32x2 xh = bn_xhat2(pair_of(v, p), mu[p], is[p]);
+            const f32x2 d = act_grad2(pair_of(g, p), bn_value2(xh, ga[p], be[p]), negslope);
+            const f32x2 o = (ga[p] * is[p]) * (d - m0[p] - xh * m1[p]);
+            r[2 * p] = (h16)o.x; r[2 * p + 1] = (h16)o.y;
+        }
+        sth8(dy + (size_t)m * a.Cp + p0, r);
+        if (a.even) sth8(a.even + (size_t)m * a.even_ld + p0, ev);
+    };
+    const long step = (long)gridDim.x * rowsPer;
+    long r = (long)blockIdx.x * rowsPer + rl;
+    if (a.dz_odd && !dm.vec) {                                  // a ragged last octet whose 16-byte loads would leave the row (C = 5..7 mod 8: no layer of the networks)
+        for (; r < a.M; r += step) {
+            h16x8 ev;
+            const h16x8 g = dz_load_both(a, dm, (size_t)r, p0, ev);
+            emit(r, ldh8(a.y + (size_t)r * a.y_ld + a.y_off + p0), g, ev);
+        }
+        return;
+    }
+    constexpr int U = 4;
+    const size_t dzo = a.dz_odd ? (size_t)dm.o0 : (size_t)(a.dz_off + p0);
+    auto pick = [&](const h16x8& d0, const h16x8& d1, const h16x8& e, h16x8& g, h16x8& ev) {
+        if (!a.dz_odd) { g = d0; ev = zero8(); return; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 2 * j + 1, k = 2 * j;
+            g[j] = (dm.sv == 0 && i >= dm.cut) ? e[i] : d0[i];
+            ev[j] = p0 + j < a.C ? ((dm.sv == 0 && k >= dm.cut) ? e[k] : d0[k]) : (h16)0.0f;
+            g[4 + j] = dm.load1 ? ((dm.sv == 1 && i >= dm.cut) ? e[i] : d1[i]) : (h16)0.0f;
+            ev[4 + j] = (dm.load1 && p0 + 4 + j < a.C) ? ((dm.sv == 1 && k >= dm.cut) ? e[k] : d1[k]) : (h16)0.0f;
         }
     };
-    {
-        h16x8 pv[RH];
-#pragma unroll
-        for (int u = 0; u < RH; ++u) {
-            const long r = rbase + u * step;
-            pv[u] = (MODE == 0 && a.pass && r < a.M) ? ldh8(a.pass + (size_t)r * a.pass_ld + a.pass_off + p0) : zero8();
-        }
-#pragma unroll
-        for (int u = 0; u < RH; ++u) {
-            const long r = rbase + u * step;
-            if (r < a.M) emit(r, rv[u], rg[u], rev[u], pv[u]);
-        }
-    }
-    const int kh = nsweep < RH + hold ? nsweep : RH + hold;
-    for (int k = RH; k < kh; ++k) {
-        const long r = rbase + (long)k * step;
-        if (r >= a.M) break;
-        const int slot = k - RH;
-        const h16x8 v = held[(size_t)slot * BNF_T + tid];
-        h16x8 g = zero8(), ev = zero8(), pv = zero8();
-        if (MODE == 1) { g = held[(size_t)(hold + slot) * BNF_T + tid]; if (a.even) ev = held[(size_t)(2 * hold + slot) * BNF_T + tid]; }
-        if (MODE == 0 && a.pass) pv = ldh8(a.pass + (size_t)r * a.pass_ld + a.pass_off + p0);
-        emit(r, v, g, ev, pv);
-    }
-    for (int k = RH + hold; k < nsweep; k += U) {
-        h16x8 v[U], g[U], ev[U], pv[U];
-        bool ok[U];
+    for (; r + (U - 1) * step < a.M; r += U * step) {
+        h16x8 v[U], d0[U], d1[U], e[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long r = rbase + (long)(k + u) * step;
-            ok[u] = r < a.M;
-            const size_t row = (size_t)(ok[u] ? r : 0);
+            const size_t row = (size_t)(r + u * step);
             v[u] = ldh8(a.y + row * a.y_ld + a.y_off + p0);
-            g[u] = ev[u] = pv[u] = zero8();
-            if (MODE == 1) g[u] = bnf_load_g(a, dm, row, p0, ev[u]);
-            if (MODE == 0 && a.pass) pv[u] = ldh8(a.pass + row * a.pass_ld + a.pass_off + p0);
+            d0[u] = ldh8(a.dz + row * a.dz_ld + dzo);
+            if (a.dz_odd) { d1[u] = ldh8(a.dz + row * a.dz_ld + dm.o1); e[u] = ldh8(a.dz + row * a.dz_ld + dm.oe); }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (ok[u]) emit(rbase + (long)(k + u) * step, v[u], g[u], ev[u], pv[u]);
+        for (int u = 0; u < U; ++u) {
+            h16x8 g, ev;
+            pick(d0[u], d1[u], e[u], g, ev);
+            emit(r + u * step, v[u], g, ev);
+        }
+    }
+    for (; r < a.M; r += step) {
+        const size_t row = (size_t)r;
+        const h16x8 v = ldh8(a.y + row * a.y_ld + a.y_off + p0), d0 = ldh8(a.dz + row * a.dz_ld + dzo);
+        h16x8 d1 = d0, e = d0, g, ev;
+        if (a.dz_odd) { d1 = ldh8(a.dz + row * a.dz_ld + dm.o1); e = ldh8(a.dz + row * a.dz_ld + dm.oe); }
+        pick(d0, d1, e, g, ev);
+        emit(r, v, g, ev);
     }
 }
 
-static int bnf_cus()
+void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hipStream_t s)
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    return cus;
-}
-
-// false: this layer cannot take the fused form (the caller launches the two-kernel form)
-bool launch_hbn_fused(const HBnFusedArgs& a0, int mode, hipStream_t s)
-{
-    static const int enabled = getenv("YN_BN_FUSED") ? atoi(getenv("YN_BN_FUSED")) : 1;
-    static const int gcap = getenv("YN_BNF_G") ? atoi(getenv("YN_BNF_G")) : 0;
-    static const int rows_min = getenv("YN_BNF_ROWS") ? atoi(getenv("YN_BNF_ROWS")) : 4;
-    if (!enabled || a0.C > 256 || a0.Cp > 256 || !a0.bar) return false;
-    HBnFusedArgs a = a0;
+    launch_hcol_reduce(a0, 2, s);
+    HRedArgs a = a0;
     a.lanes = hlanes_for(a.Cp);
-    const int rowsPer = BNF_T / a.lanes;
-    int cap = bnf_cus();
-    if (gcap > 0 && gcap < cap) cap = gcap;
-    if (a.gcap > 0 && a.gcap < cap) cap = a.gcap;
-    long G = ((long)a.M + (long)rowsPer * rows_min - 1) / ((long)rowsPer * rows_min);
-    if (G > cap) G = cap;
-    if (G < 1) G = 1;
-    const long sweeps = ((long)a.M + G * rowsPer - 1) / (G * rowsPer);
-    const int RH = mode ? BnfCfg<1>::RH : BnfCfg<0>::RH, HOLD = mode ? BnfCfg<1>::HOLD : BnfCfg<0>::HOLD;
-    const int planes = mode ? (a.even ? 3 : 2) : 1;
-    long hold = sweeps - RH;
-    if (hold < 0) hold = 0;
-    const int hmax = mode ? (HOLD * 2) / planes : HOLD;
-    if (hold > hmax) hold = hmax;
-    a.hold = (int)hold;
-    const size_t lds = (size_t)hold * planes * BNF_T * sizeof(h16x8);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbn_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, BnfCfg<0>::HOLD * BNF_T * (int)sizeof(h16x8));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hbn_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BnfCfg<1>::HOLD * BNF_T * (int)sizeof(h16x8));
-        attr_set = true;
-    }
-    if (mode == 0) hipLaunchKernelGGL(hbn_fused_kernel<0>, dim3((unsigned)G), dim3(BNF_T), lds, s, a);
-    else hipLaunchKernelGGL(hbn_fused_kernel<1>, dim3((unsigned)G), dim3(BNF_T), lds, s, a);
-    return true;
+    hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a, dy, dgamma, dbeta);
 }
 
 // =================================================================================================

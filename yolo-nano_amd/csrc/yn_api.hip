@@ -115,9 +115,6 @@ struct yn_handle {
     std::vector<ynk::HPackDesc> hpack_jobs;   // recorded while the first fp16 step packs layer by layer; later steps pack everything in one launch
     ynk::HPackDesc* hpack_table = nullptr;     // device copy
     int hpack_table_n = 0;
-    int bn_fuse = 1, bn_fuse_gcap = 0;    // yn_train_bn_fuse: one launch per BatchNorm and direction (hbn_fused_kernel); test cap on its grid
-    int* bn_err = nullptr;                // device int: a fused BatchNorm kernel's grid barrier timed out (hbn_fused_kernel)
-    int* bn_err_host = nullptr;           // pinned copy, refreshed at the end of every fp16 step, looked at when the next one starts
     float* scale_state = nullptr;         // device float[8]: loss scale, its inverse, clean-step counter, local overflow flag, step-pending mark (kernels_h16.hip)
     float loss_scale_init = 0.0f, loss_scale_clean = 0.0f;   // yn_train_set_loss_scale before the first fp16 step (checkpoint resume)
     std::vector<hipEvent_t> train_events;
@@ -1179,8 +1176,6 @@ void yn_destroy(yn_handle* h)
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
-    if (h->bn_err) (void)hipFree(h->bn_err);
-    if (h->bn_err_host) (void)hipHostFree(h->bn_err_host);
     if (h->hpack_table) (void)hipFree(h->hpack_table);
     for (HPack& pk : h->hpacks) { void* q[] = {pk.wf, pk.wb, pk.bias, pk.dwf, pk.dwb}; for (void* v : q) if (v) (void)hipFree(v); }
     for (hipEvent_t e : h->train_events) (void)hipEventDestroy(e);

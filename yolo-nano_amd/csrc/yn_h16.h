@@ -48,6 +48,7 @@ struct HRedArgs {
     const h16* dz; int dz_ld, dz_off, dz_odd, dz_half, dz_gap;
     const float* mean; const float* invstd; const float* gamma; const float* beta; int act;
     double* acc; float* facc; size_t slot_stride;
+    h16* even; int even_ld;                     // hbn_bwd_kernel, dz_odd only, optional: the EVEN logical channels of dz -> dense [M][even_ld] (pads zero)
     int lanes;                                  // filled by the launcher
 };
 void launch_hcol_reduce(const HRedArgs& a, int mode, hipStream_t s);      // mode 0 stats, 2 BN-backward sums, 3 column sum -> facc slots
@@ -63,29 +64,6 @@ struct HBnApplyArgs {
     int lanes;                                  // filled by the launcher
 };
 void launch_hbn_apply(const HBnApplyArgs& a, hipStream_t s);
-
-// statistics + apply (mode 0) or backward sums + dy (mode 1) of one BatchNorm in ONE launch around a grid-wide barrier (hbn_fused_kernel)
-struct HBnFusedArgs {
-    const h16* y; int y_ld, y_off;              // the pre-BN conv output
-    int M, C, Cp, half, gap, act;
-    const float* gamma; const float* beta;
-    double* acc;                                // [HACC_SLOTS][2][C], zeroed
-    unsigned* bar;                              // 40 zeroed counters: [0] top level, [8 + g] arrival groups
-    int* err;                                   // set when the barrier timed out (never on a healthy device)
-    int lanes, hold;                            // filled by the launcher
-    int gcap;                                   // > 0: at most this many workgroups (tests: forces the LDS-kept and re-read row paths on small tensors)
-    // forward
-    float eps; float* mean_out; float* invstd_out; float* rmean; float* rvar; float momentum;
-    h16* out; int out_ld, out_off;
-    const h16* pass; int pass_ld, pass_off, out_half, out_gap;      // shuffle mode
-    // backward
-    const h16* dz; int dz_ld, dz_off, dz_odd, dz_half, dz_gap;
-    const float* mean; const float* invstd;
-    h16* dy; float* dgamma; float* dbeta;
-    h16* even; int even_ld;                     // dz_odd only, optional: the even logical channels of dz -> dense [M][even_ld] (pads zero)
-};
-bool launch_hbn_fused(const HBnFusedArgs& a, int mode, hipStream_t s);      // false: not applicable, use the two-kernel form
-constexpr int HBN_BAR_WORDS = 40;
 
 void launch_hstem(const float* x_nchw, int B, int H, int W, const float* w, const float* bias, h16* y, hipStream_t s);
 void launch_hstem_wgrad(const h16* dy, const float* x_nchw, int B, int H, int W, float* dw_slots, size_t slot_stride, hipStream_t s);
