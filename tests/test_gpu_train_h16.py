@@ -152,6 +152,53 @@ def test_h16_batchnorm_as_the_last_layer_of_a_unit(hop, M, C, act):
     assert rel(dg.cpu().numpy(), rdg) < 2e-3 and rel(db.cpu().numpy(), rdb) < 2e-3
 
 
+@pytest.mark.parametrize("kind,Cin,Cout,gapped,B,H,W,act", [
+    (0, 58, 58, 0, 3, 11, 9, 1),        # NT = 2 tile, ragged M (297 rows: 3 row tiles, the last one partial)
+    (0, 116, 116, 0, 2, 19, 17, 1),     # NT = 4
+    (0, 96, 96, 0, 2, 13, 13, 2),       # NT = 3 (12 segments of a 16-wide statistics layout), LeakyReLU below
+    (0, 116, 58, 1, 2, 10, 12, 0),      # gapped two-plane input: the layer below has the unit's channel map (branch1's depthwise conv)
+    (0, 24, 58, 0, 2, 15, 15, 1),       # NT = 1 backward (24 -> 32 columns)
+    (2, 96, 96, 0, 2, 12, 11, 2),       # dense 3x3
+])
+def test_h16_gemm_epilogue_sums(hop, kind, Cin, Cout, gapped, B, H, W, act):
+    """hgemm_kernel's HColStat epilogues against float64 on the values the kernel itself stored: forward sum y / sum y^2 over the fp16
+    output (what hcol_reduce_kernel<0> would read back), and the BatchNorm-backward sums of the layer below from the fp16 input gradient
+    it just wrote (hcol_reduce_kernel<2>'s): fp32 inside a 128-row tile, double across tiles -> 1e-5 of the column's scale."""
+    rs = np.random.RandomState(Cin * 7 + Cout + kind)
+    x = rs.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, 3, 3) if kind == 2 else (Cout, Cin, 1, 1)) * 0.2).astype(np.float32)
+    dy = rs.standard_normal((B, H, W, Cout)).astype(np.float32)
+    yb = (rs.standard_normal((B, H, W, Cin)) * 1.5 + 0.3).astype(np.float32)
+    ybq = _q(yb)
+    mean = ybq.reshape(-1, Cin).mean(0).float()
+    invstd = (1.0 / torch.sqrt(ybq.reshape(-1, Cin).var(0, unbiased=False) + 1e-5)).float()
+    ga, be = torch.as_tensor(rs.uniform(0.7, 1.3, Cin).astype(np.float32)), torch.as_tensor(rs.uniform(-0.3, 0.3, Cin).astype(np.float32))
+    cu = lambda t: torch.as_tensor(t).cuda()
+    y, sf, dx, sb = hop.op_h16_gemm_stats(kind, cu(x), cu(w), gapped, cu(dy), cu(yb), cu(mean), cu(invstd), cu(ga), cu(be), act)
+    yq = y.cpu().double().reshape(-1, Cout)                              # exactly the stored fp16 values
+    within = lambda got, ref, tol: bool(np.all(np.abs(got - np.asarray(ref)) <= np.asarray(tol)))
+    for got, ref in ((sf[0], yq.sum(0)), (sf[1], (yq * yq).sum(0))):
+        assert within(got, ref.numpy(), 1e-5 * float(yq.abs().sum(0).max() + (yq * yq).sum(0).max())), np.abs(got - ref.numpy()).max()
+    # the conv itself (as test_h16_conv_kernels_vs_float64)
+    xq, wq = _q(x).permute(0, 3, 1, 2).requires_grad_(True), _q(w)
+    ref = F.conv2d(xq, wq, None, padding=0 if kind == 0 else 1)
+    ref.backward(_q(dy).permute(0, 3, 1, 2))
+    _close(y.permute(0, 3, 1, 2).cpu().numpy(), ref.detach())
+    _close(dx.permute(0, 3, 1, 2).cpu().numpy(), xq.grad)
+    # backward sums from the stored dx, in float64, with the device's float32 BN value deciding the activation's branch
+    dxq = dx.cpu().double().reshape(-1, Cin)
+    y2 = ybq.reshape(-1, Cin)
+    xh32 = ((y2.float() - mean) * invstd)
+    z32 = torch.addcmul(be, xh32, ga)                                    # fma(xhat, gamma, beta) up to one rounding
+    slope = {0: 1.0, 1: 0.0, 2: 0.1}[act]
+    sure = (z32.abs() > 1e-5)                                            # elements whose branch cannot depend on the last bit
+    d = dxq * torch.where(z32 > 0, torch.ones_like(dxq), torch.full_like(dxq, slope))
+    xh = (y2 - mean.double()) * invstd.double()
+    slack = (dxq.abs() * (~sure).double()).sum(0) * (1.0 - slope)
+    assert within(sb[0], d.sum(0).numpy(), float(1e-5 * dxq.abs().sum(0).max()) + slack.numpy()), np.abs(sb[0] - d.sum(0).numpy()).max()
+    assert within(sb[1], (d * xh).sum(0).numpy(), float(2e-5 * (dxq.abs() * xh.abs()).sum(0).max()) + (slack * xh.abs().max()).numpy()), np.abs(sb[1] - (d * xh).sum(0).numpy()).max()
+
+
 def _oracles(sd, backbone, C, x, target, S):
     from oracle.torch_port import TrainNet
     mk = lambda **kw: TrainNet(sd, backbone, C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=torch.float64, **kw)

@@ -99,6 +99,7 @@ SIGNATURES = {
     "yn_op_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "yn_op_h16_conv": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "yn_op_h16_bn": (_i32, [_vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yn_op_h16_gemm_stats": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "yn_op_h16_bn_unit": (_i32, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "yn_profile_enable": (_i32, [_vp, _i32]),
     "yn_profile_count": (_i32, [_vp]),
@@ -695,6 +696,21 @@ class Handle:
         self._ck(self.lib.yn_op_h16_bn(self.h, self._in(y).data_ptr(), _ptr(self._in(dz) if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
                                        int(act), z.data_ptr(), _ptr(dy), _ptr(dg), _ptr(db)), "yn_op_h16_bn")
         return z, dy, dg, db
+
+    def op_h16_gemm_stats(self, kind, x, w, gapped=False, dy=None, y_below=None, mean=None, invstd=None, gamma=None, beta=None, act=0):
+        """hgemm with its HColStat epilogue: -> y, sums_fwd (numpy double [2][Cout]) and, with dy, dx, sums_bwd ([2][Cin])."""
+        import numpy as np
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        sf = np.zeros((2, Cout), np.float64)
+        dx = torch.empty_like(x) if dy is not None else None
+        sb = np.zeros((2, Cin), np.float64) if dy is not None else None
+        keep = [self._in(t) if t is not None else None for t in (x, w, dy, y_below, mean, invstd, gamma, beta)]
+        self._ck(self.lib.yn_op_h16_gemm_stats(self.h, int(kind), keep[0].data_ptr(), B, H, W, Cin, int(bool(gapped)), keep[1].data_ptr(), Cout, y.data_ptr(),
+                                               sf.ctypes.data, _ptr(keep[2]), _ptr(keep[3]), _ptr(keep[4]), _ptr(keep[5]), _ptr(keep[6]), _ptr(keep[7]), int(act),
+                                               _ptr(dx), sb.ctypes.data if sb is not None else None), "yn_op_h16_gemm_stats")
+        return y, sf, dx, sb
 
     def op_h16_bn_unit(self, y, passthrough, gamma, beta, act=0, dunit=None):
         """BatchNorm as the last layer of a ShuffleV2 unit: -> unit [M][2C] (and dy, deven, dgamma, dbeta when dunit [M][2C] is given)."""

@@ -63,6 +63,25 @@ __device__ __forceinline__ int logical_of(int p, int C, int half, int gap)
     return c < C ? c : -1;
 }
 
+// Two channels per instruction: the streaming BatchNorm kernels are instruction-bound at one wavefront per SIMD (16 VALU operations per
+// element in the first form: 2.1 ms per 608 / bs-32 step for the backward sums alone), and gfx950 has packed fp32 multiply / add / fma.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pair_of(const h16x8& v, int p) { f32x2 r; r.x = (float)v[2 * p]; r.y = (float)v[2 * p + 1]; return r; }
+__device__ __forceinline__ f32x2 splat2(float x) { f32x2 r; r.x = x; r.y = x; return r; }
+// xhat and the BatchNorm value with exactly hbn_value's operation sequence (sub, mul, fma): the sign of z decides the activation's branch
+// and has to come out the same in the forward apply, the backward sums and the backward apply
+__device__ __forceinline__ f32x2 bn_xhat2(f32x2 y, f32x2 mu, f32x2 is) { return (y - mu) * is; }
+__device__ __forceinline__ f32x2 bn_value2(f32x2 xh, f32x2 ga, f32x2 be) { return __builtin_elementwise_fma(xh, ga, be); }
+// d = g * act'(z): g where z > 0, else g * negslope (0 / 0.1 / 1 for ReLU / LeakyReLU(0.1) / none)
+__device__ __forceinline__ f32x2 act_grad2(f32x2 g, f32x2 z, float negslope)
+{
+    f32x2 m;
+    m.x = z.x > 0.0f ? 1.0f : negslope;
+    m.y = z.y > 0.0f ? 1.0f : negslope;
+    return g * m;
+}
+__device__ __forceinline__ float act_negslope(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.1f : 1.0f); }
+
 // =================================================================================================
 // GEMM-shaped convolutions on the f16 MFMA: pointwise 1x1 (TAPS = 1) and dense 3x3 stride 1 pad 1 (TAPS = 9), used for the
 // forward pass and — on transposed (/ flipped) packs — for the input gradients.
@@ -75,8 +94,8 @@ __device__ __forceinline__ int logical_of(int p, int C, int half, int gap)
 // what is already there (dX accumulation).  MFMA operand convention: lane l supplies row/column l%32 and the k-octet l/32 of
 // a 16-deep step for both A and B, so the k-sum is consistent whatever order the hardware walks the octet in.
 // =================================================================================================
-template <int NT, int TAPS>
-__global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a)
+template <int NT, int TAPS, int STAT>       // STAT: 0 none, 1 forward statistics of the output, 2 BatchNorm-backward sums of the layer below (HColStat)
+__global__ __launch_bounds__(256, NT >= 3 ? 3 : 4) void hgemm_kernel(HGemmArgs a)       // (min waves per SIMD: the statistics epilogues must not cost the main loop its occupancy)
 {
     constexpr int BM = 128, BN = 32 * NT, KC = 32, AST = KC + 8;      // A row stride in LDS (halves): 80 bytes, conflict-free b128 reads
     constexpr int OST = BN + 8;                                        // epilogue tile row stride (halves)
@@ -172,6 +191,19 @@ __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a)
         }
     }
     // ---- epilogue: bias, h16, through LDS so that whole 16-byte row segments are written (and read, when accumulating)
+    constexpr int segs = BN / 8;                                        // 16-byte segments per tile row
+    constexpr int SEGP = segs <= 4 ? 4 : (segs <= 8 ? 8 : 16), RG = 256 / SEGP, RPT = BM / RG;      // statistics layout: SEGP octet-lanes x RG row groups
+    const int st_so = t & (SEGP - 1), st_rg = t / SEGP;
+    const int st_pc0 = n0 + st_so * 8;                                   // physical channel of the octet's first column
+    const bool st_on = STAT != 0 && st_so < segs && st_pc0 < a.Np;
+    h16x8 st_y[STAT == 2 ? RPT : 1];
+    if (STAT == 2 && st_on) {                                            // the layer below's pre-BN rows: requested now, needed after the tile has left
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int m = m0 + st_rg + k * RG;
+            st_y[k] = ldh8(a.st.y + (size_t)(m < a.M ? m : m0) * a.st.y_ld + st_pc0);
+        }
+    }
     __syncthreads();
     h16* Os = smem;
 #pragma unroll
@@ -185,7 +217,6 @@ __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a)
         }
     }
     __syncthreads();
-    const int segs = BN / 8;                                            // 16-byte segments per tile row
     for (int g = t; g < BM * segs; g += 256) {
         const int row = g / segs, sg = g - row * segs;
         const int m = m0 + row, n = n0 + sg * 8;
@@ -199,6 +230,70 @@ __global__ __launch_bounds__(256) void hgemm_kernel(HGemmArgs a)
         }
         sth8(o, v);
     }
+    // ---- optional: column sums of the tile just written (HColStat), from its fp16 values in LDS
+    if (STAT != 0) {
+        __shared__ float st_red[4][16][16];
+        const int so = st_so, rg = st_rg, pc0 = st_pc0;
+        const bool on = st_on;
+        f32x2 s0[4], s1[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { s0[p] = splat2(0.0f); s1[p] = splat2(0.0f); }
+        if (on) {
+            if (STAT == 1) {
+#pragma unroll 2
+                for (int k = 0; k < RPT; ++k) {
+                    const int row = rg + k * RG;
+                    if (m0 + row >= a.M) continue;
+                    const h16x8 v = ldh8(Os + row * OST + so * 8);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { const f32x2 x = pair_of(v, p); s0[p] += x; s1[p] = __builtin_elementwise_fma(x, x, s1[p]); }
+                }
+            } else {
+                const float negslope = act_negslope(a.st.act);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {                                    // pair by pair: the coefficients of one pair live at a time (registers decide the main loop's occupancy)
+                    const int c0 = logical_of(pc0 + 2 * p, a.st.C, a.st.half, a.st.gap), c1 = logical_of(pc0 + 2 * p + 1, a.st.C, a.st.half, a.st.gap);
+                    f32x2 mu, is, ga, be;
+                    mu.x = c0 >= 0 ? a.st.mean[c0] : 0.0f; is.x = c0 >= 0 ? a.st.invstd[c0] : 0.0f; ga.x = c0 >= 0 ? a.st.gamma[c0] : 0.0f; be.x = c0 >= 0 ? a.st.beta[c0] : 0.0f;
+                    mu.y = c1 >= 0 ? a.st.mean[c1] : 0.0f; is.y = c1 >= 0 ? a.st.invstd[c1] : 0.0f; ga.y = c1 >= 0 ? a.st.gamma[c1] : 0.0f; be.y = c1 >= 0 ? a.st.beta[c1] : 0.0f;
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const int row = rg + k * RG;
+                        const h16x2 v2 = *reinterpret_cast<const h16x2*>(Os + row * OST + so * 8 + 2 * p);
+                        f32x2 g; g.x = (float)v2[0]; g.y = (float)v2[1];
+                        if (m0 + row >= a.M) g = splat2(0.0f);                   // a row past the end: d = 0
+                        const f32x2 xh = bn_xhat2(pair_of(st_y[k], p), mu, is);
+                        const f32x2 d = act_grad2(g, bn_value2(xh, ga, be), negslope);
+                        s0[p] += d; s1[p] = __builtin_elementwise_fma(d, xh, s1[p]);
+                    }
+                }
+            }
+        }
+        for (int off = 32; off >= SEGP; off >>= 1) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                s0[p].x += __shfl_xor(s0[p].x, off); s0[p].y += __shfl_xor(s0[p].y, off);
+                s1[p].x += __shfl_xor(s1[p].x, off); s1[p].y += __shfl_xor(s1[p].y, off);
+            }
+        }
+        if (lane < SEGP) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                st_red[wave][lane][2 * p] = s0[p].x; st_red[wave][lane][2 * p + 1] = s0[p].y;
+                st_red[wave][lane][8 + 2 * p] = s1[p].x; st_red[wave][lane][8 + 2 * p + 1] = s1[p].y;
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < a.Np) {
+            const int c = logical_of(n0 + t, a.st.C, a.st.half, a.st.gap);
+            if (c >= 0) {
+                const int o = t >> 3, j = t & 7;
+                double* acc = a.st.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * a.st.C;
+                atomicAdd(acc + c, (double)((st_red[0][o][j] + st_red[1][o][j]) + (st_red[2][o][j] + st_red[3][o][j])));
+                atomicAdd(acc + a.st.C + c, (double)((st_red[0][o][8 + j] + st_red[1][o][8 + j]) + (st_red[2][o][8 + j] + st_red[3][o][8 + j])));
+            }
+        }
+    }
 }
 
 template <int NT>
@@ -206,8 +301,16 @@ static void launch_hgemm_nt(const HGemmArgs& a, hipStream_t s)
 {
     const int BN = 32 * NT;
     const dim3 grid(xcd_grid((unsigned)((a.M + 127) / 128)) * (unsigned)(a.Npad / BN));
-    if (a.taps == 9) hipLaunchKernelGGL((hgemm_kernel<NT, 9>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((hgemm_kernel<NT, 1>), grid, dim3(256), 0, s, a);
+    const int stat = !a.st.acc ? 0 : (a.st.y ? 2 : 1);
+    if (a.taps == 9) {
+        if (stat == 0) hipLaunchKernelGGL((hgemm_kernel<NT, 9, 0>), grid, dim3(256), 0, s, a);
+        else if (stat == 1) hipLaunchKernelGGL((hgemm_kernel<NT, 9, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hgemm_kernel<NT, 9, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        if (stat == 0) hipLaunchKernelGGL((hgemm_kernel<NT, 1, 0>), grid, dim3(256), 0, s, a);
+        else if (stat == 1) hipLaunchKernelGGL((hgemm_kernel<NT, 1, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hgemm_kernel<NT, 1, 2>), grid, dim3(256), 0, s, a);
+    }
 }
 
 // Npad must be a multiple of 32; the widest column tile that divides it is used (<= 128 columns: 64 accumulator registers)
@@ -555,25 +658,6 @@ __device__ __forceinline__ void load_dz8(const HRedArgs& a, size_t row, int p0, 
         }
     }
 }
-
-// Two channels per instruction: the streaming BatchNorm kernels are instruction-bound at one wavefront per SIMD (16 VALU operations per
-// element in the first form: 2.1 ms per 608 / bs-32 step for the backward sums alone), and gfx950 has packed fp32 multiply / add / fma.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pair_of(const h16x8& v, int p) { f32x2 r; r.x = (float)v[2 * p]; r.y = (float)v[2 * p + 1]; return r; }
-__device__ __forceinline__ f32x2 splat2(float x) { f32x2 r; r.x = x; r.y = x; return r; }
-// xhat and the BatchNorm value with exactly hbn_value's operation sequence (sub, mul, fma): the sign of z decides the activation's branch
-// and has to come out the same in the forward apply, the backward sums and the backward apply
-__device__ __forceinline__ f32x2 bn_xhat2(f32x2 y, f32x2 mu, f32x2 is) { return (y - mu) * is; }
-__device__ __forceinline__ f32x2 bn_value2(f32x2 xh, f32x2 ga, f32x2 be) { return __builtin_elementwise_fma(xh, ga, be); }
-// d = g * act'(z): g where z > 0, else g * negslope (0 / 0.1 / 1 for ReLU / LeakyReLU(0.1) / none)
-__device__ __forceinline__ f32x2 act_grad2(f32x2 g, f32x2 z, float negslope)
-{
-    f32x2 m;
-    m.x = z.x > 0.0f ? 1.0f : negslope;
-    m.y = z.y > 0.0f ? 1.0f : negslope;
-    return g * m;
-}
-__device__ __forceinline__ float act_negslope(int act) { return act == 1 ? 0.0f : (act == 2 ? 0.1f : 1.0f); }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void hcol_reduce_kernel(HRedArgs a)
@@ -993,9 +1077,9 @@ __global__ __launch_bounds__(256) void hbn_bwd_kernel(HRedArgs a, h16* dy /* may
     }
 }
 
-void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hipStream_t s)
+void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hipStream_t s, bool sums_done)
 {
-    launch_hcol_reduce(a0, 2, s);
+    if (!sums_done) launch_hcol_reduce(a0, 2, s);
     HRedArgs a = a0;
     a.lanes = hlanes_for(a.Cp);
     hipLaunchKernelGGL(hbn_bwd_kernel, dim3((unsigned)hstream_blocks(a.M, 256 / a.lanes)), dim3(256), 0, s, a, dy, dgamma, dbeta);

@@ -109,6 +109,7 @@ struct yn_handle {
     std::map<std::string, size_t> toff;
     std::vector<TrainPack> tpacks;
     float* zeros = nullptr;
+    hipStream_t train_side = nullptr;     // the fp16 step's weight-gradient stream (lowest priority: the main stream is the critical path)
     int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
     int train_dtype = 0;                  // 0 fp32, 1 fp16 storage + f16 MFMA (yn_train_precision)
     std::vector<HPack> hpacks;
@@ -1174,6 +1175,7 @@ void yn_destroy(yn_handle* h)
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->range_flags) (void)hipFree(h->range_flags);
     if (h->zeros) (void)hipFree(h->zeros);
+    if (h->train_side) (void)hipStreamDestroy(h->train_side);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
     if (h->hpack_table) (void)hipFree(h->hpack_table);

@@ -9,6 +9,19 @@ typedef _Float16 h16;
 // memory side: with 8 copies and 512 blocks the tail of a reduction was longer than its streaming phase)
 constexpr int HACC_SLOTS = 32;
 
+// Column sums of an hgemm output tile, taken in the kernel's epilogue while the tile sits in LDS (one launch and one pass over the
+// tensor less per BatchNorm and direction):
+//   forward (y == null):  acc[0][c] += sum out,  acc[1][c] += sum out^2      — the BatchNorm statistics of the conv output just computed;
+//   input gradient (y != null): the tile is dz of the layer BELOW (the BN + activation whose output this conv consumed); with that layer's
+//   pre-BN output y and saved statistics:  acc[0][c] += sum d,  acc[1][c] += sum d * xhat,  d = dz * act'(BN(y))  (hcol_reduce_kernel<2>'s sums).
+// Physical column p of the tile <-> logical channel logical_of(p, C, half, gap); fp32 over the tile's 128 rows, double atomics per tile.
+struct HColStat {
+    double* acc;                                // [HACC_SLOTS][2][C]; null = no statistics
+    int C, half, gap;
+    const h16* y; int y_ld;
+    const float* mean; const float* invstd; const float* gamma; const float* beta; int act;
+};
+
 // C[M][Np] (+)= A[M][Kp] (x taps) * Wp + bias — see hgemm_kernel
 struct HGemmArgs {
     const h16* in; int in_ld, in_off;           // A rows: Kp physical channels at in + m*in_ld + in_off (16-byte aligned)
@@ -17,6 +30,7 @@ struct HGemmArgs {
     h16* out; int out_ld, out_off;
     int M, Kp, Np, Npad;                        // Np = physical output channels written (multiple of 8), Npad = packed width (multiple of 32)
     int accumulate;                             // out += result (input-gradient accumulation)
+    HColStat st;                                // epilogue statistics (st.acc == null: none); not with accumulate
 };
 void launch_hgemm(const HGemmArgs& a, hipStream_t s);
 
@@ -52,7 +66,7 @@ struct HRedArgs {
     int lanes;                                  // filled by the launcher
 };
 void launch_hcol_reduce(const HRedArgs& a, int mode, hipStream_t s);      // mode 0 stats, 2 BN-backward sums, 3 column sum -> facc slots
-void launch_hbn_bwd(const HRedArgs& a, h16* dy, float* dgamma, float* dbeta, hipStream_t s);
+void launch_hbn_bwd(const HRedArgs& a, h16* dy, float* dgamma, float* dbeta, hipStream_t s, bool sums_done = false);   // sums_done: acc already holds the sums (HColStat)
 
 struct HBnApplyArgs {
     const h16* y; int y_ld; const double* acc; float eps;
