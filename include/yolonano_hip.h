@@ -322,8 +322,8 @@ int  yn_op_nhwc_to_nchw(yn_handle* h, const float* x, int B, int C, int H, int W
  * (stride 1|2), 2 dense 3x3; w / dw in the reference layouts; y = conv(x) + bias, dx / dw = the gradients for dy (null = skip). */
 int  yn_op_h16_conv(yn_handle* h, int kind, const float* x, int B, int H, int W, int Cin, int gapped, const float* w, const float* bias,
                     int Cout, int stride, const float* dy, float* y, float* dx, float* dw);
-/* The column sums the fp16 step takes in its conv kernels instead of separate reduction launches, on their own (kind 0 pointwise,
- * 1 depthwise 3x3 stride 1, 2 dense 3x3, 3 depthwise 3x3 stride 2; layouts as yn_op_h16_conv; y, dy at the output resolution): y = conv(x) with sums_fwd[0][c] = sum y, sums_fwd[1][c] = sum y^2 over the STORED fp16
+/* The column sums the fp16 step takes in its GEMM epilogues instead of separate reduction launches, on their own (kind 0 pointwise,
+ * 2 dense 3x3; layouts as yn_op_h16_conv): y = conv(x) with sums_fwd[0][c] = sum y, sums_fwd[1][c] = sum y^2 over the STORED fp16
  * values (the train-mode BatchNorm statistics, utils/modules.py:12-21);  and, when dy is given, dx = the input gradient with
  * sums_bwd[0][c] = sum d, sums_bwd[1][c] = sum d * xhat, d = dx * act'(BN(y_below)), xhat = (y_below - mean) * invstd — the two sums
  * the BatchNorm backward of the layer BELOW needs (y_below [B,H,W,Cin] its pre-BN output; mean / invstd / gamma / beta [Cin] device

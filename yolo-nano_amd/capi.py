@@ -702,8 +702,7 @@ class Handle:
         import numpy as np
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
-        Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if kind == 3 else (H, W)
-        y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
         sf = np.zeros((2, Cout), np.float64)
         dx = torch.empty_like(x) if dy is not None else None
         sb = np.zeros((2, Cin), np.float64) if dy is not None else None

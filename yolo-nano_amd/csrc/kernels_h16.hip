@@ -478,101 +478,20 @@ void launch_hwgrad(const HWgradArgs& a, hipStream_t s)
 // thread = one channel octet of one output pixel; XCD-contiguous pixel order (the 3 input rows of a window share an L2).
 // Serves the forward convs and — with flipped taps — the stride-1 input gradient (accumulate: dX += ).
 // =================================================================================================
-// Column sums for kernels whose thread owns ONE (pixel, channel octet) of the output at a time (depthwise conv / its gradients).  The
-// statistics-taking variants lay the block out as OL octet-lanes (a power of two >= the octet count) x 256/OL pixel-lanes and walk
-// a.chunks groups of pixels, so a thread keeps ONE octet and sums it in registers; the block reduces once at the end (LDS float atomics
-// per item - ds_add_f32, a few lanes per address - made the kernels 4x slower: 0.6 lane-operations per clock and CU).  STAT 1: sums of r (fp16 values just stored); STAT 2: BatchNorm-backward sums
-// of the layer below from r = dz and that layer's pre-BN y at the same (pixel, octet).  Every thread of the block must reach the flush.
-struct OctetCoef { f32x2 mu[4], is[4], ga[4], be[4]; float negslope; };
-// the BatchNorm constants of the thread's octet (STAT 2), loaded ONCE per thread: 32 scalar loads per item made the kernel 3x slower
-__device__ __forceinline__ void octet_coef_load(const HColStat& st, int c, OctetCoef& k)
-{
-    k.negslope = act_negslope(st.act);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int c0 = logical_of(c + 2 * p, st.C, st.half, st.gap), c1 = logical_of(c + 2 * p + 1, st.C, st.half, st.gap);
-        k.mu[p].x = c0 >= 0 ? st.mean[c0] : 0.0f; k.is[p].x = c0 >= 0 ? st.invstd[c0] : 0.0f; k.ga[p].x = c0 >= 0 ? st.gamma[c0] : 0.0f; k.be[p].x = c0 >= 0 ? st.beta[c0] : 0.0f;
-        k.mu[p].y = c1 >= 0 ? st.mean[c1] : 0.0f; k.is[p].y = c1 >= 0 ? st.invstd[c1] : 0.0f; k.ga[p].y = c1 >= 0 ? st.gamma[c1] : 0.0f; k.be[p].y = c1 >= 0 ? st.beta[c1] : 0.0f;
-    }
-}
-template <int STAT>
-__device__ __forceinline__ void octet_colstat_add(const HColStat& st, const OctetCoef& k, const h16x8& r, const h16x8& yv /* STAT 2: the layer below's y at (pixel, octet) */,
-                                                  f32x2 (&s0)[4], f32x2 (&s1)[4])
-{
-    if (STAT == 1) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { const f32x2 v = pair_of(r, p); s0[p] += v; s1[p] = __builtin_elementwise_fma(v, v, s1[p]); }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const f32x2 xh = bn_xhat2(pair_of(yv, p), k.mu[p], k.is[p]);
-            const f32x2 d = act_grad2(pair_of(r, p), bn_value2(xh, k.ga[p], k.be[p]), k.negslope);
-            s0[p] += d; s1[p] = __builtin_elementwise_fma(d, xh, s1[p]);
-        }
-    }
-}
-// the threads' sums -> the double slots: pixel-lanes of a wave by xor-shuffles (same octet: OL lanes apart), the four waves through LDS, one
-// thread per channel issues the two atomics.  Every thread of the block calls it once.
-__device__ __forceinline__ void octet_colstat_flush(const HColStat& st, int OL, int Cp, f32x2 (&s0)[4], f32x2 (&s1)[4], float (*red)[32][16])
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 32; off >= OL; off >>= 1) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            s0[p].x += __shfl_xor(s0[p].x, off); s0[p].y += __shfl_xor(s0[p].y, off);
-            s1[p].x += __shfl_xor(s1[p].x, off); s1[p].y += __shfl_xor(s1[p].y, off);
-        }
-    }
-    if (lane < OL) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            red[wave][lane][2 * p] = s0[p].x; red[wave][lane][2 * p + 1] = s0[p].y;
-            red[wave][lane][8 + 2 * p] = s1[p].x; red[wave][lane][8 + 2 * p + 1] = s1[p].y;
-        }
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < Cp; p += 256) {
-        const int lc = logical_of(p, st.C, st.half, st.gap);
-        if (lc < 0) continue;
-        const int o = p >> 3, j = p & 7;
-        double* acc = st.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * st.C;
-        atomicAdd(acc + lc, (double)((red[0][o][j] + red[1][o][j]) + (red[2][o][j] + red[3][o][j])));
-        atomicAdd(acc + st.C + lc, (double)((red[0][o][8 + j] + red[1][o][8 + j]) + (red[2][o][8 + j] + red[3][o][8 + j])));
-    }
-}
-
-template <int STRIDE, int STAT>
+template <int STRIDE>
 __global__ __launch_bounds__(256) void hdw_kernel(HDwArgs a)
 {
     const int Ho = (a.H - 1) / STRIDE + 1, Wo = (a.W - 1) / STRIDE + 1;
     const int OC = a.Cp >> 3;
     const long total = (long)a.B * Ho * Wo * OC;
-    __shared__ float st_red[STAT ? 4 : 1][32][16];
-    f32x2 s0[4], s1[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s0[k] = splat2(0.0f); s1[k] = splat2(0.0f); }
-    const int OL = STAT != 0 ? a.lanes : 1, PL = 256 / OL;
-    const long npix = (long)a.B * Ho * Wo;
-    const int chunks = STAT != 0 ? a.chunks : 1;
-    OctetCoef kf;
-    if (STAT == 2 && (int)(threadIdx.x & (OL - 1)) < OC) octet_coef_load(a.st, (int)(threadIdx.x & (OL - 1)) * 8, kf);
-    for (int it = 0; it < chunks; ++it) {
-    int oc; long p;
-    if (STAT == 0) {
-        const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-        if (i >= total) break;
-        oc = (int)(i % OC); p = i / OC;
-    } else {
-        oc = threadIdx.x & (OL - 1);
-        p = ((long)xcd_block(blockIdx.x, gridDim.x) * chunks + it) * PL + threadIdx.x / OL;
-        if (oc >= OC || p >= npix) continue;
-    }
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    long p = i / OC;
     const int ox = (int)(p % Wo); const long q = p / Wo;
     const int oy = (int)(q % Ho), b = (int)(q / Ho);
     const int c = oc * 8;
     h16x8 v[9];
-    h16x8 ybelow = zero8();
-    if (STAT == 2) ybelow = ldh8(a.st.y + (size_t)p * a.st.y_ld + c);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * STRIDE - 1 + ky;
@@ -608,69 +527,28 @@ __global__ __launch_bounds__(256) void hdw_kernel(HDwArgs a)
         for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
     }
     sth8(o, r);
-    if (STAT != 0) octet_colstat_add<STAT>(a.st, kf, r, ybelow, s0, s1);
-    }
-    if (STAT != 0) octet_colstat_flush(a.st, OL, a.Cp, s0, s1, st_red);
 }
 
-// pixel groups (256 / lanes pixels each) one workgroup of a statistics-taking depthwise kernel walks: about 1024 workgroups per launch, at most 16
-static int hlanes_for(int Cp);
-static int dw_stat_chunks(long npix, int lanes)
+void launch_hdw(const HDwArgs& a, hipStream_t s)
 {
-    static const int target = getenv("YN_DW_WGS") ? atoi(getenv("YN_DW_WGS")) : 1024;
-    const long n = (npix + 256 / lanes - 1) / (256 / lanes);
-    long ch = (n + target - 1) / target;
-    return (int)(ch < 1 ? 1 : (ch > 16 ? 16 : ch));
-}
-
-void launch_hdw(const HDwArgs& a0, hipStream_t s)
-{
-    HDwArgs a = a0;
     const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
     const long total = (long)a.B * Ho * Wo * (a.Cp >> 3);
-    const int stat = (!a.st.acc || a.accumulate || a.Cp > 256) ? 0 : (a.st.y ? 2 : 1);
-    a.lanes = hlanes_for(a.Cp);
-    const long npix = (long)a.B * Ho * Wo, per = 256 / a.lanes;
-    a.chunks = stat ? dw_stat_chunks(npix, a.lanes) : 1;
-    const dim3 grid(stat ? xcd_grid((unsigned)((npix + per * a.chunks - 1) / (per * a.chunks))) : xcd_grid((unsigned)((total + 255) / 256)));
-    if (a.stride == 1) {
-        if (stat == 0) hipLaunchKernelGGL((hdw_kernel<1, 0>), grid, dim3(256), 0, s, a);
-        else if (stat == 1) hipLaunchKernelGGL((hdw_kernel<1, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hdw_kernel<1, 2>), grid, dim3(256), 0, s, a);
-    } else {
-        if (stat == 0) hipLaunchKernelGGL((hdw_kernel<2, 0>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hdw_kernel<2, 1>), grid, dim3(256), 0, s, a);       // (a stride-2 conv's input gradient is hdw_dgrad_s2_kernel)
-    }
+    const dim3 grid(xcd_grid((unsigned)((total + 255) / 256)));
+    if (a.stride == 1) hipLaunchKernelGGL(hdw_kernel<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hdw_kernel<2>, grid, dim3(256), 0, s, a);
 }
 
 // depthwise 3x3 stride-2 input gradient (gather form, see dw_dgrad_s2_kernel): thread = (input pixel, channel octet); w = forward taps [9][Cp]
-template <int STAT>
 __global__ __launch_bounds__(256) void hdw_dgrad_s2_kernel(const h16* __restrict__ dy, int dy_ld, const float* __restrict__ w, int B, int H, int W, int Cp,
-                                                            h16* __restrict__ dx, int dx_ld, int dx_off, int accumulate, HColStat st, int chunks, int lanes)
+                                                            h16* __restrict__ dx, int dx_ld, int dx_off, int accumulate)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int OC = Cp >> 3;
     const long total = (long)B * H * W * OC;
-    __shared__ float st_red[STAT ? 4 : 1][32][16];
-    f32x2 s0[4], s1[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s0[k] = splat2(0.0f); s1[k] = splat2(0.0f); }
-    const int OL = STAT != 0 ? lanes : 1, PL = 256 / OL;
-    const long npix = (long)B * H * W;
-    const int nch = STAT != 0 ? chunks : 1;
-    OctetCoef kf;
-    if (STAT == 2 && (int)(threadIdx.x & (OL - 1)) < OC) octet_coef_load(st, (int)(threadIdx.x & (OL - 1)) * 8, kf);
-    for (int it = 0; it < nch; ++it) {
-    int oc; long p;
-    if (STAT == 0) {
-        const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-        if (i >= total) break;
-        oc = (int)(i % OC); p = i / OC;
-    } else {
-        oc = threadIdx.x & (OL - 1);
-        p = ((long)xcd_block(blockIdx.x, gridDim.x) * nch + it) * PL + threadIdx.x / OL;
-        if (oc >= OC || p >= npix) continue;
-    }
+    const long i = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oc = (int)(i % OC);
+    long p = i / OC;
     const int ix = (int)(p % W); const long q = p / W;
     const int iy = (int)(q % H), b = (int)(q / H);
     const int c = oc * 8;
@@ -681,8 +559,6 @@ __global__ __launch_bounds__(256) void hdw_dgrad_s2_kernel(const h16* __restrict
     ox[0] = (ix + 1) >> 1; kx[0] = ix + 1 - 2 * ox[0]; vx[0] = ox[0] < Wo;
     ox[1] = ox[0] - 1;     kx[1] = 2;                  vx[1] = kx[0] == 0 && ox[1] >= 0;
     h16x8 g[4];
-    h16x8 ybelow = zero8();
-    if (STAT == 2) ybelow = ldh8(st.y + (size_t)p * st.y_ld + c);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int e = u >> 1, f = u & 1;
@@ -708,20 +584,12 @@ __global__ __launch_bounds__(256) void hdw_dgrad_s2_kernel(const h16* __restrict
         for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
     }
     sth8(o, r);
-    if (STAT != 0) octet_colstat_add<2>(st, kf, r, ybelow, s0, s1);
-    }
-    if (STAT != 0) octet_colstat_flush(st, OL, Cp, s0, s1, st_red);
 }
 
-void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s, const HColStat* st)
+void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s)
 {
     const long total = (long)B * H * W * (Cp >> 3);
-    const bool stat = st && st->acc && st->y && !accumulate && Cp <= 256;
-    const int lanes = hlanes_for(Cp);
-    const long npix = (long)B * H * W, per = 256 / lanes;
-    const int chunks = stat ? dw_stat_chunks(npix, lanes) : 1;
-    if (stat) hipLaunchKernelGGL(hdw_dgrad_s2_kernel<2>, dim3(xcd_grid((unsigned)((npix + per * chunks - 1) / (per * chunks)))), dim3(256), 0, s, dy, dy_ld, w, B, H, W, Cp, dx, dx_ld, dx_off, accumulate, *st, chunks, lanes);
-    else hipLaunchKernelGGL(hdw_dgrad_s2_kernel<0>, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, dy_ld, w, B, H, W, Cp, dx, dx_ld, dx_off, accumulate, HColStat{}, 1, 1);
+    hipLaunchKernelGGL(hdw_dgrad_s2_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, dy_ld, w, B, H, W, Cp, dx, dx_ld, dx_off, accumulate);
 }
 
 // =================================================================================================
@@ -1218,15 +1086,15 @@ void launch_hbn_bwd(const HRedArgs& a0, h16* dy, float* dgamma, float* dbeta, hi
 }
 
 // =================================================================================================
-// Depthwise weight gradient: dW[c][tap] += sum_p dY[p][c] * X[p*stride + tap - 1][c]  -> fp32 atomics into the gradient slots
-// (reference layout [C][1][3][3], logical channels).  Block = OL octet-lanes x row-lanes; a row-lane takes a contiguous range
-// of output pixels; LDS combine, one atomic per (c, tap) per block.
+// Depthwise weight gradient: dW[c][tap] += sum_p dY[p][c] * X[p*stride + tap - 1][c]  (reference layout [C][1][3][3], logical channels).
+// Block = OL octet-lanes x row-lanes; a row-lane takes a contiguous range of output pixels; the block's partial [C][9] goes to its own row of
+// a scratch matrix, a second small kernel adds the rows into dW.
 // =================================================================================================
 template <int STRIDE>
 __global__ __launch_bounds__(256) void hdw_wgrad_kernel(const h16* __restrict__ dy, int dy_ld, const h16* __restrict__ x, int x_ld, int x_off,
-                                                         int B, int H, int W, int C, int Cp, int half, int gap, float* __restrict__ dw, size_t slot_stride, int OL)
+                                                         int B, int H, int W, int C, int Cp, int half, int gap, float* __restrict__ part, int OL)
 {
-    __shared__ float red[256][9];
+    __shared__ float red[128][9];
     const int Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const int rowsPer = 256 / OL;
     const int ol = threadIdx.x & (OL - 1), rl = threadIdx.x / OL;
@@ -1246,7 +1114,7 @@ __global__ __launch_bounds__(256) void hdw_wgrad_kernel(const h16* __restrict__ 
         const long nruns = (long)B * Ho * runsPerRow;
         const long lanes_total = (long)gridDim.x * rowsPer;
         const long per = (nruns + lanes_total - 1) / lanes_total;
-        const long begin = ((long)xcd_block(blockIdx.x, gridDim.x) * rowsPer + rl) * per;
+        const long begin = ((long)blockIdx.x * rowsPer + rl) * per;
         const long end = begin + per < nruns ? begin + per : nruns;
         for (long u = begin; u < end; ++u) {
             const int seg = (int)(u % runsPerRow); const long row = u / runsPerRow;
@@ -1279,40 +1147,68 @@ __global__ __launch_bounds__(256) void hdw_wgrad_kernel(const h16* __restrict__ 
                         for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += (float)g[o][j] * (float)col[ky][o * STRIDE + kx][j];
         }
     }
-    // combine the row-lanes, one channel of the octet at a time (9 floats per thread per round)
+    // combine: the row-lanes of a wave by xor-shuffles (same octet: OL lanes apart), the four waves through LDS one channel of the octet at a
+    // time, and the block's [C][9] partial goes to ITS OWN row of `part` with plain stores (hdw_wgrad_sum_kernel adds the rows up).  The first
+    // form sent every block's 9*C values to 8 gradient slots with fp32 atomics: the same-address chains capped the grid at a few hundred
+    // blocks (24-368: most of the chip idle, 32-110 us per layer) and made more blocks SLOWER (2048 blocks: 3x).
+    for (int off = 32; off >= OL; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] += __shfl_xor(acc[k][j], off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* prow = part + (size_t)blockIdx.x * C * 9;
     for (int j = 0; j < 8; ++j) {
         __syncthreads();
+        if (lane < OL) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) red[threadIdx.x][k] = acc[k][j];
+            for (int k = 0; k < 9; ++k) red[wave * 32 + lane][k] = acc[k][j];
+        }
         __syncthreads();
-        if (rl == 0 && live) {
+        if (threadIdx.x < OL && live) {
             const int lc = logical_of(c0 + j, C, half, gap);
             if (lc >= 0) {
-                float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride + (size_t)lc * 9;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    float sum = 0.0f;
-                    for (int r = 0; r < rowsPer; ++r) sum += red[r * OL + ol][k];
-                    atomicAdd(out + k, sum);
-                }
+                for (int k = 0; k < 9; ++k) prow[(size_t)lc * 9 + k] = (red[ol][k] + red[32 + ol][k]) + (red[64 + ol][k] + red[96 + ol][k]);
             }
         }
     }
 }
 
+// dw[i] += sum over the G block rows of part[g][i]  (i < n = 9 * C); grid (ceil(n / 256), GY): block row y sums its slice of g and adds it with
+// one atomic per element (GY same-address atomics: nothing)
+__global__ __launch_bounds__(256) void hdw_wgrad_sum_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ dw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int per = (G + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+        s0 += part[(size_t)g * n + i]; s1 += part[(size_t)(g + 1) * n + i]; s2 += part[(size_t)(g + 2) * n + i]; s3 += part[(size_t)(g + 3) * n + i];
+    }
+    for (; g < g1; ++g) s0 += part[(size_t)g * n + i];
+    if (g1 > g0) atomicAdd(dw + i, (s0 + s1) + (s2 + s3));
+}
+
 void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_off, int B, int H, int W, int C, int Cp, int half, int gap, int stride,
-                      float* dw, size_t slot_stride, hipStream_t s)
+                      float* dw, float* part, size_t part_cap, hipStream_t s)
 {
     const int OL = hlanes_for(Cp);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long npix = (long)B * Ho * ((Wo + 3) / 4);                    // runs of 4 output pixels
-    long G = (npix + (256 / OL) * 8 - 1) / ((256 / OL) * 8);
-    static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 512;
+    static const int runs = getenv("YN_DWW_RUNS") ? atoi(getenv("YN_DWW_RUNS")) : 4;
+    long G = (npix + (256 / OL) * runs - 1) / ((256 / OL) * runs);
+    static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 2048;
     if (G > gmax) G = gmax;
+    if ((size_t)G * C * 9 > part_cap) G = (long)(part_cap / ((size_t)C * 9));
     if (G < 1) G = 1;
-    G = (long)xcd_grid((unsigned)G);
-    if (stride == 1) hipLaunchKernelGGL(hdw_wgrad_kernel<1>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, dw, slot_stride, OL);
-    else hipLaunchKernelGGL(hdw_wgrad_kernel<2>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, dw, slot_stride, OL);
+    if (stride == 1) hipLaunchKernelGGL(hdw_wgrad_kernel<1>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, part, OL);
+    else hipLaunchKernelGGL(hdw_wgrad_kernel<2>, dim3((unsigned)G), dim3(256), 0, s, dy, dy_ld, x, x_ld, x_off, B, H, W, C, Cp, half, gap, part, OL);
+    const int n = C * 9;
+    hipLaunchKernelGGL(hdw_wgrad_sum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(G >= 64 ? 16 : 1)), dim3(256), 0, s, part, (int)G, n, dw);
 }
 
 // =================================================================================================

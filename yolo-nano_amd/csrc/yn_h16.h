@@ -50,14 +50,11 @@ struct HDwArgs {
     const float* w; const float* bias;          // [9][Cp], [Cp] or null
     h16* out; int out_ld, out_off;
     int B, H, W, Cp, stride, accumulate;
-    HColStat st;                                // column sums of the output, as hgemm's (st.acc == null: none; not with accumulate): through LDS atomics
-    int chunks, lanes;                          // filled by the launcher
 };
 void launch_hdw(const HDwArgs& a, hipStream_t s);
-void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s,
-                         const HColStat* st = nullptr);
+void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
 void launch_hdw_wgrad(const h16* dy, int dy_ld, const h16* x, int x_ld, int x_off, int B, int H, int W, int C, int Cp, int half, int gap, int stride,
-                      float* dw_slots, size_t slot_stride, hipStream_t s);
+                      float* dw /* [C][9], added to */, float* part /* scratch, part_cap floats */, size_t part_cap, hipStream_t s);
 
 struct HRedArgs {
     const h16* y; int y_ld, y_off;              // the matrix (stats / column sum) or the pre-BN conv output (BN backward)
