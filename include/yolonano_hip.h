@@ -288,6 +288,11 @@ int  yn_train_skipped_steps(yn_handle* h, int64_t* count_host);
  * gradients / the optimiser stay fp32 on the fp32 master weights, and the loss gradient is multiplied by a dynamic loss scale
  * kept on the device (halved when a step's gradients overflow — that step is skipped — doubled after 2000 clean steps). */
 int  yn_train_precision(yn_handle* h, int dtype);
+/* Opt-in: the fp16 step replays everything between its host-side preparation and the optimiser (~540 launches on two streams) from a
+ * hipGraph once the same (x, target, batch, grid) has been seen twice on a handle with a stream of its own; callers whose tensors'
+ * addresses never repeat stay on direct launches.  Off by default: measured slower than direct launches on this runtime.
+ * enable: 1 / 0 switch it, -1 leaves it; replays (optional) receives the number of steps served from a graph so far. */
+int  yn_train_graph(yn_handle* h, int enable, int64_t* replays);
 
 /* ---- single operators (op-level parity tests; NHWC float32 device tensors) ------------------ */
 /* weights in the reference (torch) layout on the DEVICE: dw [C,1,3,3], pw [Cout,Cin,1,1],

@@ -199,6 +199,45 @@ def test_h16_gemm_epilogue_sums(hop, kind, Cin, Cout, gapped, B, H, W, act):
     assert within(sb[1], (d * xh).sum(0).numpy(), float(2e-5 * (dxq.abs() * xh.abs()).sum(0).max()) + (slack * xh.abs().max()).numpy()), np.abs(sb[1] - (d * xh).sum(0).numpy()).max()
 
 
+def test_h16_step_replayed_from_a_graph(golden):
+    """The step's body as a hipGraph (opt-in, yn_train_graph): the first two steps on given tensors launch directly, the third is captured,
+    later ones replay.  Without updates every step computes the same thing, so the replayed steps must reproduce the directly launched ones
+    (losses 1e-4, every gradient to atomic-summation noise); the running statistics keep moving across replays; with updates the replayed
+    steps train; other input tensors fall back to direct launches; a handle that never uses a graph agrees step for step."""
+    g = golden("train.npz")
+    S, C, B = 128, 20, 4
+    x, target = torch.as_tensor(weights.make_input(B, S, seed=9)).cuda(), torch.as_tensor(_targets(S, C, B)).cuda()
+    stream = torch.cuda.Stream()                                                 # capture needs a stream of the handle's own (not the legacy default one)
+    torch.cuda.synchronize()
+    runs = {}
+    for name, use in (("graph", True), ("direct", False)):
+        h, sd = _handle(S, C, B, float(g["init_bias_value"]))
+        h.train_precision("f16")
+        h.set_stream(stream)
+        h.train_graph(use)
+        with torch.cuda.stream(stream):
+            losses, grads, rmean = [], [], []
+            for it in range(5):                                                  # no updates: five times the same step (1-2 direct, 3 captured + replayed, 4-5 replayed)
+                losses.append(h.train_step(x, target, lr=1e-4, update=False).cpu().numpy())
+                grads.append(h.flat_grads.clone())
+                rmean.append(h.read_param("backbone.conv1.1.running_mean", (24,)).copy())
+            assert h.train_graph() == (3 if use else 0), (name, h.train_graph())
+            for it in range(1, 5):
+                np.testing.assert_allclose(losses[it], losses[0], rtol=1e-4)
+                assert float((grads[it] - grads[0]).abs().max()) <= 2e-3 * float(grads[0].abs().max()), (name, it)
+                assert np.abs(rmean[it] - rmean[it - 1]).max() > 0                # the momentum update ran again
+            trained = [h.train_step(x, target, lr=1e-4, momentum=0.9, weight_decay=5e-4, update=True).cpu().numpy() for _ in range(6)]
+            assert h.train_graph() == (9 if use else 0) and h.skipped_steps() == 0
+            assert np.isfinite(trained).all() and float(trained[-1].sum()) < float(trained[0].sum())
+            x2 = x.clone()                                                       # other tensors: not in the cache, direct launches again
+            assert np.isfinite(h.train_step(x2, target, lr=1e-4, update=False).cpu().numpy()).all() and h.train_graph() == (9 if use else 0)
+            runs[name] = (np.array(losses), grads[0])
+        stream.synchronize()
+        h.close()
+    np.testing.assert_allclose(runs["graph"][0], runs["direct"][0], rtol=1e-4)
+    assert float((runs["graph"][1] - runs["direct"][1]).abs().max()) <= 2e-3 * float(runs["direct"][1].abs().max())
+
+
 def _oracles(sd, backbone, C, x, target, S):
     from oracle.torch_port import TrainNet
     mk = lambda **kw: TrainNet(sd, backbone, C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=torch.float64, **kw)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "yn_train_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_train_skipped_steps": (_i32, [_vp, _i64p]),
     "yn_train_precision": (_i32, [_vp, _i32]),
+    "yn_train_graph": (_i32, [_vp, _i32, _vp]),
     "yn_train_get_loss_scale": (_i32, [_vp, ctypes.POINTER(_f32), ctypes.POINTER(_f32)]),
     "yn_train_set_loss_scale": (_i32, [_vp, _f32, _f32]),
     "yn_make_targets": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
@@ -696,6 +697,12 @@ class Handle:
         self._ck(self.lib.yn_op_h16_bn(self.h, self._in(y).data_ptr(), _ptr(self._in(dz) if dz is not None else None), M, C, gamma.data_ptr(), beta.data_ptr(),
                                        int(act), z.data_ptr(), _ptr(dy), _ptr(dg), _ptr(db)), "yn_op_h16_bn")
         return z, dy, dg, db
+
+    def train_graph(self, enable=None):
+        """Switch the fp16 step's hipGraph replay (None: leave); -> number of steps served from a graph so far."""
+        n = ctypes.c_int64(0)
+        self._ck(self.lib.yn_train_graph(self.h, -1 if enable is None else int(bool(enable)), ctypes.byref(n)), "yn_train_graph")
+        return int(n.value)
 
     def op_h16_gemm_stats(self, kind, x, w, gapped=False, dy=None, y_below=None, mean=None, invstd=None, gamma=None, beta=None, act=0):
         """hgemm with its HColStat epilogue: -> y, sums_fwd (numpy double [2][Cout]) and, with dy, dx, sums_bwd ([2][Cin])."""

@@ -62,6 +62,7 @@ struct ProfRec {
     double flops, bytes;
 };
 
+struct TrainGraph { std::vector<uintptr_t> key; hipGraphExec_t exec; int direct_runs; };      // the fp16 training step's body as a graph (yn_train_h16.inc)
 struct GraphEntry {
     std::vector<uintptr_t> key;
     hipGraphExec_t exec = nullptr;
@@ -109,6 +110,8 @@ struct yn_handle {
     std::map<std::string, size_t> toff;
     std::vector<TrainPack> tpacks;
     float* zeros = nullptr;
+    float* train_losses = nullptr;        // device float[4]: the step's body writes its losses here (a fixed address for the graph), copied to the caller's buffer afterwards
+    std::vector<TrainGraph> train_graphs; int train_graph_misses = 0; bool train_graph = false; int64_t train_graph_replays = 0;   // yn_train_graph
     hipStream_t train_side = nullptr;     // the fp16 step's weight-gradient stream (lowest priority: the main stream is the critical path)
     int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
     int train_dtype = 0;                  // 0 fp32, 1 fp16 storage + f16 MFMA (yn_train_precision)
@@ -285,8 +288,16 @@ size_t network_arena_bytes(yn_handle* h, int B, int S)
 }
 
 // every cached hipGraphExec_t refers to the buffers it was captured with: destroy them whenever those go away
+void drop_train_graphs(yn_handle* h)
+{
+    if (!h->train_graphs.empty()) (void)hipStreamSynchronize(h->stream);
+    for (TrainGraph& g : h->train_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->train_graphs.clear();
+}
+
 void drop_graphs(yn_handle* h)
 {
+    drop_train_graphs(h);
     if (!h->graphs.empty()) (void)hipStreamSynchronize(h->stream);     // a replay may still be in flight (the setters below reach here without draining)
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     h->graphs.clear();
@@ -1175,7 +1186,9 @@ void yn_destroy(yn_handle* h)
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->range_flags) (void)hipFree(h->range_flags);
     if (h->zeros) (void)hipFree(h->zeros);
+    for (TrainGraph& g : h->train_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (h->train_side) (void)hipStreamDestroy(h->train_side);
+    if (h->train_losses) (void)hipFree(h->train_losses);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
     if (h->hpack_table) (void)hipFree(h->hpack_table);
