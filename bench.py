@@ -759,7 +759,7 @@ def main():
             extras["infer_0.5x_416_bs128"] = side_workload(args, dev, rank, world, dist, 416, 128, "0.5x", 60, 24, ns)          # BASELINE configs[3]
         extras["infer_exact_f32_%s_%d_bs%d" % (args.backbone, S, B)] = side_workload(args, dev, rank, world, dist, S, B, args.backbone, 40, 12, ns, exact=True)   # the headline workload on the f32 MFMA only
         targs = argparse.Namespace(**vars(args))
-        targs.size, targs.batch, targs.steps, targs.warmup, targs.backbone = 608, 32, 12, 3, "1.0x"
+        targs.size, targs.batch, targs.steps, targs.warmup, targs.backbone = 608, 32, 12, 7, "1.0x"          # (warm-up: allocation steps + the handle's four head-fork trial steps)
         for dt in ("f16", "f32"):                                                                                               # BASELINE configs[2]
             try:
                 extras["train_608_bs32_" + dt] = train_bench(targs, rank, world, dev, dist, dt, brief=True)

@@ -201,7 +201,7 @@ def test_h16_gemm_epilogue_sums(hop, kind, Cin, Cout, gapped, B, H, W, act):
 
 def test_h16_step_replayed_from_a_graph(golden):
     """The step's body as a hipGraph (opt-in, yn_train_graph): the first two steps on given tensors launch directly, the third is captured,
-    later ones replay.  Without updates every step computes the same thing, so the replayed steps must reproduce the directly launched ones
+    later ones replay (steps 2-5 of a handle's life also time the step with and without the head-tower forks; the graph starts after that).  Without updates every step computes the same thing, so the replayed steps must reproduce the directly launched ones
     (losses 1e-4, every gradient to atomic-summation noise); the running statistics keep moving across replays; with updates the replayed
     steps train; other input tensors fall back to direct launches; a handle that never uses a graph agrees step for step."""
     g = golden("train.npz")
@@ -216,21 +216,28 @@ def test_h16_step_replayed_from_a_graph(golden):
         h.set_stream(stream)
         h.train_graph(use)
         with torch.cuda.stream(stream):
-            losses, grads, rmean = [], [], []
-            for it in range(5):                                                  # no updates: five times the same step (1-2 direct, 3 captured + replayed, 4-5 replayed)
+            losses, grads, rmean, served = [], [], [], []
+            for it in range(10):                                                 # no updates: ten times the same step (direct, the head-fork trials, captured, replayed)
                 losses.append(h.train_step(x, target, lr=1e-4, update=False).cpu().numpy())
                 grads.append(h.flat_grads.clone())
                 rmean.append(h.read_param("backbone.conv1.1.running_mean", (24,)).copy())
-            assert h.train_graph() == (3 if use else 0), (name, h.train_graph())
-            for it in range(1, 5):
+                served.append(h.train_graph())
+            if use:
+                first = next(i for i, n in enumerate(served) if n > 0)
+                assert first <= 6 and served[first:] == list(range(1, 10 - first + 1)), served      # from the first replay on every step comes from the graph
+            else:
+                assert served[-1] == 0
+            for it in range(1, 10):
                 np.testing.assert_allclose(losses[it], losses[0], rtol=1e-4)
                 assert float((grads[it] - grads[0]).abs().max()) <= 2e-3 * float(grads[0].abs().max()), (name, it)
                 assert np.abs(rmean[it] - rmean[it - 1]).max() > 0                # the momentum update ran again
+            n0 = h.train_graph()
             trained = [h.train_step(x, target, lr=1e-4, momentum=0.9, weight_decay=5e-4, update=True).cpu().numpy() for _ in range(6)]
-            assert h.train_graph() == (9 if use else 0) and h.skipped_steps() == 0
+            assert h.train_graph() == (n0 + 6 if use else 0) and h.skipped_steps() == 0
             assert np.isfinite(trained).all() and float(trained[-1].sum()) < float(trained[0].sum())
+            n1 = h.train_graph()
             x2 = x.clone()                                                       # other tensors: not in the cache, direct launches again
-            assert np.isfinite(h.train_step(x2, target, lr=1e-4, update=False).cpu().numpy()).all() and h.train_graph() == (9 if use else 0)
+            assert np.isfinite(h.train_step(x2, target, lr=1e-4, update=False).cpu().numpy()).all() and h.train_graph() == n1
             runs[name] = (np.array(losses), grads[0])
         stream.synchronize()
         h.close()

@@ -112,6 +112,8 @@ struct yn_handle {
     float* zeros = nullptr;
     float* train_losses = nullptr;        // device float[4]: the step's body writes its losses here (a fixed address for the graph), copied to the caller's buffer afterwards
     std::vector<TrainGraph> train_graphs; int train_graph_misses = 0; bool train_graph = false; int64_t train_graph_replays = 0;   // yn_train_graph
+    int head_fork = -1, head_fork_now = 0, fork_trials = 0;      // -1: undecided (steps 3-6 time the step with and without the forks), else the choice
+    hipEvent_t fork_ev[8] = {};           // timing events of the trials
     hipStream_t train_fork[2] = {nullptr, nullptr};      // the head towers of levels 3 / 4 (forward and backward) beside the main stream
     hipStream_t train_side = nullptr;     // the fp16 step's weight-gradient stream (lowest priority: the main stream is the critical path)
     int* skip_flag = nullptr;             // device int[2]: [0] this step's gradient is non-finite, [1] number of skipped updates
@@ -1190,6 +1192,7 @@ void yn_destroy(yn_handle* h)
     for (TrainGraph& g : h->train_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (h->train_side) (void)hipStreamDestroy(h->train_side);
     for (int i = 0; i < 2; ++i) if (h->train_fork[i]) (void)hipStreamDestroy(h->train_fork[i]);
+    for (int i = 0; i < 8; ++i) if (h->fork_ev[i]) (void)hipEventDestroy(h->fork_ev[i]);
     if (h->train_losses) (void)hipFree(h->train_losses);
     if (h->skip_flag) (void)hipFree(h->skip_flag);
     if (h->scale_state) (void)hipFree(h->scale_state);
