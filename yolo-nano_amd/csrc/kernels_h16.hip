@@ -1372,7 +1372,9 @@ void launch_hstem_wgrad(const h16* dy, const float* x, int B, int H, int W, floa
 }
 
 // ---- 3x3 stride-2 max pool with recorded arg-max (first maximum in scan order, as ATen) and its gather-form backward; C = 24
-__global__ __launch_bounds__(256) void hmaxpool_idx_kernel(const h16* __restrict__ x, int B, int H, int W, int Cp, h16* __restrict__ y, int32_t* __restrict__ idx)
+// The argmax is kept as the WINDOW POSITION (ky * 3 + kx, one byte per channel: 8 bytes per octet instead of 32 for pixel indices —
+// the backward kernel reads four windows' worth per input pixel).  First maximum in window order wins, as F.max_pool2d's index does.
+__global__ __launch_bounds__(256) void hmaxpool_idx_kernel(const h16* __restrict__ x, int B, int H, int W, int Cp, h16* __restrict__ y, uint8_t* __restrict__ idx)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, OC = Cp >> 3;
     const long total = (long)B * Ho * Wo * OC;
@@ -1382,27 +1384,42 @@ __global__ __launch_bounds__(256) void hmaxpool_idx_kernel(const h16* __restrict
     const long p = i / OC;
     const int ox = (int)(p % Wo); const long q = p / Wo;
     const int oy = (int)(q % Ho), b = (int)(q / Ho);
+    h16x8 v[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            ok[ky * 3 + kx] = yok && ix >= 0 && ix < W;
+            v[ky * 3 + kx] = ldh8(x + ((size_t)(b * H + (yok ? iy : 0)) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix))) * Cp + oc * 8);
+        }
+    }
     float m[8]; int best[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; best[j] = -1; }
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const h16x8 v = ldh8(x + ((size_t)(b * H + iy) * W + ix) * Cp + oc * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if ((float)v[j] > m[j] || best[j] < 0) { m[j] = (float)v[j]; best[j] = iy * W + ix; }
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool take = ok[k] && ((float)v[k][j] > m[j] || best[j] < 0);
+            m[j] = take ? (float)v[k][j] : m[j];
+            best[j] = take ? k : best[j];
         }
-    }
     h16x8 r;
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { r[j] = (h16)m[j]; idx[(size_t)p * Cp + oc * 8 + j] = best[j]; }
+    for (int j = 0; j < 8; ++j) {
+        r[j] = (h16)m[j];
+        if (j < 4) lo |= (unsigned)(best[j] & 0xff) << (8 * j); else hi |= (unsigned)(best[j] & 0xff) << (8 * (j - 4));
+    }
+    *reinterpret_cast<uint2*>(idx + (size_t)p * Cp + oc * 8) = make_uint2(lo, hi);
     sth8(y + (size_t)p * Cp + oc * 8, r);
 }
 
-__global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const h16* __restrict__ dy, const int32_t* __restrict__ idx, int B, int H, int W, int Cp, h16* __restrict__ dx)
+__global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const h16* __restrict__ dy, const uint8_t* __restrict__ idx, int B, int H, int W, int Cp, h16* __restrict__ dx)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, OC = Cp >> 3;
     const long total = (long)B * H * W * OC;
@@ -1412,33 +1429,42 @@ __global__ __launch_bounds__(256) void hmaxpool_bwd_kernel(const h16* __restrict
     const long p = i / OC;
     const int ix = (int)(p % W); const long q = p / W;
     const int iy = (int)(q % H), b = (int)(q / H);
-    const int me = iy * W + ix;
     int oy[2], ox[2]; bool vy[2], vx[2];
     oy[0] = (iy + 1) >> 1; vy[0] = oy[0] < Ho; oy[1] = oy[0] - 1; vy[1] = (iy & 1) && oy[1] >= 0;
     ox[0] = (ix + 1) >> 1; vx[0] = ox[0] < Wo; ox[1] = ox[0] - 1; vx[1] = (ix & 1) && ox[1] >= 0;
+    h16x8 g[4];
+    uint2 cd[4];
+    unsigned me[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = u >> 1, f = u & 1;
+        const size_t o = ((size_t)(b * Ho + (vy[e] ? oy[e] : 0)) * Wo + (vx[f] ? ox[f] : 0)) * Cp + oc * 8;
+        g[u] = ldh8(dy + o);
+        cd[u] = *reinterpret_cast<const uint2*>(idx + o);
+        me[u] = (vy[e] && vx[f]) ? (unsigned)((iy - (2 * oy[e] - 1)) * 3 + (ix - (2 * ox[f] - 1))) : 0xffu;      // this pixel's position in that window (0xff: no such window)
+    }
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const bool ok = vy[u >> 1] && vx[u & 1];
-        const size_t o = ((size_t)(b * Ho + (vy[u >> 1] ? oy[u >> 1] : 0)) * Wo + (vx[u & 1] ? ox[u & 1] : 0)) * Cp + oc * 8;
-        const h16x8 g = ldh8(dy + o);
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += (ok && idx[o + j] == me) ? (float)g[j] : 0.0f;
-    }
+        for (int j = 0; j < 8; ++j) {
+            const unsigned c = ((j < 4 ? cd[u].x : cd[u].y) >> (8 * (j & 3))) & 0xffu;
+            acc[j] += c == me[u] ? (float)g[u][j] : 0.0f;
+        }
     h16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
     sth8(dx + (size_t)p * Cp + oc * 8, r);
 }
 
-void launch_hmaxpool_idx(const h16* x, int B, int H, int W, int Cp, h16* y, int32_t* idx, hipStream_t s)
+void launch_hmaxpool_idx(const h16* x, int B, int H, int W, int Cp, h16* y, uint8_t* idx, hipStream_t s)
 {
     const long total = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (Cp >> 3);
     hipLaunchKernelGGL(hmaxpool_idx_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, x, B, H, W, Cp, y, idx);
 }
-void launch_hmaxpool_bwd(const h16* dy, const int32_t* idx, int B, int H, int W, int Cp, h16* dx, hipStream_t s)
+void launch_hmaxpool_bwd(const h16* dy, const uint8_t* idx, int B, int H, int W, int Cp, h16* dx, hipStream_t s)
 {
     const long total = (long)B * H * W * (Cp >> 3);
     hipLaunchKernelGGL(hmaxpool_bwd_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, idx, B, H, W, Cp, dx);
