@@ -517,7 +517,7 @@ void launch_wgrad(const WgradArgs& a, hipStream_t s)
 //      registers.  LDS combine over the row-lanes, one float atomic per (c, tap) per block into the block's gradient slot.
 template <int STRIDE, bool XVEC>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int x_ld, int x_off,
-                                                        int B, int H, int W, int C, float* __restrict__ dw, size_t slot_stride, int lanesC)
+                                                        int B, int H, int W, int C, float* __restrict__ part, int lanesC)
 {
     __shared__ float red[256][19];
     constexpr int RUN = STRIDE == 1 ? 8 : 4;
@@ -588,32 +588,55 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
             for (int j = 1; j < rowsPer; ++j)
 #pragma unroll
                 for (int k = 0; k < 18; ++k) acc[k] += red[j * lanesC + cl][k];
-            float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride;
+            float* out = part + (size_t)blockIdx.x * C * 9;         // the block's own row of the scratch matrix (rows_sum_kernel adds the rows up)
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                atomicAdd(out + (size_t)c0 * 9 + k, acc[2 * k]);
-                if (has1) atomicAdd(out + (size_t)(c0 + 1) * 9 + k, acc[2 * k + 1]);
+                out[(size_t)c0 * 9 + k] = acc[2 * k];
+                if (has1) out[(size_t)(c0 + 1) * 9 + k] = acc[2 * k + 1];
             }
         }
     }
 }
 
-void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, size_t slot_stride, hipStream_t s)
+// out[i] += sum over the G rows of part[g][i]; grid (ceil(n / 256), GY): block row y sums its slice of g, one atomic per element
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int per = (G + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = g0 + per < G ? g0 + per : G;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+        s0 += part[(size_t)g * n + i]; s1 += part[(size_t)(g + 1) * n + i]; s2 += part[(size_t)(g + 2) * n + i]; s3 += part[(size_t)(g + 3) * n + i];
+    }
+    for (; g < g1; ++g) s0 += part[(size_t)g * n + i];
+    if (g1 > g0) atomicAdd(out + i, (s0 + s1) + (s2 + s3));
+}
+
+void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, float* part, size_t part_cap, hipStream_t s)
 {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const int run = stride == 1 ? 8 : 4;
     const int runs = B * Ho * ((Wo + run - 1) / run);
     const Lanes L = lanes_for(C);
-    int G = (runs + L.rowsPer - 1) / L.rowsPer;
-    static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 128;
+    // per-block partial rows instead of atomics into 8 slots (round 3, as the fp16 step's hdw_wgrad_kernel): the same-address chains had capped
+    // the grid at 128 blocks
+    static const int rpl = getenv("YN_DWW_RUNS") ? atoi(getenv("YN_DWW_RUNS")) : 2;
+    int G = (runs + L.rowsPer * rpl - 1) / (L.rowsPer * rpl);
+    static const int gmax = getenv("YN_DWW_G") ? atoi(getenv("YN_DWW_G")) : 1024;
     if (G > gmax) G = gmax;
-    if (G < 1) G = 1;
+    if ((size_t)G * C * 9 > part_cap) G = (int)(part_cap / ((size_t)C * 9));
+    if (G < 8) G = 8;
     G = (int)xcd_grid((unsigned)G);                         // multiple of 8 for xcd_block
+    if ((size_t)G * C * 9 > part_cap) G -= 8;
     const bool vec = !(C & 1) && !(x_ld & 1) && !(x_off & 1);
-#define YN_DWW(ST, V) hipLaunchKernelGGL((dw_wgrad_kernel<ST, V>), dim3(G), dim3(256), 0, s, dy, x, x_ld, x_off, B, H, W, C, dw, slot_stride, L.lanesC)
+#define YN_DWW(ST, V) hipLaunchKernelGGL((dw_wgrad_kernel<ST, V>), dim3(G), dim3(256), 0, s, dy, x, x_ld, x_off, B, H, W, C, part, L.lanesC)
     if (stride == 1) { if (vec) YN_DWW(1, true); else YN_DWW(1, false); }
     else { if (vec) YN_DWW(2, true); else YN_DWW(2, false); }
 #undef YN_DWW
+    const int n = C * 9;
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(G >= 64 ? 16 : 1)), dim3(256), 0, s, part, G, n, dw);
 }
 
 // ---- gradient slots -> the flat gradient buffer: g[i] += sum_s slots[s][i]

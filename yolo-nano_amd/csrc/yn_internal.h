@@ -200,7 +200,8 @@ void launch_grad_combine(float* g, const float* slots, long n, size_t stride, hi
 void launch_bn_apply(const BnApplyArgs& a, hipStream_t s);
 void launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 void launch_wgrad(const WgradArgs& a, hipStream_t s);
-void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw, size_t slot_stride, hipStream_t s);
+void launch_dw_wgrad(const float* dy, const float* x, int x_ld, int x_off, int B, int H, int W, int C, int stride, float* dw /* [C][9], added to */,
+                     float* part /* scratch */, size_t part_cap /* floats */, hipStream_t s);
 void launch_dw_dgrad_s2(const float* dy, const float* w, int B, int H, int W, int C, float* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
 void launch_stem_wgrad(const float* dy, const float* x, int B, int H, int W, int Cout, float* dw, float* partial, size_t partial_cap, hipStream_t s);
 void launch_maxpool_idx(const float* x, int B, int H, int W, int C, float* y, int32_t* idx, hipStream_t s);
