@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel stats of the fp16 training step on the GPU box, per step.   bash tools/train_ab.sh [size] [steps] [env assignments to compare, e.g. YN_RED_G=512]
+# Kernel stats of the training step (DTYPE=f16|f32, default f16) on the GPU box, per step.   bash tools/train_ab.sh [size] [steps] [env assignments to compare, e.g. YN_RED_G=512]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/train_ab
 mkdir -p $O
@@ -9,7 +9,7 @@ for f in base "$@"; do
     [ "$f" != base ] && export "$f"
     tag=$(echo $f | tr '= ' '__')
     rm -rf /tmp/yn_tab_$tag
-    rocprofv3 --kernel-trace --stats -d /tmp/yn_tab_$tag -o run --output-format csv -- python3 $R/bench.py --train --dtype f16 --size $S --batch 32 --steps $N --warmup 5 > $O/log_$tag.txt 2>&1
+    rocprofv3 --kernel-trace --stats -d /tmp/yn_tab_$tag -o run --output-format csv -- python3 $R/bench.py --train --dtype ${DTYPE:-f16} --size $S --batch 32 --steps $N --warmup 5 > $O/log_$tag.txt 2>&1
     cp $(find /tmp/yn_tab_$tag -name "*kernel_stats.csv" | head -1) $O/stats_$tag.csv
     echo "== $f: $(grep -o '"ms_per_step": [0-9.]*' $O/log_$tag.txt)"
     python3 - $O/stats_$tag.csv $((N + 5)) <<'PY'
