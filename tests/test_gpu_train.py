@@ -398,8 +398,8 @@ def test_multi_scale_training_through_set_grid(golden, precision):
             if precision == "f32":
                 np.testing.assert_allclose(losses, l64, rtol=1e-4, err_msg="phase %d step %d" % (phase, it))
             else:
-                for a, e, q in zip(losses, l64, lq):              # (after updates: two fp16 realisations of a step differ by up to 2-3 % in the small conf loss)
-                    assert abs(a - e) <= 3.0 * abs(q - e) + 1e-2 * abs(e) + 1e-2, (phase, it, losses, l64, lq)
+                for a, e, q in zip(losses, l64, lq):              # (after updates two fp16 realisations of a step differ by 2-3 %: soak, 1.8 % in the bbox loss on one run in ten)
+                    assert abs(a - e) <= 3.0 * abs(q - e) + 4e-2 * abs(e) + 2e-2, (phase, it, losses, l64, lq)
             gmax = max(float(np.abs(v).max()) for v in g64.values())
             live = [n for n, v in g64.items() if float(np.abs(v).max()) >= 1e-9 * gmax]
             ey = {n: rel(gy[n], g64[n]) for n in live}
