@@ -594,7 +594,8 @@ void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H,
 
 // =================================================================================================
 // Column reductions over an [M][Cp] h16 matrix.  Block = OL octet-lanes x (256/OL) row-lanes; a thread owns 8 channels and
-// walks down the rows with four independent 16-byte loads in flight, accumulating in double; row-lanes are combined through
+// walks down the rows with four independent 16-byte loads in flight (fp32 batch partials, two channels per instruction, entering double
+// accumulators once per batch); row-lanes are combined through
 // LDS and ONE double atomic per channel per block goes into the block's accumulator slot (HACC_SLOTS copies).
 //   MODE 0  stats:     acc[0][c] += sum y,   acc[1][c] += sum y*y
 //   MODE 2  BN bwd:    acc[0][c] += sum dyh, acc[1][c] += sum dyh * xhat      (dyh = dz * act'(BN(y)), xhat = (y - mean) * invstd)
@@ -832,7 +833,7 @@ void launch_hcol_reduce(const HRedArgs& a0, int mode, hipStream_t s)
 }
 
 // one row-octet of the BatchNorm forward output: dense (out has y's map, pads zero) or shuffle (out = the gapped unit output:
-// out[2c] = pass[c], out[2c+1] = z[c], pads zeroed) — shared by hbn_apply_kernel and hbn_fused_kernel<0>
+// out[2c] = pass[c], out[2c+1] = z[c], pads zeroed) — hbn_apply_kernel's store
 __device__ __forceinline__ void bn_apply_emit(h16* __restrict__ out, int out_ld, int out_off, bool shuffle, int out_half, int out_gap, int C, float negslope, long m, int p0, int ol,
                                               const f32x2 (&mu)[4], const f32x2 (&is)[4], const f32x2 (&ga)[4], const f32x2 (&be)[4],       // pad channels: gamma = beta = 0
                                               const h16x8& v, const h16x8& pv)
