@@ -77,6 +77,9 @@ int  yn_exact_f32(yn_handle* h, int enable);
  *     65504; *activation_overflow returns that flag for everything issued since the last call and clears it.  The call synchronises
  *     the handle's stream.  A set flag means the results of those calls are NOT valid: re-run them after yn_exact_f32(h, 1)
  *     (the host shim yolo_nano_amd.YOLONano does this by itself, once, and stays on the f32-MFMA family).
+ *     yn_infer also delivers the flag WITH its results, at no extra synchronisation: while it is set every count_dev[b] comes back
+ *     NEGATIVE (-1 - K_b), and yn_pack_detections carries the mark on as offsets_dev[B] = -1 - total.  The flag is sticky until
+ *     yn_range_status clears it.
  * Tiny values need no guard: below the f16 normal range lo = (x - hi) * 2^11 still carries x. */
 int  yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow);
 /* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's
@@ -267,7 +270,9 @@ int  yn_read_param(yn_handle* h, const char* state_dict_key, float* host, int64_
 /* The fp16 step's dynamic loss scale (initial 1024; halved on an overflowing step, doubled after 2000 clean ones; all on the device).
  * The decision is taken by yn_sgd_step from the finite-scan of the bucket it applies - after the data-parallel all-reduce that bucket is
  * the same on every rank, so the replicas' scales move together.  get / set (both synchronise) let a checkpoint carry the scale and its
- * clean-step counter across a resume; set before the first fp16 step replaces the default start value. */
+ * clean-step counter across a resume; set before the first fp16 step replaces the default start value.  set also discards the overflow
+ * flag / pending mark of a step that has not been settled yet (the restored state starts clean).  Accepted range [1, 2^30]; the device
+ * only ever DOUBLES up to 65536, so a larger restored value can only shrink. */
 int  yn_train_get_loss_scale(yn_handle* h, float* scale, float* clean_steps);
 int  yn_train_set_loss_scale(yn_handle* h, float scale, float clean_steps);
 /* The gradient exchange of the data-parallel step (train.py:13-14 imports DistributedDataParallel; BASELINE configs[2]: "DDP grad

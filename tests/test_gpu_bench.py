@@ -35,6 +35,30 @@ def test_two_rank_inference_bench():
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
 
 
+def test_four_rank_default_run_walks_every_barrier():
+    """The DEFAULT run (extras on: single stream, 608 / 0.5x / exact-f32 / threshold / init_bias workloads, both training steps, latency block on
+    rank 0) with FOUR ranks on the one GPU over gloo, at toy sizes (--extras-small): every barrier / all_gather / max-over-ranks of
+    `extras` and `train_bench` is walked by more than two ranks, one autotune pass for the job, ONE JSON line, summary block at its end."""
+    env = dict(os.environ, YN_BENCH_ONE_GPU="1", YN_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2", "--batch", "4", "--size", "224",
+           "--extras-small", "--latency-calls", "20", "--streams", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["rccl_ranks"] == 4 and d["config"]["global_batch"] == 16 and d["cpu_baseline"] is None
+    assert len(d["config"]["per_rank_images_per_s"]) == 4
+    ex = d["extras"]
+    for k in ("infer_608_bs32", "infer_0.5x_416_bs128", "train_608_bs32_f16", "train_608_bs32_f32"):
+        assert k in ex and "error" not in ex[k], (k, ex.get(k))
+    assert any(k.startswith("infer_conf0.1_nms0.45") for k in ex) and any(k.startswith("infer_initbias_conf0.1") for k in ex)
+    assert len(ex["train_608_bs32_f16"]["per_rank_images_per_s"]) == 4 and ex["train_608_bs32_f16"]["allreduce_us_per_step"] > 0
+    assert list(d)[-1] == "summary" and d["summary"]["n_gpus"] == 4 and d["summary"]["allreduce_us_per_step"] > 0
+    assert len(d["summary"]["per_rank_images_per_s_spread"]) == 2
+
+
 def test_plain_python_gpus_2_launches_two_ranks():
     """The form the driver may use: `python bench.py --gpus 2` with no launcher.  bench.py must start the two ranks itself (a child
     torch.distributed.run, never an exec of a GPU-initialised process) and relay ONE JSON line with n_gpus == 2."""

@@ -69,6 +69,38 @@ def test_model_ema_shim_follows_the_training_loop():
     assert boxes.shape[1] == 4 and len(scores) == len(boxes)
 
 
+def test_model_ema_copy_is_re_evaluated_after_every_update():
+    """yn_ema_update writes the EMA tensors through data_ptr(): torch's version counters do not move.  The copy's cached handle must
+    nevertheless pick the new weights up: eval -> train step + update (a decay that moves the copy visibly) -> eval again has to equal a
+    FRESH model loaded from ema.ema.state_dict(), and differ from the first eval."""
+    import yolo_nano_amd
+    S, C, B = 128, 20, 2
+    model = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=True, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in weights.make_state_dict("1.0x", C).items()}, strict=False)
+    model = model.to("cuda").train()
+    opt = yolo_nano_amd.SGD(model, lr=5e-2)
+    x = torch.as_tensor(weights.make_input(B, S, seed=2)).cuda()
+    labels = [[[0.2, 0.2, 0.6, 0.7, 3.0]], [[0.1, 0.3, 0.5, 0.9, 7.0], [0.5, 0.5, 0.8, 0.8, 1.0]]]
+    t = yolo_nano_amd.multi_gt_creator(S, [8, 16, 32], labels, arch.MULTI_ANCHOR_SIZE)
+    sum(model(x, target=t)).backward(); opt.step(); opt.zero_grad()
+    ema = yolo_nano_amd.ModelEMA(model, decay=0.5)
+    ema.decay = lambda n: 0.5                                   # (the reference's ramp starts at ~0: make the update visible)
+    ema.ema.trainable = False
+    first = [t_.clone() for t_ in ema.ema.forward_raw(x)]
+    for _ in range(2):
+        sum(model(x, target=t)).backward(); opt.step(); opt.zero_grad()
+        ema.update(model)
+        got = [t_.clone() for t_ in ema.ema.forward_raw(x)]
+        fresh = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=False, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
+        fresh.load_state_dict({k: v.detach().clone() for k, v in ema.ema.state_dict().items()})
+        fresh = fresh.to("cuda").eval()
+        want = fresh.forward_raw(x)
+        for a, b, c in zip(got, want, first):
+            assert torch.equal(a, b)
+            assert not torch.equal(a, c)
+        first = got
+
+
 def test_tta_merge_bit_exact_vs_reference_fixture(golden):
     from yolo_nano_amd import capi
     g = golden("tta.npz")

@@ -1036,7 +1036,7 @@ def test_grouped_launches_are_bit_identical(hcoco, hvoc, which, S, B):
         h.set_grid(old)
 
 
-@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 3), ("1.0x", 20, 320, 2), ("0.5x", 20, 224, 1), ("1.0x", 20, 288, 1)])
+@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 3), ("1.0x", 20, 320, 2), ("0.5x", 20, 224, 1), ("1.0x", 20, 288, 1), ("1.0x", 20, 416, 13), ("1.5x", 20, 224, 2)])
 def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
     """yn_down_fuse: pw1 -> depthwise stride 2 -> pw2 -> concat+shuffle of stage 2's first unit as ONE kernel (down_unit_kernel) gives
     exactly the backbone taps and raw heads of the three launches - maps whose size is not a multiple of the 8 x 4 output tile included
@@ -1055,7 +1055,13 @@ def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
     kernels = [r[1] for r in h.profile_records()]
     h.profile_enable(False)
     taps1 = h.forward_taps(x)
-    assert any(k.startswith("down_unit_kernel") for k in kernels), kernels
+    wide = backbone == "1.5x"            # bf = 88 / 176 / 352: stage 2 is too wide for down_unit_kernel (down2 takes it), stage 4 for down2_kernel (five launches)
+    assert wide or any(k.startswith("down_unit_kernel") for k in kernels), kernels
+    # round 4: the stride-2 units of stages 3 and 4 as pw1 + ONE kernel (down2_kernel: both depthwise convs, both pointwise convs behind
+    # them, concat + shuffle) instead of five launches - odd output maps (13 x 13, 9 x 9, 7 x 7), ragged last 32-pixel tiles, K chunks of 32
+    # (many tiles) and 64 (few) are all in the parameter list above
+    assert sum(k.startswith("down2_kernel") for k in kernels) == 2, kernels
+    assert wide or not any(k.startswith("dwconv3x3_kernel<2") for k in kernels), kernels   # no stride-2 depthwise launch is left
     for a, b in zip(taps0, taps1):
         assert torch.equal(a, b)
     for a, b in zip(raw0, raw1):
@@ -1157,6 +1163,18 @@ def test_range_guard_whole_network_and_shim(capi):
     hb.load_state_dict(sdb); hb.fold_bn()
     hb.forward_raw(dev(x_np))
     assert hb.range_status() == (False, True)
+    # yn_infer delivers the same flag with its counts (negative: -1 - kept), yn_pack_detections carries it on in offsets[B]; sticky until
+    # yn_range_status clears it; under yn_exact_f32 the counts are plain again
+    outb = hb.infer(dev(x_np))
+    assert int(outb[4][0]) < 0
+    _, offb = hb.pack_detections(outb)
+    assert int(offb[1]) == int(outb[4][0]) and int(offb[0]) == 0
+    with pytest.raises(capi.YnRangeError):
+        hb.detections_to_host(outb)
+    assert hb.range_status() == (False, True) and hb.range_status() == (False, False)
+    hb.exact_f32(True)
+    outb = hb.infer(dev(x_np))
+    assert int(outb[4][0]) >= 0 and hb.range_status() == (False, False)
     hb.close()
     refb = orc.Net(sdb, "1.0x", C, fold=True).forward_raw(x_np)
     m = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, anchor_size=arch.MULTI_ANCHOR_SIZE)
@@ -1172,6 +1190,18 @@ def test_range_guard_whole_network_and_shim(capi):
         warnings.simplefilter("always")
         m(dev(x_np))
     assert not any("split-f16 range" in str(w_.message) for w_ in rec2)
+    # the same through forward() alone (no forward_raw first): the mark arrives with the counts, the shim re-runs once and stays exact
+    m2 = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, anchor_size=arch.MULTI_ANCHOR_SIZE)
+    m2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sdb.items()})
+    m2 = m2.to("cuda").eval()
+    with warnings.catch_warnings(record=True) as rec3:
+        warnings.simplefilter("always")
+        r2 = m2(dev(x_np))
+        rb = m2.forward_batch(dev(x_np))
+    assert m2._exact_f32 and sum("split-f16 range" in str(w_.message) for w_ in rec3) == 1
+    r1 = m(dev(x_np))
+    for u, v, w_ in zip(r1, r2, rb[0]):
+        np.testing.assert_array_equal(u, v); np.testing.assert_array_equal(u, w_)
 
 
 @pytest.mark.parametrize("B,S", [(5, 416), (1, 320)])

@@ -447,6 +447,14 @@ def test_h16_loss_scale_is_decided_by_the_reduced_bucket_and_can_be_restored(gol
     assert h1.loss_scale()[0] == 2.0 ** 26
     h1.train_step(x, t, update=False)                           # settles the previous step first: halved
     assert h1.loss_scale()[0] == 2.0 ** 25
+    # restoring a scale discards an unsettled step's overflow flag / pending mark: the restored values are what the next step sees
+    h1.set_loss_scale(2.0 ** 26, 0.0)
+    h1.train_step(x, t, update=False)                           # overflows, stays pending
+    h1.set_loss_scale(512.0, 3.0)
+    h1.train_step(x, t, update=False)                           # nothing to settle: not halved, counter untouched
+    assert h1.loss_scale() == (512.0, 3.0)
     with pytest.raises(Exception):
         h1.set_loss_scale(0.5)
+    with pytest.raises(Exception):
+        h1.set_loss_scale(2.0 ** 31)
     h0.close(); h1.close()

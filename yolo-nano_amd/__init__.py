@@ -11,7 +11,7 @@ def __getattr__(name):
     if name in ("YOLONano", "fuse_conv_bn", "Conv", "ShuffleNetV2", "ShuffleV2Block", "shufflenetv2", "SGD", "multi_gt_creator", "ModelEMA", "TestTimeAugmentation", "ValTransforms", "rescale_boxes"):
         from . import model
         return getattr(model, name)
-    if name in ("Handle", "YnError", "load_library"):
+    if name in ("Handle", "YnError", "YnRangeError", "load_library"):
         from . import capi
         return getattr(capi, name)
     raise AttributeError(name)

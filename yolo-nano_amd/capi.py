@@ -115,6 +115,11 @@ class YnError(RuntimeError):
     pass
 
 
+class YnRangeError(YnError):
+    """yn_infer reported (negative counts / offsets[B]) that an activation left the split-f16 range: the detections of that call are not
+    valid.  Call range_status() (clears the flag), switch the handle to exact_f32(True) and run again - YOLONano does this by itself."""
+
+
 def load_library():
     """dlopen the in-tree HIP library and type every entry point.  Raises if it is not built."""
     global _lib
@@ -437,6 +442,8 @@ class Handle:
         scores [K] f32, cls_inds [K] i64) numpy triples, fresh and writable."""
         rec, offsets = self.pack_detections(out)
         off = offsets.cpu().numpy()
+        if int(off[-1]) < 0:                                    # compact_kernel's range mark, carried through pack_kernel
+            raise YnRangeError("yn_infer: an activation exceeded the split-f16 range (|x| >= 65504); results invalid, re-run under exact_f32")
         host = rec[: int(off[-1])].cpu().numpy()
         res = []
         for b in range(len(off) - 1):

@@ -1374,6 +1374,243 @@ void launch_down_unit(const DownArgs& a, hipStream_t s)
 }
 
 // -------------------------------------------------------------------------------------------------
+// The stride-2 ShuffleV2 units of stages 3 and 4 (backbone/shufflenetv2.py:42-49, 53-63, 73-74; cin = bf = 116 / 232): too wide for
+// down_unit_kernel's window form (pw1 on the 17 x 9 halo needs the whole K = cin of 153 pixels in LDS).  The unit is cut where the chain
+// kernels cut theirs - at the depthwise convs, after which everything is pixel-local:
+//     launch 1 (gemm_split_kernel):  y1 = relu(pw1(x))                                          [B][H][W][bf]
+//     launch 2 (down2_kernel):       y3 = relu(pw2(dw_s2(y1))),  z2 = relu(pw(dw_s2(x))),  out = shuffle(cat(z2, y3))
+// Two launches instead of five; the four tensors between them (both depthwise outputs, branch 1's output, 60 MB per step at stage 3)
+// never reach memory.  Workgroup = 32 consecutive output pixels (flat, all images): thread = (4 channels, every ppl-th pixel) with the
+// nine taps of its channels in registers; the 3 x 3 stride-2 windows of TWO pixels are in flight per round (18 clamped, masked 16-byte
+// loads), results split straight into the A planes of their branch; then ONE chunk loop walks the K chunks of pw2 and of branch 1's
+// pointwise conv back to back (the next chunk's weights always in flight), four wavefronts x NT column tiles.  The accumulator layout
+// gives a lane the SAME column n and the same 16 rows in both GEMMs, so the concat + shuffle is the store: out[row][2n .. 2n+1] =
+// (z2, y3) as one 8-byte store.  Every sum in the order of dwconv3x3_kernel / gemm_split_kernel: bit-identical to the five launches
+// (test_down_unit_is_bit_identical).  LDS 48 KB at bf = 116 (three workgroups per CU: the 676 workgroups of a 32-image step are all resident).
+// -------------------------------------------------------------------------------------------------
+template <int NT, int KC>
+__global__ __launch_bounds__(256, NT == 1 ? (KC == 32 ? 3 : 2) : 1) void down2_kernel(Down2Args a)
+{
+    constexpr int BM = 32, BN = 128 * NT, OQ = KC / 8;
+    constexpr int B_PER = (2 * OQ * BN + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float d2_smem[];
+    const int bf = a.bf, cin = a.cin;
+    const int KQ2 = (bf + 7) >> 3, KQ1 = (cin + 7) >> 3, PS2 = KQ2 * 8 + 8, PS1 = KQ1 * 8 + 8;
+    const int n2 = (bf + KC - 1) / KC, n1 = (cin + KC - 1) / KC, ntot = n2 + n1;
+    uch16* A2h = reinterpret_cast<uch16*>(d2_smem);                     // [BM][PS2]
+    uch16* A2l = A2h + BM * PS2;
+    uch16* A1h = A2l + BM * PS2;                                        // [BM][PS1]
+    uch16* A1l = A1h + BM * PS1;
+    uch16* Bh = A1l + BM * PS1;                                         // [OQ][BN][8], then the lo plane
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1, HWo = Ho * Wo, Mo = a.B * HWo;
+    const int m0 = (int)xcd_block(blockIdx.x, gridDim.x) * BM;
+    if (m0 >= Mo) return;
+    const int nrows = Mo - m0 < BM ? Mo - m0 : BM;
+
+    uch16x8 b_reg[B_PER];
+    auto prefetch_b = [&](int g) {                                      // chunk g of the concatenated walk: pw2's chunks, then branch 1's
+        const bool second = g >= n2;
+        const int c = second ? g - n2 : g, KQ = second ? KQ1 : KQ2;
+        const uch16* Wh = reinterpret_cast<const uch16*>(second ? a.W3h : a.W2h);
+        const uch16* Wl = reinterpret_cast<const uch16*>(second ? a.W3l : a.W2l);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int q = t + 256 * i;
+            const int pl = q / (OQ * BN), r = q - pl * (OQ * BN);
+            const int o = r / BN, n = r - o * BN;
+            const int kq = c * OQ + o;
+            const bool ok = q < 2 * OQ * BN && kq < KQ && n < a.Npad;
+            uch16x8 v = *reinterpret_cast<const uch16x8*>((pl ? Wl : Wh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
+            }
+            b_reg[i] = v;
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int q = t + 256 * i;
+            if (q < 2 * OQ * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)q * 8) = b_reg[i];
+        }
+    };
+    prefetch_b(0);                                                      // in flight during the depthwise phase
+    float bias2[NT], bias3[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wave * NT + nt) * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias3[nt] = n < bf ? a.b3[n] : 0.0f;
+    }
+
+    // ---- 1. both depthwise convs (stride 2, dwconv3x3_kernel's fma chain) -> the split planes of their branch ---------------------------
+    float amax = 0.0f;                                                   // range guard (yn_device.h)
+    auto dw_branch = [&](const float* __restrict__ src, int C, const float* __restrict__ wd, const float* __restrict__ bd, int act, uch16* Ph, uch16* Pl, int PS) {
+        const int cqn = C >> 2, ppl = 256 / cqn;
+        const int cq = t % cqn, pl = t / cqn, c = cq * 4;
+        if (pl < ppl) {
+            float4 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(wd + k * C + c);
+            const float4 bias = *reinterpret_cast<const float4*>(bd + c);
+            for (int r0 = pl; r0 < nrows; r0 += 2 * ppl) {
+                float4 win[2][9];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = r0 + u * ppl;
+                    const int m = m0 + (r < nrows ? r : r0);
+                    const int b = m / HWo, rem = m - b * HWo;
+                    const int oy = rem / Wo, ox = rem - oy * Wo;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int iy = 2 * oy - 1 + ky;
+                        const bool yok = iy >= 0 && iy < a.H;
+                        const float* rowp = src + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * C + c;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int ix = 2 * ox - 1 + kx;
+                            const bool ok = yok && ix >= 0 && ix < a.W;
+                            win[u][ky * 3 + kx] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int r = r0 + u * ppl;
+                    if (r < nrows) {
+                        float4 acc = bias;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) vfma(acc, win[u][k], w[k]);
+                        acc = vact(acc, act);
+                        const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
+                        uch16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
+                        *reinterpret_cast<uch16x4*>(Ph + r * PS + c) = hi;
+                        *reinterpret_cast<uch16x4*>(Pl + r * PS + c) = lo;
+                    }
+                }
+            }
+        }
+        // K tail [C, PS) of every row and the idle rows [nrows, BM): zeros (they meet zero weight rows / are never stored, but must not be NaN bit patterns)
+        const int padn = PS - C;
+        for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = C + i - r * padn; Ph[r * PS + c2] = (uch16)0.0f; Pl[r * PS + c2] = (uch16)0.0f; }
+        for (int i = t; i < (BM - nrows) * (C >> 2); i += 256) {
+            const int r = nrows + i / (C >> 2), c2 = (i % (C >> 2)) * 4;
+            uch16x4 z; z[0] = z[1] = z[2] = z[3] = (uch16)0.0f;
+            *reinterpret_cast<uch16x4*>(Ph + r * PS + c2) = z; *reinterpret_cast<uch16x4*>(Pl + r * PS + c2) = z;
+        }
+    };
+    dw_branch(a.y1, bf, a.wdw, a.bdw, a.dw_act, A2h, A2l, PS2);
+    dw_branch(a.x, cin, a.wdw1, a.bdw1, a.dw1_act, A1h, A1l, PS1);
+    stage_b();
+    if (ntot > 1) prefetch_b(1);
+    __syncthreads();
+    range_report(a.ovf, amax);                                          // every split of this workgroup is done
+
+    // ---- 2. the two pointwise convs as ONE walk over their K chunks (gemm_split_tile's order inside each) ------------------------------
+    f32x16 acc0[NT], acc1[NT];
+    float y3[NT][16];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+    for (int g = 0; g < ntot; ++g) {
+        const bool second = g >= n2;
+        if (g == n2) {                                                  // pw2 is complete: its tile waits in registers for its partner
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y3[nt][r] = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias2[nt], a.act2);
+                    acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f;
+                }
+        }
+        const int c = second ? g - n2 : g, KQ = second ? KQ1 : KQ2, PS = second ? PS1 : PS2;
+        const uch16* Ahb = (second ? A1h : A2h) + l31 * PS + c * KC + h * 8;
+        const uch16* Alb = (second ? A1l : A2l) + l31 * PS + c * KC + h * 8;
+        const uch16* Bhb = Bh + (size_t)(h * BN + wave * NT * 32 + l31) * 8;
+        const uch16* Blb = Bhb + OQ * BN * 8;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            if (c * OQ + ks * 2 >= KQ) break;                           // wave-uniform: beyond the (zero-padded) K
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+            }
+        }
+        if (g + 1 < ntot) {
+            __syncthreads();                                            // every wave is done with this chunk's weights
+            stage_b();
+            __syncthreads();
+            if (g + 2 < ntot) prefetch_b(g + 2);
+        }
+    }
+
+    // ---- 3. concat + shuffle store: out[row][2n] = branch 1, out[row][2n + 1] = branch 2 -------------------------------------------------
+    char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * (2 * bf));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wave * NT + nt) * 32 + l31;
+        if (n < bf) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < nrows) {
+                    const float z = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias3[nt], a.act3);
+                    *reinterpret_cast<float2*>(out_base + (unsigned)(row * 2 * bf + 2 * n) * 4u) = make_float2(z, y3[nt][r]);
+                }
+            }
+        }
+    }
+}
+
+static size_t down2_lds(int bf, int cin, int NT, int KC)
+{
+    const int PS2 = ((bf + 7) / 8) * 8 + 8, PS1 = ((cin + 7) / 8) * 8 + 8;
+    return ((size_t)2 * 32 * PS2 + (size_t)2 * 32 * PS1 + (size_t)2 * (KC / 8) * 128 * NT * 8) * 2;
+}
+
+bool down2_covers(const Down2Args& a)
+{
+    return a.x && a.y1 && a.W2h && a.W2l && a.W3h && a.W3l && a.wdw && a.wdw1 && a.bdw && a.bdw1 && a.b2 && a.b3 && a.B > 0 && a.H > 1 && a.W > 1 &&
+           a.bf >= 4 && a.cin >= 4 && !(a.bf & 3) && !(a.cin & 3) && a.bf <= 256 && a.cin <= 256 && a.Npad >= a.bf && a.Npad <= 256 &&
+           (long)a.B * a.H * a.W * (a.bf > a.cin ? a.bf : a.cin) < (1l << 30);
+}
+
+void launch_down2(const Down2Args& a, hipStream_t s)
+{
+    const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+    const unsigned tiles = (unsigned)(((long)a.B * Ho * Wo + 31) / 32);
+    static const int kc_env = getenv("YN_DOWN2_KC") ? atoi(getenv("YN_DOWN2_KC")) : 0;       // A/B: 32 / 64 (bit-identical)
+    static unsigned long long attr = 0;
+    if (attr_pending(attr)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<1, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (a.Npad <= 128) {
+        // K chunks of 32 keep the workgroup at 48 KB (three per CU: every workgroup of a 32-image step resident at once); fewer than one
+        // workgroup per CU (one image): chunks of 64, half the barrier rounds
+        const int KC = kc_env ? kc_env : (tiles > 256 ? 32 : 64);
+        if (KC == 64) { set_last_kernel_name("down2_kernel<1,64>"); hipLaunchKernelGGL((down2_kernel<1, 64>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 1, 64), s, a); }
+        else          { set_last_kernel_name("down2_kernel<1,32>"); hipLaunchKernelGGL((down2_kernel<1, 32>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 1, 32), s, a); }
+    } else {                                                // stage 4 (bf = 232): one workgroup per CU at most, K = 232 in four rounds per pointwise conv
+        set_last_kernel_name("down2_kernel<2,64>");
+        hipLaunchKernelGGL((down2_kernel<2, 64>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 2, 64), s, a);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Depthwise 3x3 + pointwise conv of a detection head (models/yolo_nano.py:60-82: Conv(96, 96, k=3, g=96) -> Conv(96, 96, k=1)) as one
 // kernel, for up to three pyramid levels per launch (Group<>).  The depthwise output of the stride-8 head is 33 MB per 32-image step,
 // written by one launch and read back by the next; here it goes from registers into the GEMM's LDS operand planes.  Workgroup = an 8 x 4

@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ cls, const int32_t* __restrict__ keep, int N,
                                                         float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                         int32_t* __restrict__ out_cls, int32_t* __restrict__ out_index,
-                                                        int32_t* __restrict__ count)
+                                                        int32_t* __restrict__ count, const unsigned* __restrict__ ovf)
 {
     // 32 chunks of 1024 candidates per pass: every keep flag of the pass is requested in one batch, the per-chunk wavefront counts go to
     // LDS, ONE barrier, then every thread derives the positions of its (up to 32) kept candidates.  (First version: load, ballot,
@@ -1675,7 +1675,9 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
         if (threadIdx.x == 0) base = total_next;
         __syncthreads();
     }
-    if (threadIdx.x == 0) count[b] = base;
+    // range guard of the split-f16 family, delivered with the result every caller reads anyway: a NEGATIVE count (-1 - kept) says an
+    // activation left the split's range somewhere in the network that produced these candidates (yn_range_status; re-run under yn_exact_f32)
+    if (threadIdx.x == 0) count[b] = (ovf && *ovf) ? -1 - base : base;
 }
 
 int nms_max_segment() { return 64 * YN_RESOLVE_MAX_T; }
@@ -1690,12 +1692,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ box
     const int b = blockIdx.x;
     if (threadIdx.x < 64) {
         int mine = 0, all = 0;
-        for (int i = threadIdx.x; i < B; i += 64) { const int c = count[i]; all += c; if (i < b) mine += c; }
-        for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o); all += __shfl_xor(all, o); }
-        if (threadIdx.x == 0) { base_s = mine; total_s = all; }
+        int bad = 0;
+        for (int i = threadIdx.x; i < B; i += 64) { int c = count[i]; if (c < 0) { bad = 1; c = -1 - c; } all += c; if (i < b) mine += c; }
+        for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o); all += __shfl_xor(all, o); bad |= __shfl_xor(bad, o); }
+        if (threadIdx.x == 0) { base_s = mine; total_s = bad ? -1 - all : all; }      // a flagged batch (compact_kernel) keeps its mark: offsets[B] < 0
     }
     __syncthreads();
-    const int base = base_s, k = count[b];
+    const int base = base_s, k = count[b] < 0 ? -1 - count[b] : count[b];
     if (threadIdx.x == 0) { offsets[b] = base; if (b == 0) offsets[B] = total_s; }
     for (int i = threadIdx.x; i < k; i += 256) {
         const size_t src = (size_t)b * N + i;
@@ -1805,7 +1808,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                                       wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
     mark("compact_kernel");
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count);
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count, wk.ovf);
 }
 
 // scratch: ids[n] int32, sbox[n] float4, M[nms_matrix_words_per_image(n,1)] u64 — all provided by the handle

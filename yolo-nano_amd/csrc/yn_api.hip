@@ -838,6 +838,18 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             const bool use_down = h->down_fuse && !exact(h) && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf && ldw.stride == 2 &&
                                   l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && down_unit_covers(d);
             static const int down_b1 = getenv("YN_DOWN_B1") ? atoi(getenv("YN_DOWN_B1")) : 1;      // 0: branch 1 as its own two kernels (A/B runs)
+            static const int down2_env = getenv("YN_DOWN2") ? atoi(getenv("YN_DOWN2")) : 1;        // 0: the wide units (stages 3 / 4) as five launches (A/B runs)
+            Down2Args d2{};
+            d2.x = cur; d2.cin = curC; d2.y1 = t1;
+            d2.wdw = ldw.w_packed; d2.bdw = ldw.b_packed; d2.dw_act = ldw.act;
+            d2.W2h = lp2.ws_hi; d2.W2l = lp2.ws_lo; d2.b2 = lp2.b_packed; d2.act2 = lp2.act;
+            d2.wdw1 = l1d.w_packed; d2.bdw1 = l1d.b_packed; d2.dw1_act = l1d.act;
+            d2.W3h = l1p.ws_hi; d2.W3l = l1p.ws_lo; d2.b3 = l1p.b_packed; d2.act3 = l1p.act;
+            d2.out = oA; d2.B = B; d2.H = curH; d2.W = curH; d2.bf = bf; d2.Npad = lp2.Npad;
+            d2.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
+            const bool use_down2 = !use_down && h->down_fuse && down2_env && !exact(h) && lp1.ws_hi && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf &&
+                                   ldw.stride == 2 && ldw.cout == bf && l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && l1p.Npad == lp2.Npad &&
+                                   down2_covers(d2);
             if (use_down && !down_b1) {
                 run_dw(h, l1d, cur, curC, 0, B, curH, curH, tdw1, curC, 0);
                 run_pw(h, l1p, tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
@@ -849,6 +861,15 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                     Bracket br(h, P0 + ".unit", 2.0 * (Mi * curC * bf + Mo * bf * (9.0 + bf) + Mo * curC * (9.0 + bf)),
                                4.0 * (Mi * (double)curC + 2.0 * Mo * bf + 2.0 * (double)curC * bf + (double)bf * bf));
                     launch_down_unit(d, h->cur);
+                }
+            } else if (use_down2) {
+                // stages 3 / 4 (cin = bf = 116 / 232): pw1 as a GEMM launch, everything behind it - both depthwise convs, both pointwise convs,
+                // concat + shuffle - as one kernel (down2_kernel): two launches instead of five
+                run_pw(h, lp1, cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
+                if (!dbg_skip(h, P0 + ".tail")) {
+                    Bracket br(h, P0 + ".dw+pw2|b1", 2.0 * (Mo * bf * (9.0 + bf) + Mo * curC * (9.0 + bf)),
+                               4.0 * (Mi * (double)(curC + bf) + 2.0 * Mo * bf + (double)curC * bf + (double)bf * bf));
+                    launch_down2(d2, h->cur);
                 }
             } else {
         fork_to(h, 0);                                      // branch1 and branch2 only meet in the fused cat+shuffle
@@ -1665,7 +1686,9 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
                 set_last_kernel_name(k);
                 x->cur = new Bracket(x->h, std::string("nms.") + k, 0.0, x->bytes);
             }, &ctx};
-            launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, g.N, g.C, h->cfg.nms_thresh, h->cfg.diou_nms, h->nms,
+            NmsWork wk = h->nms;
+            wk.ovf = exact(h) ? nullptr : h->range_flags + 1;         // the network's range flag rides out with the counts (compact_kernel)
+            launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, g.N, g.C, h->cfg.nms_thresh, h->cfg.diou_nms, wk,
                                 out_boxes, out_scores, out_cls, out_index, count, h->stream, h->profiling ? &hook : nullptr);
             delete ctx.cur;
         }
@@ -1691,6 +1714,7 @@ static int ensure_loss(yn_handle* h, int B)
     const size_t need = (size_t)loss_num_blocks(h->grid, B) * 4;
     if (need <= h->loss_partial_cap) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_train_graphs(h);                                   // a captured fp16 step carries loss_partial's address (launch_loss_h16)
     if (h->loss_partial) HIPCHK(h, hipFree(h->loss_partial));
     HIPCHK(h, hipMalloc((void**)&h->loss_partial, need * sizeof(float)));
     h->loss_partial_cap = need;
@@ -1782,10 +1806,13 @@ int yn_train_get_loss_scale(yn_handle* h, float* scale, float* clean_steps)
 int yn_train_set_loss_scale(yn_handle* h, float scale, float clean_steps)
 {
     YN_ENTER(h);
+    // hscale_update_kernel halves down to 1 and doubles up to 65536; a larger restored value (up to 2^30: the overflow tests start there)
+    // is accepted and can only shrink from then on
     if (!(scale >= 1.0f) || !(scale <= 1073741824.0f) || !(clean_steps >= 0.0f)) return fail(h, "yn_train_set_loss_scale: scale must lie in [1, 2^30], clean_steps >= 0");
     h->loss_scale_init = scale; h->loss_scale_clean = clean_steps;
     if (h->scale_state) {
-        const float v[3] = {scale, 1.0f / scale, clean_steps};
+        // all five words: a restored scale must not inherit the overflow flag / pending mark of an unsettled do_update = 0 step
+        const float v[5] = {scale, 1.0f / scale, clean_steps, 0.0f, 0.0f};
         HIPCHK(h, hipMemcpyAsync(h->scale_state, v, sizeof v, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }

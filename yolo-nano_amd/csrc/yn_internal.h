@@ -61,6 +61,21 @@ struct DownArgs {
     int B, H, W, bf;
     unsigned* ovf;                              // split-f16 range guard flag or null
 };
+// A stride-2 ShuffleV2 unit AFTER its first pointwise conv (kernels_chain.hip, down2_kernel): both depthwise convs (stride 2), both
+// pointwise convs behind them and the concat + shuffle as one kernel; y1 = act(pw1(x)) comes from a gemm_split_kernel launch.
+struct Down2Args {
+    const float* x; int cin;                    // unit input [B][H][W][cin] (dense)
+    const float* y1;                            // act(pw1(x)) [B][H][W][bf] (dense)
+    const float* wdw; const float* bdw; int dw_act;                // branch 2 depthwise [9][bf], [bf]
+    const void *W2h, *W2l; const float* b2; int act2;              // pw2: split packs [ceil(bf/8)][Npad][8], bias
+    const float* wdw1; const float* bdw1; int dw1_act;             // branch 1 depthwise (on x): [9][cin], [cin]
+    const void *W3h, *W3l; const float* b3; int act3;              // branch 1 pointwise cin -> bf: split packs [ceil(cin/8)][Npad][8]
+    float* out;                                 // [B][Ho][Wo][2*bf]: out[2n] = branch 1, out[2n+1] = branch 2
+    int B, H, W, bf, Npad;
+    unsigned* ovf;                              // split-f16 range guard flag or null
+};
+bool down2_covers(const Down2Args& a);
+void launch_down2(const Down2Args& a, hipStream_t s);
 // depthwise 3x3 (stride 1) + pointwise conv of a detection head as one kernel (kernels_chain.hip, dwpw_group_kernel): C = Cout = 96
 struct DwPwArgs {
     const float* in;                            // [B][H][W][C] dense
@@ -142,6 +157,8 @@ struct NmsWork {                                // per-handle scratch, sized for
     int32_t* ctr;                               // [B][2]  bucket_sort_kernel's position cursor / finished-workgroup count (zero between launches)
     int      prefilter;                         // 0 off, 1 for batches of >= 4 images, 2 always
     int      large_cap;
+    const unsigned* ovf;                        // yn_infer: the split-f16 range flag of the network kernels that produced the candidates, or null.
+                                                // Set => compact_kernel reports count[b] = -1 - kept (the results are invalid: yn_range_status)
 };
 size_t nms_matrix_words_per_image(int N, int C);
 int nms_max_segment();                      // largest per-class segment resolve_segment() can hold (its removed-mask lives in LDS)

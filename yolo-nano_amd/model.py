@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import arch
-from .capi import Handle, YnError
+from .capi import Handle, YnError, YnRangeError
 
 
 # ---- parameter containers with the reference's module tree (keys must match exactly) -----------
@@ -305,6 +305,8 @@ class YOLONano(nn.Module):
     def _to_host(out, b, k=None):
         boxes, scores, cls, _, count = out
         k = int(count[b].item()) if k is None else k
+        if k < 0:                                              # yn_infer's range mark (compact_kernel): the batch is invalid
+            raise YnRangeError("yn_infer: an activation exceeded the split-f16 range (|x| >= 65504)")
         # fresh, writable, caller-owned arrays: callers rescale them in place (benchmark.py:69-71)
         return (boxes[b, :k].cpu().numpy().copy(), scores[b, :k].cpu().numpy().copy(),
                 cls[b, :k].cpu().numpy().astype(np.int64))
@@ -313,7 +315,8 @@ class YOLONano(nn.Module):
     def _range_guarded(self, h, run):
         """Run `run(h)` on the default (split-f16) family and check the handle's range guard (yn_range_status): if an activation
         reached 65504 — outside x = hi + lo * 2^-11, where the reference's fp32 is still finite — switch the handle to the f32-MFMA
-        family for good and run again.  Costs one 4-byte read-back per call (the callers synchronise for their results anyway)."""
+        family for good and run again.  Only forward_raw (device tensors out, nothing read back) goes through this form and pays its
+        synchronising 4-byte read-back; forward / forward_batch learn the same from yn_infer's counts (_infer_guarded)."""
         out = run(h)
         if not self._exact_f32:
             _, overflow = h.range_status()
@@ -326,6 +329,23 @@ class YOLONano(nn.Module):
                 out = run(h)
         return out
 
+    def _infer_guarded(self, h, xf, finish):
+        """yn_infer + `finish(out)` (the read-back the caller makes anyway).  yn_infer itself reports an activation outside the split-f16 range
+        through NEGATIVE counts (compact_kernel), so the guard costs no extra synchronisation here: on that mark the handle is switched to the
+        f32-MFMA family for good and the call runs again."""
+        try:
+            return finish(h.infer(xf))
+        except YnRangeError:
+            if self._exact_f32:
+                raise
+            import warnings
+            warnings.warn("yolo_nano_amd: an activation exceeded the split-f16 range (|x| >= 65504); re-running this and all later "
+                          "forwards of the model on the exact f32-MFMA kernels (yn_exact_f32)")
+            h.range_status()                                   # clears the device flag
+            self._exact_f32 = True
+            h.exact_f32(True)
+            return finish(h.infer(xf))
+
     def forward_raw(self, x):
         """Raw head tensors as the reference's hooks see them: three NCHW views [B, A(5+C), H, W]."""
         h = self.handle(x.shape[0])
@@ -336,7 +356,7 @@ class YOLONano(nn.Module):
         """Eval-mode forward for EVERY image: list of (bboxes, scores, cls_inds) numpy triples."""
         h = self.handle(x.shape[0])
         xf = x.float()
-        return h.detections_to_host(self._range_guarded(h, lambda hh: hh.infer(xf)))      # two device-to-host copies per batch (yn_pack_detections)
+        return self._infer_guarded(h, xf, h.detections_to_host)      # two device-to-host copies per batch (yn_pack_detections)
 
     # ---- training (models/yolo_nano.py:332-358, train.py:219-231) -----------------------------------------
     def _train_handle(self, batch):
@@ -420,8 +440,7 @@ class YOLONano(nn.Module):
             return _TrainStep.apply(self, x, target, *list(self.parameters()))
         h = self.handle(x.shape[0])
         xf = x.float()
-        out = self._range_guarded(h, lambda hh: hh.infer(xf))
-        return self._to_host(out, 0)          # batch element 0 only, as models/yolo_nano.py:365-367
+        return self._infer_guarded(h, xf, lambda out: self._to_host(out, 0))          # batch element 0 only, as models/yolo_nano.py:365-367
 
 
 class ModelEMA(object):
@@ -514,6 +533,9 @@ class ModelEMA(object):
                 else:
                     v *= d
                     v += (1. - d) * src
+        # yn_ema_update writes through data_ptr(): torch's version counters do not move, so the copy's cached handle would keep the
+        # weights it folded before this update (state_dict() right, inference stale) - drop the signature, the next eval re-loads
+        self.ema._sig = None
 
 
 class ValTransforms(object):

@@ -151,6 +151,23 @@ def dp_train_step(handle, x, target, lr, momentum=0.9, weight_decay=5e-4):
         handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0)
         return losses
     losses = handle.train_step(x, target, lr, momentum, weight_decay, update=False)
-    dist.all_reduce(handle.flat_grads, op=dist.ReduceOp.SUM)
+    with _on_handle_stream(handle):
+        dist.all_reduce(handle.flat_grads, op=dist.ReduceOp.SUM)
     handle.sgd_step(handle.flat_params, handle.flat_grads, handle.flat_momentum, lr, momentum, weight_decay, grad_scale=1.0 / world)
     return losses
+
+
+def _on_handle_stream(handle):
+    """Context that makes torch's current stream THE stream the handle launches on: yn_train_step / yn_sgd_step run on the handle's
+    stream, the process group's all-reduce on torch's current one - the exchange is only ordered between them when the two are the
+    same.  (A handle created inside `with torch.cuda.stream(s)` and called there already satisfies this; nothing else used to.)"""
+    import contextlib
+    ts = getattr(handle, "_torch_stream", None)
+    if ts is None or not torch.cuda.is_available():
+        return contextlib.nullcontext()                     # CPU stand-ins of the gloo tests
+    st = ts()
+    cur = torch.cuda.current_stream(handle.device)
+    if cur.cuda_stream == st.cuda_stream:
+        return contextlib.nullcontext()
+    st.wait_stream(cur)                                     # inputs produced on the caller's stream
+    return torch.cuda.stream(st)
