@@ -1388,20 +1388,19 @@ void launch_down_unit(const DownArgs& a, hipStream_t s)
 // (z2, y3) as one 8-byte store.  Every sum in the order of dwconv3x3_kernel / gemm_split_kernel: bit-identical to the five launches
 // (test_down_unit_is_bit_identical).  LDS 48 KB at bf = 116 (three workgroups per CU: the 676 workgroups of a 32-image step are all resident).
 // -------------------------------------------------------------------------------------------------
-template <int NT, int KC>
-__global__ __launch_bounds__(256, NT == 1 ? (KC == 32 ? 3 : 2) : 1) void down2_kernel(Down2Args a)
+template <int NT, int D>                                   // NT column tiles of 32 per wavefront (4 wavefronts); D k-steps of weights in flight
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a)
 {
-    constexpr int BM = 32, BN = 128 * NT, OQ = KC / 8;
-    constexpr int B_PER = (2 * OQ * BN + 255) / 256;
+    constexpr int BM = 32;
     extern __shared__ __attribute__((aligned(16))) float d2_smem[];
     const int bf = a.bf, cin = a.cin;
     const int KQ2 = (bf + 7) >> 3, KQ1 = (cin + 7) >> 3, PS2 = KQ2 * 8 + 8, PS1 = KQ1 * 8 + 8;
-    const int n2 = (bf + KC - 1) / KC, n1 = (cin + KC - 1) / KC, ntot = n2 + n1;
+    const int S2 = (KQ2 + 1) >> 1, S1 = (KQ1 + 1) >> 1, S = S2 + S1;    // 16-deep k-steps of pw2, of branch 1's pointwise conv
+    const bool chain = a.W1nh != nullptr;                               // + the next unit's pw1 (K = bf: S2 steps more, after the store)
     uch16* A2h = reinterpret_cast<uch16*>(d2_smem);                     // [BM][PS2]
     uch16* A2l = A2h + BM * PS2;
     uch16* A1h = A2l + BM * PS2;                                        // [BM][PS1]
     uch16* A1l = A1h + BM * PS1;
-    uch16* Bh = A1l + BM * PS1;                                         // [OQ][BN][8], then the lo plane
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1, HWo = Ho * Wo, Mo = a.B * HWo;
@@ -1409,43 +1408,40 @@ __global__ __launch_bounds__(256, NT == 1 ? (KC == 32 ? 3 : 2) : 1) void down2_k
     if (m0 >= Mo) return;
     const int nrows = Mo - m0 < BM ? Mo - m0 : BM;
 
-    uch16x8 b_reg[B_PER];
-    auto prefetch_b = [&](int g) {                                      // chunk g of the concatenated walk: pw2's chunks, then branch 1's
-        const bool second = g >= n2;
-        const int c = second ? g - n2 : g, KQ = second ? KQ1 : KQ2;
-        const uch16* Wh = reinterpret_cast<const uch16*>(second ? a.W3h : a.W2h);
-        const uch16* Wl = reinterpret_cast<const uch16*>(second ? a.W3l : a.W2l);
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
+    // The weights never pass through LDS: a lane's B fragment of a k-step is 16 contiguous bytes of the pre-split pack
+    // ([octet][column][8 halves]; the 32 lanes of a half-wavefront read 512 contiguous bytes), so every wavefront streams the fragments of
+    // ITS columns straight from L2 into registers, D k-steps ahead, with no barrier between the steps of the two pointwise convs (the first
+    // form staged K chunks through LDS: eight barrier rounds of ~3.7 k cycles, each waiting for a load issued one round earlier behind the
+    // other workgroups' window traffic - 30 k of the workgroup's 60 k cycles).  Step s of the walk: pw2's steps, then branch 1's.
+    uch16x8 bq[D][NT][2];
+    auto load_b = [&](int s, uch16x8 (&dst)[NT][2]) {
+        const bool second = s >= S2, third = s >= S;
+        const int ks = third ? s - S : (second ? s - S2 : s), KQ = (second && !third) ? KQ1 : KQ2;
+        // (without a next unit the steps >= S are masked loads at a clamped address: the base must still be a real pointer)
+        const uch16* Wh = reinterpret_cast<const uch16*>((third && chain) ? a.W1nh : ((second && !third) ? a.W3h : a.W2h));
+        const uch16* Wl = reinterpret_cast<const uch16*>((third && chain) ? a.W1nl : ((second && !third) ? a.W3l : a.W2l));
+        const int kq = ks * 2 + h;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int q = t + 256 * i;
-            const int pl = q / (OQ * BN), r = q - pl * (OQ * BN);
-            const int o = r / BN, n = r - o * BN;
-            const int kq = c * OQ + o;
-            const bool ok = q < 2 * OQ * BN && kq < KQ && n < a.Npad;
-            uch16x8 v = *reinterpret_cast<const uch16x8*>((pl ? Wl : Wh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8);
-            if (!ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
-            }
-            b_reg[i] = v;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (wave * NT + nt) * 32 + l31;
+            const bool ok = (s < S || (chain && s < S + S2)) && kq < KQ && n < a.Npad;
+            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
+            const unsigned mk = opaque_mask(ok);
+            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
+            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
+            dst[nt][0] = *reinterpret_cast<uch16x8*>(&vh);
+            dst[nt][1] = *reinterpret_cast<uch16x8*>(&vl);
         }
     };
-    auto stage_b = [&]() {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int q = t + 256 * i;
-            if (q < 2 * OQ * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)q * 8) = b_reg[i];
-        }
-    };
-    prefetch_b(0);                                                      // in flight during the depthwise phase
-    float bias2[NT], bias3[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = (wave * NT + nt) * 32 + l31;
-        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
-        bias3[nt] = n < bf ? a.b3[n] : 0.0f;
-    }
-
+    for (int j = 0; j < D; ++j) load_b(j, bq[j]);                        // requested first: they return before the window loads below
     // ---- 1. both depthwise convs (stride 2, dwconv3x3_kernel's fma chain) -> the split planes of their branch ---------------------------
     float amax = 0.0f;                                                   // range guard (yn_device.h)
     auto dw_branch = [&](const float* __restrict__ src, int C, const float* __restrict__ wd, const float* __restrict__ bd, int act, uch16* Ph, uch16* Pl, int PS) {
@@ -1505,79 +1501,123 @@ __global__ __launch_bounds__(256, NT == 1 ? (KC == 32 ? 3 : 2) : 1) void down2_k
         }
     };
     dw_branch(a.y1, bf, a.wdw, a.bdw, a.dw_act, A2h, A2l, PS2);
+    YN_TS();
     dw_branch(a.x, cin, a.wdw1, a.bdw1, a.dw1_act, A1h, A1l, PS1);
-    stage_b();
-    if (ntot > 1) prefetch_b(1);
-    __syncthreads();
+    YN_TS();
+    // the biases of this lane's columns: requested here (not live during the register-hungry window rounds), used thousands of cycles later
+    float bias2[NT], bias3[NT], bias1n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wave * NT + nt) * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias3[nt] = n < bf ? a.b3[n] : 0.0f;
+        bias1n[nt] = (chain && n < bf) ? a.b1n[n] : 0.0f;
+    }
+    __syncthreads();                                                    // both operand tiles are complete
+    YN_TS();
     range_report(a.ovf, amax);                                          // every split of this workgroup is done
 
-    // ---- 2. the two pointwise convs as ONE walk over their K chunks (gemm_split_tile's order inside each) ------------------------------
+    // ---- 2. the pointwise convs as ONE walk over their k-steps (gemm_split_tile's order inside each): pw2, branch 1's, then - with a next
+    //      unit behind this one - that unit's pw1, whose operand is produced half way (step S): the weight fragments keep streaming across
+    //      the two barriers there ---------------------------------------------------------------------------------------------------------
     f32x16 acc0[NT], acc1[NT];
     float y3[NT][16];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
-    for (int g = 0; g < ntot; ++g) {
-        const bool second = g >= n2;
-        if (g == n2) {                                                  // pw2 is complete: its tile waits in registers for its partner
+    const int jhi = bf >> 1, Stot = chain ? S + S2 : S;
+    char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * (2 * bf));
+    // concat + shuffle store: out[row][2n] = branch 1, out[row][2n + 1] = branch 2; with a next unit behind it, the pairs of the columns
+    // n >= bf/2 - channels [bf, 2bf) of the output: that unit's x2 - are ALSO split into the (then free) planes of branch 2
+    auto store_pairs = [&]() {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (wave * NT + nt) * 32 + l31;
+            if (n < bf) {
+                const bool to_plane = chain && n >= jhi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    y3[nt][r] = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias2[nt], a.act2);
-                    acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float z = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias3[nt], a.act3);
+                    if (row < nrows) *reinterpret_cast<float2*>(out_base + (unsigned)(row * 2 * bf + 2 * n) * 4u) = make_float2(z, y3[nt][r]);
+                    if (to_plane) {                                     // (idle rows carry finite values of zero operands: never stored)
+                        const float v0 = z, v1 = y3[nt][r];
+                        uch16x2 hi, lo;
+                        amax = range_track(range_track(amax, v0), v1);
+                        hi[0] = (uch16)v0; hi[1] = (uch16)v1;
+                        lo[0] = (uch16)((v0 - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((v1 - (float)hi[1]) * 2048.0f);
+                        *reinterpret_cast<uch16x2*>(A2h + row * PS2 + 2 * (n - jhi)) = hi;
+                        *reinterpret_cast<uch16x2*>(A2l + row * PS2 + 2 * (n - jhi)) = lo;
+                    }
                 }
+            }
         }
-        const int c = second ? g - n2 : g, KQ = second ? KQ1 : KQ2, PS = second ? PS1 : PS2;
-        const uch16* Ahb = (second ? A1h : A2h) + l31 * PS + c * KC + h * 8;
-        const uch16* Alb = (second ? A1l : A2l) + l31 * PS + c * KC + h * 8;
-        const uch16* Bhb = Bh + (size_t)(h * BN + wave * NT * 32 + l31) * 8;
-        const uch16* Blb = Bhb + OQ * BN * 8;
+    };
+    for (int s0 = 0; s0 < Stot; s0 += D) {
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-            if (c * OQ + ks * 2 >= KQ) break;                           // wave-uniform: beyond the (zero-padded) K
-            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
-            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+        for (int j = 0; j < D; ++j) {
+            const int s = s0 + j;
+            if (s == S2) {                                              // (wave-uniform) pw2 is complete: its tile waits in registers for its partner
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        y3[nt][r] = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias2[nt], a.act2);
+                        acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f;
+                    }
+            }
+            if (chain && s == S) {                                      // (wave-uniform) the unit's output is complete: store it, x2' -> planes
+                __syncthreads();                                        // every wavefront is past its last read of the planes
+                store_pairs();
+                __syncthreads();                                        // x2' is complete (its K tail [bf, PS2) is still zero)
+                range_report(a.ovf, amax);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f; }
+            }
+            // steps beyond the walk (s >= Stot, at most D - 1 of them) multiply a valid A fragment by zero weights: exact zeros, no branch
+            const int sc = s < Stot ? s : Stot - 1;
+            const bool second = sc >= S2 && sc < S;
+            const int ks = sc >= S ? sc - S : (second ? sc - S2 : sc), PS = second ? PS1 : PS2;
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>((second ? A1h : A2h) + l31 * PS + ks * 16 + h * 8);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>((second ? A1l : A2l) + l31 * PS + ks * 16 + h * 8);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][1], acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[j][nt][0], acc1[nt], 0, 0, 0);
             }
-        }
-        if (g + 1 < ntot) {
-            __syncthreads();                                            // every wave is done with this chunk's weights
-            stage_b();
-            __syncthreads();
-            if (g + 2 < ntot) prefetch_b(g + 2);
+            load_b(s + D, bq[j]);                                       // (masked to zeros beyond the walk)
         }
     }
-
-    // ---- 3. concat + shuffle store: out[row][2n] = branch 1, out[row][2n + 1] = branch 2 -------------------------------------------------
-    char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * (2 * bf));
+    YN_TS();
+    if (!chain) {
+        store_pairs();
+    } else {
+        // the next unit's pw1 -> t1n (gemm_split_kernel's epilogue: 16-byte stores through the in-quad transpose)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = (wave * NT + nt) * 32 + l31;
-        if (n < bf) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < nrows) {
-                    const float z = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias3[nt], a.act3);
-                    *reinterpret_cast<float2*>(out_base + (unsigned)(row * 2 * bf + 2 * n) * 4u) = make_float2(z, y3[nt][r]);
-                }
-            }
-        }
+            for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+        GemmArgs e{};
+        e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = m0 + nrows; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
+        gemm_epilogue<NT>(e, acc0, m0, wave * NT * 32, true, lane, bias1n);
     }
+#ifdef YN_EXP_TIMING
+    YN_TS();
+    if (t == 0 && (blockIdx.x % 97) == 5)
+        printf("down2 bf %d blk %d dw2 %lld dw1 %lld sync %lld walk %lld end %lld total %lld\n", bf, (int)blockIdx.x, TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2],
+               TS[4] - TS[3], TS[5] - TS[4], TS[5] - TS[0]);
+#endif
+#undef YN_TS
 }
 
-static size_t down2_lds(int bf, int cin, int NT, int KC)
+static size_t down2_lds(int bf, int cin)
 {
     const int PS2 = ((bf + 7) / 8) * 8 + 8, PS1 = ((cin + 7) / 8) * 8 + 8;
-    return ((size_t)2 * 32 * PS2 + (size_t)2 * 32 * PS1 + (size_t)2 * (KC / 8) * 128 * NT * 8) * 2;
+    return ((size_t)2 * 32 * PS2 + (size_t)2 * 32 * PS1) * 2;
 }
 
 bool down2_covers(const Down2Args& a)
@@ -1591,23 +1631,13 @@ void launch_down2(const Down2Args& a, hipStream_t s)
 {
     const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
     const unsigned tiles = (unsigned)(((long)a.B * Ho * Wo + 31) / 32);
-    static const int kc_env = getenv("YN_DOWN2_KC") ? atoi(getenv("YN_DOWN2_KC")) : 0;       // A/B: 32 / 64 (bit-identical)
     static unsigned long long attr = 0;
     if (attr_pending(attr)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<1, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (a.Npad <= 128) {
-        // K chunks of 32 keep the workgroup at 48 KB (three per CU: every workgroup of a 32-image step resident at once); fewer than one
-        // workgroup per CU (one image): chunks of 64, half the barrier rounds
-        const int KC = kc_env ? kc_env : (tiles > 256 ? 32 : 64);
-        if (KC == 64) { set_last_kernel_name("down2_kernel<1,64>"); hipLaunchKernelGGL((down2_kernel<1, 64>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 1, 64), s, a); }
-        else          { set_last_kernel_name("down2_kernel<1,32>"); hipLaunchKernelGGL((down2_kernel<1, 32>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 1, 32), s, a); }
-    } else {                                                // stage 4 (bf = 232): one workgroup per CU at most, K = 232 in four rounds per pointwise conv
-        set_last_kernel_name("down2_kernel<2,64>");
-        hipLaunchKernelGGL((down2_kernel<2, 64>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin, 2, 64), s, a);
-    }
+    if (a.Npad <= 128) { set_last_kernel_name("down2_kernel<1,4>"); hipLaunchKernelGGL((down2_kernel<1, 4>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin), s, a); }
+    else               { set_last_kernel_name("down2_kernel<2,4>"); hipLaunchKernelGGL((down2_kernel<2, 4>), dim3(xcd_grid(tiles)), dim3(256), down2_lds(a.bf, a.cin), s, a); }
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -97,6 +97,7 @@ struct yn_handle {
     size_t nms_cap = 0;           // elements B*N currently allocated
     size_t nms_seg_cap = 0;       // B*(C+1)
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
+    size_t nms_iter_cap = 0;      // uint64 words of the parallel resolve's mask sequence
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
     float* fwd_only[3] = {nullptr, nullptr, nullptr};     // yn_train_forward: the training executors stop after the forward pass and copy the raw heads here
@@ -362,8 +363,10 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_order, need_seg * sizeof(int32_t)));
-        HIPCHK(h, hipMalloc((void**)&h->nms.ctr, need_seg * sizeof(int32_t)));          // >= 2 * B ints
-        HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, need_seg * sizeof(int32_t), h->stream));
+        HIPCHK(h, hipMalloc((void**)&h->nms.ctr, (need_seg + 4 * (size_t)B) * sizeof(int32_t)));          // >= 3 * B ints
+        HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, (need_seg + 4 * (size_t)B) * sizeof(int32_t), h->stream));
+        if (h->nms.seg_slot) { HIPCHK(h, hipFree(h->nms.seg_slot)); h->nms.seg_slot = nullptr; }
+        HIPCHK(h, hipMalloc((void**)&h->nms.seg_slot, need_seg * sizeof(int32_t)));
         h->nms_seg_cap = need_seg;
         drop_graphs(h);
     }
@@ -376,6 +379,21 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     }
     h->nms.matrix_stride = m_stride;
     h->nms.large_cap = (N / 1024 + 1) < C ? (N / 1024 + 1) : C;       // at most N/1024 segments can exceed 1024 items
+    // the parallel resolve of the large segments of a few-segment batch (one to three images): its removed-mask sequence
+    if ((long)B * C <= 256) {
+        const size_t cap = (size_t)(N / 1024 + 1), T = (size_t)(N + 63) / 64;
+        const size_t need_it = (size_t)(YN_NMS_ITER_K + 1) * B * cap * T;
+        if (need_it > h->nms_iter_cap) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (h->nms.iter) { HIPCHK(h, hipFree(h->nms.iter)); h->nms.iter = nullptr; }
+            if (h->nms.iter_last) { HIPCHK(h, hipFree(h->nms.iter_last)); h->nms.iter_last = nullptr; }
+            HIPCHK(h, hipMalloc(&h->nms.iter, need_it * sizeof(unsigned long long)));
+            HIPCHK(h, hipMalloc((void**)&h->nms.iter_last, (size_t)B * cap * sizeof(int32_t)));
+            h->nms_iter_cap = need_it;
+            drop_graphs(h);
+        }
+        h->nms.iter_T = (int)T;
+    }
     return 0;
 }
 
@@ -575,7 +593,10 @@ void run_unit(yn_handle* h, const std::string& P, const float* x, int B, int H, 
 // input), oB = a second [M][C] buffer (holds the two [M][bf] pass-through halves in flight), tA / tB = [M][bf] scratch.
 // Returns 0 (nothing launched) when the chain is off, the map is too small or no instantiated tile covers the shape; 1 when
 // the stage ran, *result = final [M][C]; -1 on an error (latched in the handle).
-int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result)
+// dry: only answer whether the stage will run as a chain (nothing launched).  t1_ready: unit 1's pw1 output is already in tA (the stride-2
+// unit's kernel computed it: down2_kernel's last phase)
+int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int W, int C, float* oB, float* tA, float* tB, float** result,
+                   bool dry = false, bool t1_ready = false)
 {
     if (!h->unit_chain) return 0;
     const int bf = C / 2;
@@ -602,7 +623,8 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
             q.out_ld = C;
             if (!unit_chain_covers(q)) return 0;
         }
-        run_pw(h, pw1, oA, C, bf, M, tA, bf, 0, nullptr, 0, 0);
+        if (dry) return 1;
+        if (!t1_ready) run_pw(h, pw1, oA, C, bf, M, tA, bf, 0, nullptr, 0, 0);
     }
     float* pbuf[2] = {oB, oB + (size_t)M * bf};
     const float* x1 = oA;
@@ -819,6 +841,7 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         TAKE(oB, Mo * C);
         snprintf(nm, sizeof nm, "backbone.stage%d.0", si + 2);
         const std::string P0 = nm;
+        bool down_chained = false;                          // the stride-2 unit's kernel has also produced unit 1's pw1 output (in t2)
         // stride-2 block: backbone/shufflenetv2.py:73-74
         {
             // the whole unit as ONE kernel where its tile fits (cin <= 32, bf <= 64: stage 2, whose pw1 output is the largest tensor of the
@@ -850,6 +873,20 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
             const bool use_down2 = !use_down && h->down_fuse && down2_env && !exact(h) && lp1.ws_hi && lp1.cin == curC && lp1.cout == bf && lp2.cin == bf && lp2.cout == bf &&
                                    ldw.stride == 2 && ldw.cout == bf && l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && l1p.Npad == lp2.Npad &&
                                    down2_covers(d2);
+            // when the stride-1 units behind it run as a chain, the kernel also computes unit 1's pw1 (on channels [bf, 2bf) of its own output)
+            // ... in the launch-latency regime only (fewer 32-pixel tiles than CUs: small batches - one 608 x 608 image saves two 10-15 us
+            // launches).  With every CU holding several workgroups the extra k-steps stream their weights at the CU's L1 rate (each 32-row
+            // workgroup pulls the whole matrix): 42 us against 30 + 13 at stage 3, 59 against 34 + 17 at stage 4 of a 32-image batch.
+            static const int down2_next = getenv("YN_DOWN2_NEXT") ? atoi(getenv("YN_DOWN2_NEXT")) : 1;     // 0: never, 2: always (A/B runs, tests)
+            const bool next_pays = down2_next == 2 || (down2_next == 1 && Mo <= 32 * 256);
+            if (use_down2 && next_pays && STAGE_REP[si] > 1 && run_unit_chain(h, si + 2, STAGE_REP[si], oA, B, Ho, Ho, C, oB, t2, t1, nullptr, true) == 1) {
+                snprintf(nm, sizeof nm, "backbone.stage%d.1.b2.pw1", si + 2);
+                const Layer& l1n = L(h, nm);
+                if (l1n.ws_hi && l1n.cin == bf && l1n.cout == bf && l1n.Npad == lp2.Npad) {
+                    d2.W1nh = l1n.ws_hi; d2.W1nl = l1n.ws_lo; d2.b1n = l1n.b_packed; d2.act1n = l1n.act; d2.t1n = t2;
+                    down_chained = true;
+                }
+            }
             if (use_down && !down_b1) {
                 run_dw(h, l1d, cur, curC, 0, B, curH, curH, tdw1, curC, 0);
                 run_pw(h, l1p, tdw1, curC, 0, Mo, tb1, bf, 0, nullptr, 0, 0);
@@ -867,8 +904,9 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                 // concat + shuffle - as one kernel (down2_kernel): two launches instead of five
                 run_pw(h, lp1, cur, curC, 0, Mi, t1, bf, 0, nullptr, 0, 0);
                 if (!dbg_skip(h, P0 + ".tail")) {
-                    Bracket br(h, P0 + ".dw+pw2|b1", 2.0 * (Mo * bf * (9.0 + bf) + Mo * curC * (9.0 + bf)),
-                               4.0 * (Mi * (double)(curC + bf) + 2.0 * Mo * bf + (double)curC * bf + (double)bf * bf));
+                    const double nx = down_chained ? 1.0 : 0.0;
+                    Bracket br(h, P0 + (down_chained ? ".dw+pw2|b1+pw1n" : ".dw+pw2|b1"), 2.0 * (Mo * bf * (9.0 + bf) + Mo * curC * (9.0 + bf) + nx * Mo * bf * bf),
+                               4.0 * (Mi * (double)(curC + bf) + (2.0 + nx) * Mo * bf + (double)curC * bf + (1.0 + nx) * bf * bf));
                     launch_down2(d2, h->cur);
                 }
             } else {
@@ -889,7 +927,9 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
         // stride-1 blocks (backbone/shufflenetv2.py:70-72; x1 = ch [0,bf) passes through, x2 = ch [bf,C)): one kernel per
         // unit, cut at the depthwise conv (unit_chain_kernel), after the first unit's pw1; else three kernels per unit
         const int R = STAGE_REP[si];
-        const int chained = R > 1 ? run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t1, t2, &o_cur) : 0;
+        const int chained = R > 1 ? (down_chained ? run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t2, t1, &o_cur, false, true)
+                                                  : run_unit_chain(h, si + 2, R, o_cur, B, Ho, Ho, C, o_nxt, t1, t2, &o_cur)) : 0;
+        if (down_chained && chained != 1) return fail(h, "stage %d: the chain the stride-2 unit prepared for did not run", si + 2);
         if (chained < 0) return 1;
         if (!chained) {
             for (int bi = 1; bi < R; ++bi) {
@@ -1200,7 +1240,7 @@ void yn_destroy(yn_handle* h)
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
-                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr};
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr, h->nms.iter, h->nms.iter_last, h->nms.seg_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
