@@ -28,7 +28,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
 PEAK_SPLIT_TFLOPS = 2500.0 / 3  # split-f16 kernels: three f16 MFMAs (2.5 PF dense) per fp32 product => 833 TFLOP/s of fp32-class work
-PMC_LAYERS_FILES = ("r03_pmc_layers.json", "r03_pmc_layers_608_bs32.json", "r03_pmc_layers_05x_bs128.json", "r02_pmc_layers.json")
+PMC_LAYERS_FILES = ("r04_pmc_layers.json", "r04_pmc_layers_608_bs32.json", "r04_pmc_layers_05x_bs128.json")
 
 
 def source_hash():
@@ -296,7 +296,7 @@ def _train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
     floor_ms = 3.0 * act_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
     line["roofline"] = {"bound": "hbm", "alg_bytes_per_step": int(3 * act_bytes), "hbm_floor_ms": round(floor_ms, 4), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "achieved": round(3.0 * act_bytes / (elapsed / args.steps) / 1e9, 1), "frac": round(floor_ms / (elapsed / args.steps * 1e3), 4),
-                        "traffic": None, "kernel": "whole step (per-kernel table: profiles/r03_kernel_stats_train_608_bs32_%s.csv)" % dtype}
+                        "traffic": None, "kernel": "whole step (per-kernel table: profiles/r04_kernel_stats_train_608_bs32_%s.csv)" % dtype}
     h.close()
     if brief:
         out = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite", "roofline")}
@@ -663,8 +663,13 @@ def main():
     force_dist = bool(os.environ.get("YN_BENCH_FORCE_DIST"))
     parallel.init(backend, dev, force=force_dist)            # RCCL; inference uses it only for the barrier / max-over-ranks
     dist = torch.distributed if (world > 1 or force_dist) else None
+    tune_file = os.environ.get("YN_TUNE_FILE")                # profiling aid: adopt a previous run's autotune table, save this run's
+    if tune_file and os.path.exists(tune_file):
+        capi.tune_load(tune_file, dev.index)
 
     def finish():
+        if tune_file and rank == 0:
+            capi.tune_save(tune_file, dev.index)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()

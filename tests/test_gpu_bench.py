@@ -183,7 +183,7 @@ assert capi.tune_load("/nonexistent/file", 0) == -1
         r = subprocess.run([sys.executable, "-c", code, mode, path], cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
     lines = open(path).read().strip().splitlines()
-    assert len(lines) > 10 and all(len(l.split()) >= 3 for l in lines)
+    assert len(lines) >= 5 and all(len(l.split()) >= 3 for l in lines)      # (round 4: fewer stand-alone pointwise launches are left to tune)
     import torch
     a, b = torch.load(path + ".save"), torch.load(path + ".load")
     assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -78,7 +78,7 @@ def test_model_ema_copy_is_re_evaluated_after_every_update():
     model = yolo_nano_amd.YOLONano("cuda", input_size=S, num_classes=C, trainable=True, anchor_size=arch.MULTI_ANCHOR_SIZE, backbone="1.0x")
     model.load_state_dict({k: torch.as_tensor(v) for k, v in weights.make_state_dict("1.0x", C).items()}, strict=False)
     model = model.to("cuda").train()
-    opt = yolo_nano_amd.SGD(model, lr=5e-2)
+    opt = yolo_nano_amd.SGD(model, lr=2e-3)
     x = torch.as_tensor(weights.make_input(B, S, seed=2)).cuda()
     labels = [[[0.2, 0.2, 0.6, 0.7, 3.0]], [[0.1, 0.3, 0.5, 0.9, 7.0], [0.5, 0.5, 0.8, 0.8, 1.0]]]
     t = yolo_nano_amd.multi_gt_creator(S, [8, 16, 32], labels, arch.MULTI_ANCHOR_SIZE)

@@ -90,7 +90,8 @@ def test_train_step_matches_reference_fixture(golden):
         net = TrainNet(sd, "1.0x", C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=dt)
         net.train_step(x0, g["target"], S, lr=lr)
         l1, g1 = net.train_step(weights.make_input(B, S, seed=11), g["target"], S, lr=lr)
-        runs[dt] = (np.asarray(l1, np.float64), {n: float(np.sqrt((g1[n].double().numpy() ** 2).sum())) for n in names})
+        runs[dt] = (np.asarray(l1, np.float64), {n: float(np.sqrt((g1[n].double().numpy() ** 2).sum())) for n in names},
+                    {k[7:]: g1[k[7:]].double().numpy() for k in g if k.startswith("grad_1:")})
     x1 = torch.as_tensor(weights.make_input(B, S, seed=11)).cuda()
     losses1 = h.train_step(x1, t, lr=lr, momentum=0.9, weight_decay=5e-4)
     assert torch.isfinite(losses1).all() and not torch.equal(losses1, losses)
@@ -105,6 +106,20 @@ def test_train_step_matches_reference_fixture(golden):
     spread_g = np.maximum.reduce([np.abs(n32 - n64), np.abs(n32 - ref_l2), np.abs(n64 - ref_l2)])
     badn = [(names[i], l2_1[i], ref_l2[i], spread_g[i]) for i in range(len(names)) if abs(l2_1[i] - ref_l2[i]) > 3 * spread_g[i] + 1e-2 * ref_l2[i] + 1e-4]
     assert not badn, badn[:8]
+    # ... and ELEMENT-WISE on the ten gradients the fixture records for this step (stem, stage 2-4, lateral, smooth, heads): every element
+    # within 3x the largest pairwise max-abs distance among the three realisations of that tensor (+ 1e-3 of its scale) of the recorded value
+    bade = []
+    for k in g:
+        if not k.startswith("grad_1:"):
+            continue
+        name = k[7:]
+        ref = g[k].astype(np.float64)
+        a32, a64 = runs[torch.float32][2][name], runs[torch.float64][2][name]
+        spread_e = max(float(np.abs(a32 - a64).max()), float(np.abs(a32 - ref).max()), float(np.abs(a64 - ref).max()))
+        err = float(np.abs(_grad(h, name, ref.shape).astype(np.float64) - ref).max())
+        if err > 3 * spread_e + 1e-3 * float(np.abs(ref).max()):
+            bade.append((name, err, spread_e, float(np.abs(ref).max())))
+    assert not bade, bade
     h.close()
 
 
@@ -343,31 +358,76 @@ def _snapshot(h, sd):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16"])
-def test_multi_scale_training_through_set_grid(golden, precision):
-    """train.py:202-208: every 10 iterations the SAME model gets a new input size through set_grid() and keeps training.
-    Two steps at 128, set_grid(192), two steps, set_grid(128) again, two steps; every step's losses and gradients are checked against
-    the float64 oracle started from the handle's own current parameters and running statistics (so each comparison stands alone:
-    nothing chaotic accumulates), the updates are real ones in between, and the arena re-carving in both directions is exercised.
-    The sharp check of set_grid itself: at every size change a FRESH handle built at the new size from the same snapshot must produce
-    the same losses and gradients (1e-5 of max|g|: only the order of atomic sums differs) - measured 2e-7; stale buffers, grids or
-    arena carving from the previous size would show here.  Against the oracle: after real updates ONE activation whose pre-activation
-    sits at zero flips sign between two fp32 realisations of the same step, and everything upstream of it moves together by 1e-2-class
-    amounts - measured (tools/diag_multiscale.py) in the HIP step and in the fp32 torch oracle alike, independently of each other
-    (e.g. HIP 1.4e-2 where the oracle has 2e-5 on one step, 6e-3 against 3.5e-2 on the next), while heads and losses agree to 1e-5.
-    The size of such a jump is not bounded by any precision argument (soak runs: 5.0e-2 - 7.9e-2 on every layer upstream of the
-    flip on one run in two, nothing on the other), so the per-gradient bar against the oracle is a gross-error bar only: max(8x the
-    fp32 oracle's own error, 0.25) for f32 and 2.5x the fp16-storage emulation's error + 0.25 for f16, plus a cosine >= 0.98 between
-    the whole flat gradient and the oracle's (f16: no more than 0.1 below the emulation's own cosine).  The sharp statements are the other three: losses to 1e-4 (f32), the fresh-handle
-    identity to 1e-5 at each size change, and the un-updated first step against train.npz in test_train_step_matches_reference_fixture."""
-    from yolo_nano_amd import capi
+def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch):
+    """The SHARP half of the multi-scale evidence (the steps with real updates below can only be held to chaos-sized bars): the same handle
+    walks 128 -> 192 -> 128 through set_grid() with update=False steps on the UNTOUCHED initial weights - nothing chaotic has happened to
+    them, so every parameter gradient at every size is held to the bars of the single-size tests: f32 as close to the float64 gradient as
+    the fp32 oracle is (x4, or half the worst fp32 error, or 2e-3), f16 within 2x the fp16-storage emulation's error (+ 2e-2) with the median
+    ratio below 1.25; losses 1e-4 (f32).  Returning to 128 must reproduce the first 128 step to the order of the atomic sums (1e-5 of
+    max|g|), and - f16 - the step with the BatchNorm sums fused into the GEMM epilogues equals the step with separate reduction launches
+    (YN_TRAIN_FUSE_STATS / YN_TRAIN_FUSE_SUMS = 0) to 2e-3 of max|g| at both sizes."""
     from oracle.torch_port import TrainNet
     g = golden("train.npz")
     C, B = 20, 4
     h, sd = _handle(128, C, B, float(g["init_bias_value"]))
     h.train_precision(precision)
     rel = lambda a, e: float(np.linalg.norm((a - e).ravel()) / np.linalg.norm(e.ravel()))
-    seen_N = []
+    first = None
     for phase, S in enumerate((128, 192, 128)):
+        h.set_grid(S)
+        x = weights.make_input(B, S, seed=60 + (phase % 2))
+        target = _targets(S, C, B, seed=17 + (phase % 2))
+        xd, td = torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda()
+        losses = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
+        grads = h.flat_grads.clone()
+        if phase == 0:
+            first = (losses, grads)
+        if phase == 2:                                             # back at the first size: the first step again, to atomic-sum order
+            np.testing.assert_allclose(losses, first[0], rtol=1e-5)
+            assert float((grads - first[1]).abs().max()) <= 1e-5 * float(first[1].abs().max())
+            continue
+        mk = lambda **kw: TrainNet(sd, "1.0x", C, anchors=arch.MULTI_ANCHOR_SIZE, **kw)
+        l64, g64 = mk(dtype=torch.float64).train_step(x, target, S, lr=1e-4)
+        g64 = {k: v.numpy() for k, v in g64.items()}
+        gmax = max(float(np.abs(v).max()) for v in g64.values())
+        live = [n for n, v in g64.items() if float(np.abs(v).max()) >= 1e-9 * gmax]
+        if precision == "f32":
+            _, gy = mk().train_step(x, target, S, lr=1e-4)
+            ey = {n: rel(gy[n].double().numpy(), g64[n]) for n in live}
+            np.testing.assert_allclose(losses, l64, rtol=1e-4)
+            worst = max(ey.values())
+            bad = [(n, rel(_grad(h, n, g64[n].shape).astype(np.float64), g64[n]), ey[n]) for n in live
+                   if rel(_grad(h, n, g64[n].shape).astype(np.float64), g64[n]) > max(4 * ey[n], 0.5 * worst, 2e-3)]
+            assert not bad, "S=%d (name, err, fp32 oracle err): %s" % (S, bad[:8])
+        else:
+            lq, gy = mk(dtype=torch.float64, fp16_storage=True).train_step(x, target, S, lr=1e-4)
+            ey = {n: rel(gy[n].numpy(), g64[n]) for n in live}
+            for a, e, q in zip(losses, l64, lq):
+                assert abs(a - e) <= 2.0 * abs(q - e) + 2e-2 * abs(e), (S, losses, l64, lq)
+            errs = {n: rel(_grad(h, n, g64[n].shape).astype(np.float64), g64[n]) for n in live}
+            bad = [(n, errs[n], ey[n]) for n in live if errs[n] > 2.0 * ey[n] + 2e-2]
+            assert not bad, "S=%d (name, err, emulation err): %s" % (S, bad[:8])
+            ratios = [errs[n] / max(ey[n], 1e-6) for n in live]
+            assert np.median(ratios) < 1.25, (S, np.median(ratios))
+            # the fused BatchNorm statistics / backward sums against their separate reduction launches, at this size
+            monkeypatch.setenv("YN_TRAIN_FUSE_STATS", "0"); monkeypatch.setenv("YN_TRAIN_FUSE_SUMS", "0")
+            l_un = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
+            monkeypatch.delenv("YN_TRAIN_FUSE_STATS"); monkeypatch.delenv("YN_TRAIN_FUSE_SUMS")
+            np.testing.assert_allclose(l_un, losses, rtol=1e-4)
+            assert float((h.flat_grads - grads).abs().max()) <= 2e-3 * float(grads.abs().max()), S
+    h.close()
+
+
+def _multi_scale_run(g, precision, sizes, B, C=20):
+    """The body of test_multi_scale_training_through_set_grid (also tools/soak_multiscale.py): -> list of per-step dicts with the worst
+    per-tensor excess over the bar, the offending tensors and the two cosines."""
+    from yolo_nano_amd import capi
+    from oracle.torch_port import TrainNet
+    h, sd = _handle(sizes[0], C, B, float(g["init_bias_value"]))
+    h.train_precision(precision)
+    rel = lambda a, e: float(np.linalg.norm((a - e).ravel()) / np.linalg.norm(e.ravel()))
+    out, seen_N = [], []
+    for phase, S in enumerate(sizes):
         h.set_grid(S)
         seen_N.append(h.N)
         assert h.N == arch.num_predictions(S)
@@ -378,6 +438,7 @@ def test_multi_scale_training_through_set_grid(golden, precision):
             mk = lambda **kw: TrainNet(cur, "1.0x", C, anchors=arch.MULTI_ANCHOR_SIZE, **kw)
             l64, g64 = mk(dtype=torch.float64).train_step(x, target, S, lr=1e-4)
             g64 = {k: v.numpy() for k, v in g64.items()}
+            lq = None
             if precision == "f32":
                 _, gy = mk().train_step(x, target, S, lr=1e-4)
                 gy = {k: v.double().numpy() for k, v in gy.items()}
@@ -395,40 +456,64 @@ def test_multi_scale_training_through_set_grid(golden, precision):
             before = h.flat_params.clone()
             losses = h.train_step(torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda(), lr=1e-4, momentum=0.9, weight_decay=5e-4, update=True).cpu().numpy()
             assert np.isfinite(losses).all() and h.skipped_steps() == 0, (phase, it, losses)
-            if precision == "f32":
-                np.testing.assert_allclose(losses, l64, rtol=1e-4, err_msg="phase %d step %d" % (phase, it))
-            else:
-                for a, e, q in zip(losses, l64, lq):              # (after updates two fp16 realisations of a step differ by 2-3 %: soak, 1.8 % in the bbox loss on one run in ten)
-                    assert abs(a - e) <= 3.0 * abs(q - e) + 4e-2 * abs(e) + 2e-2, (phase, it, losses, l64, lq)
+            assert not torch.equal(h.flat_params, before)                        # the update was applied
             gmax = max(float(np.abs(v).max()) for v in g64.values())
             live = [n for n, v in g64.items() if float(np.abs(v).max()) >= 1e-9 * gmax]
             ey = {n: rel(gy[n], g64[n]) for n in live}
-            bad = []
+            errs = {}
             for n in live:
                 got = _grad(h, n, g64[n].shape).astype(np.float64)
                 assert np.isfinite(got).all(), n
-                err = rel(got, g64[n])
-                lim = max(8 * ey[n], 0.25) if precision == "f32" else 2.5 * ey[n] + 0.25
-                if err > lim:
-                    bad.append((n, err, ey[n]))
-            # f16 after real updates: a few small tensors of the 4 x 4 head level (64 positions in the batch: a BatchNorm gamma's gradient is a handful of
-            # fp16-rounded terms) land outside any per-tensor bar on one run in five (soak: head_det_3.1.convs.1.weight at 1.37 against a yardstick of
-            # 0.26) while every other tensor and the whole-gradient cosine below are in: at most three such tensors, none grossly off
-            allowed = 0 if precision == "f32" else 3
-            assert len(bad) <= allowed and all(e <= 3.0 for _, e, _ in bad), "phase %d (S=%d) step %d: (name, err, yardstick) %s" % (phase, S, it, bad[:8])
+                errs[n] = rel(got, g64[n])
             va = np.concatenate([_grad(h, n, g64[n].shape).astype(np.float64).ravel() for n in live])
             ve = np.concatenate([g64[n].ravel() for n in live])
+            vy = np.concatenate([gy[n].ravel() for n in live])
             cos = lambda u, w: float(u @ w / (np.linalg.norm(u) * np.linalg.norm(w)))
-            vy = np.concatenate([gy[n].ravel() for n in live])                 # the yardstick's own direction error (fp16 storage: 0.85-0.9 on this network)
-            assert cos(va, ve) >= (0.98 if precision == "f32" else min(0.98, cos(vy, ve) - 0.1)), (phase, it, cos(va, ve), cos(vy, ve))
-            assert not torch.equal(h.flat_params, before)                        # the update was applied
+            out.append({"phase": phase, "S": S, "it": it, "losses": losses, "l64": np.asarray(l64), "lq": None if lq is None else np.asarray(lq),
+                        "errs": errs, "ey": ey, "cos": cos(va, ve), "cos_y": cos(vy, ve)})
     assert seen_N[0] == seen_N[2] != seen_N[1]
     # and the eval path after the size changes: fold the trained weights, infer at a third size
     h.set_grid(160)
     h.fold_bn()
-    out = h.infer(torch.as_tensor(weights.make_input(2, 160, seed=1)).cuda())
-    assert int(out[4].sum().item()) > 0
+    o = h.infer(torch.as_tensor(weights.make_input(2, 160, seed=1)).cuda())
+    assert int(o[4].sum().item()) > 0
     h.close()
+    return out
+
+
+# per-tensor bar of the steps WITH updates: (multiple of the yardstick's own error, absolute floor)
+MS_SIZES, MS_B = (256, 320, 256), 4
+MS_BAR = {"f32": (8.0, 0.1), "f16": (2.5, 0.1)}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_multi_scale_training_through_set_grid(golden, precision):
+    """train.py:202-208: every 10 iterations the SAME model gets a new input size through set_grid() and keeps training.
+    Two steps at 256, set_grid(320), two steps, set_grid(256) again, two steps - REAL updates in between; every step's losses and gradients
+    are checked against the float64 oracle started from the handle's own current parameters and running statistics (each comparison stands
+    alone), and the arena re-carving in both directions is exercised.  Sharp statements: at every size change a FRESH handle built at the new
+    size from the same snapshot gives the same losses and gradients (1e-5 of max|g|: only the order of atomic sums differs; measured 2e-7),
+    losses to 1e-4 (f32), and the update-free walk of test_set_grid_steps_without_updates_are_sharp.  After real updates single activations
+    whose pre-activation sits at zero flip sign between two fp32 realisations of one step (measured in the HIP step and in the fp32 torch
+    oracle alike, tools/diag_multiscale.py), and everything upstream moves with them; round 3 ran this walk at 128 / 192 with four images,
+    where the stride-32 level gives a BatchNorm channel 64 positions and one flip moved whole tensors by up to 300 % - the test then allowed
+    three tensors outside any bar.  Round 4 runs it at 256 / 320 (256 / 400 positions per channel at stride 32): a flip is a 1 / 256 effect,
+    and EVERY tensor is held to max(8x the fp32 oracle's own error, 0.1) (f32) / 2.5x the fp16-storage emulation's error + 0.1 (f16) - no
+    exemptions - plus a cosine >= 0.98 between the whole flat gradient and the oracle's (f16: no more than 0.1 below the emulation's own).
+    Soak: gpurun_out/r4_soak_multiscale.txt (tools/soak_multiscale.py, 20 runs per precision)."""
+    g = golden("train.npz")
+    k_mul, k_abs = MS_BAR[precision]
+    for st in _multi_scale_run(g, precision, MS_SIZES, MS_B):
+        tag = "phase %d (S=%d) step %d" % (st["phase"], st["S"], st["it"])
+        if precision == "f32":
+            np.testing.assert_allclose(st["losses"], st["l64"], rtol=1e-4, err_msg=tag)
+        else:
+            for a, e, q in zip(st["losses"], st["l64"], st["lq"]):
+                assert abs(a - e) <= 3.0 * abs(q - e) + 4e-2 * abs(e) + 2e-2, (tag, st["losses"], st["l64"], st["lq"])
+        bar = (lambda y: max(k_mul * y, k_abs)) if precision == "f32" else (lambda y: k_mul * y + k_abs)
+        bad = [(n, e, st["ey"][n]) for n, e in st["errs"].items() if e > bar(st["ey"][n])]
+        assert not bad, "%s: (name, err, yardstick) %s" % (tag, bad[:8])
+        assert st["cos"] >= (0.98 if precision == "f32" else min(0.98, st["cos_y"] - 0.1)), (tag, st["cos"], st["cos_y"])
 
 
 def test_allreduce_grads_over_rccl_without_torch_distributed(golden):

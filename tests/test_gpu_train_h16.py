@@ -294,6 +294,27 @@ def test_h16_step_is_as_exact_as_fp16_storage_allows(golden, backbone, S, C, B):
             bad.append((name, e_hip, e_emul))
     assert not bad, "fp16 gradients further from exact than fp16 storage explains (name, hip, emulation): %s" % bad[:10]
     assert np.median(ratios) < 1.25 and np.percentile(ratios, 90) < 1.6, (np.median(ratios), np.percentile(ratios, 90))      # over all parameters: no further than the emulation
+    # A SECOND, independent realisation of "fp16 storage": the same storage points on float32 arithmetic (other summation orders, other
+    # roundings in front of every fp16 rounding point - the stored values land on neighbouring fp16 numbers here and there, as they do in
+    # the HIP step).  The two emulations span what fp16 storage does to this step; the HIP gradient has to sit INSIDE that span, tensor by
+    # tensor: no further from either emulation than 1.5x their distance from each other (+ 2e-2), and no further from exact than the worse of
+    # the two (x1.3 + 2e-2) - a yardstick that does not depend on one emulation's rounding points being the builder's own choice.
+    from oracle.torch_port import TrainNet
+    _, gq32 = TrainNet(sd, backbone, C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=torch.float32, fp16_storage=True).train_step(x, target, S)
+    bad2, span = [], []
+    for name, exact in g64.items():
+        if float(np.abs(exact).max()) < 1e-9 * gmax:
+            continue
+        got_g = h.flat_grads[h.param_slice(name)].cpu().numpy().reshape(exact.shape).astype(np.float64)
+        e32 = gq32[name].double().numpy()
+        d_ee = rel(e32, gq[name])                             # the two emulations against each other
+        d_h64, d_h32 = rel(got_g, gq[name]), rel(got_g, e32)
+        worse = max(rel(gq[name], exact), rel(e32, exact))
+        span.append(max(d_h64, d_h32) / max(d_ee, 1e-6))
+        if max(d_h64, d_h32) > 1.5 * d_ee + 2e-2 or rel(got_g, exact) > 1.3 * worse + 2e-2:
+            bad2.append((name, d_h64, d_h32, d_ee, rel(got_g, exact), worse))
+    assert not bad2, "outside the span of two fp16-storage realisations (name, d(hip,e64), d(hip,e32), d(e64,e32), err, worse emulation err): %s" % bad2[:8]
+    assert np.median(span) < 1.2, np.median(span)
     # the loss scale is removed again, and a clean step leaves it in place
     assert h.skipped_steps() == 0
     h.close()

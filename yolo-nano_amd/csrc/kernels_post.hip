@@ -996,13 +996,10 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
 __global__ __launch_bounds__(1024) void bucket_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const int32_t* __restrict__ cls,
                                                            int N, int C, int32_t* __restrict__ seg_count, int32_t* __restrict__ seg_off,
                                                            int32_t* __restrict__ tile_off, int32_t* __restrict__ bucket, int32_t* __restrict__ keep,
-                                                           float4* __restrict__ sbox, u64* __restrict__ gscratch, size_t gscratch_stride, int32_t* __restrict__ ctr,
-                                                           int32_t* __restrict__ unsorted, int rank_min,
-                                                           int32_t* __restrict__ seg_slot, int32_t* __restrict__ slot_list, int slot_cap,
-                                                           u64* __restrict__ iter, int32_t* __restrict__ iter_last, int iter_T)
+                                                           float4* __restrict__ sbox, u64* __restrict__ gscratch, size_t gscratch_stride, int32_t* __restrict__ ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    __shared__ int wcnt[16], s_n, s_off, s_last, s_slot;
+    __shared__ int wcnt[16], s_n, s_off, s_last;
     const int c = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t* c_in = cls + (size_t)b * N;
@@ -1031,31 +1028,11 @@ __global__ __launch_bounds__(1024) void bucket_sort_kernel(const float* __restri
         s_off = n ? atomicAdd(&ctr[b * 2], n) : 0;
         seg_count[(size_t)b * C + c] = n;
         seg_off[(size_t)b * C + c] = s_off;
-        // a segment above YN_NMS_ITER_MIN boxes takes a slot of the parallel resolve (resolve_iter_kernel): its removed-mask sequence starts at zero
-        int slot = -1;
-        if (seg_slot) {
-            if (iter && n > YN_NMS_ITER_MIN) {
-                slot = atomicAdd(&ctr[2 * gridDim.y + b], 1);
-                if (slot < slot_cap) { slot_list[(size_t)b * (slot_cap + 1) + 1 + slot] = c; iter_last[(size_t)b * slot_cap + slot] = 0; }
-                else slot = -1;
-            }
-            seg_slot[(size_t)b * C + c] = slot;
-        }
-        s_slot = slot;
     }
     __syncthreads();
     const int n_c = s_n, off = s_off;
-    if (s_slot >= 0) {                                      // masks 0 and 1 of the sequence: all zero (iteration it clears mask it + 1)
-        const size_t per_it = (size_t)gridDim.y * slot_cap * iter_T;
-        u64* r0 = iter + ((size_t)b * slot_cap + s_slot) * iter_T;
-        const int T = (n_c + 63) >> 6;
-        for (int w = tid; w < T; w += 1024) { r0[w] = 0ull; r0[per_it + w] = 0ull; }
-    }
     if (n_c) {
-        // a segment above rank_min boxes is only COLLECTED here (ascending candidate ids, into `unsorted`): rank_sort_kernel, spread over
-        // the chip, puts it in order - one workgroup's bitonic network over 8 192 keys is 90 us of a 608 x 608 image's 690
-        const bool by_rank = unsorted != nullptr && n_c > rank_min;
-        int32_t* ids = (by_rank ? unsorted : bucket) + (size_t)b * N + off;
+        int32_t* ids = bucket + (size_t)b * N + off;
         int pos = wcnt[wave];
         for (int n0 = r0; n0 < r1; n0 += 512) {
             int lab[8];
@@ -1073,12 +1050,7 @@ __global__ __launch_bounds__(1024) void bucket_sort_kernel(const float* __restri
         __threadfence_block();
         __syncthreads();
         const int P = nms_pow2(n_c);
-        if (by_rank) {                                      // the (score, id) keys of the segment, for rank_sort_kernel's scalar loads (scratch: the matrix area)
-            u64* kout = gscratch + (size_t)b * gscratch_stride + off;
-            const float* sc = scores + (size_t)b * N;
-            for (int j = tid; j < n_c; j += 1024) { const int id = ids[j]; kout[j] = ((u64)order_bits(sc[id]) << 32) | (unsigned)id; }
-        }
-        else if (n_c > YN_SORT_LARGE) sort_segment<false>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, ids, true, n_c, P, gscratch + (size_t)b * gscratch_stride, sbox + (size_t)b * N + off);
+        if (n_c > YN_SORT_LARGE) sort_segment<false>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, ids, true, n_c, P, gscratch + (size_t)b * gscratch_stride, sbox + (size_t)b * N + off);
         else sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, ids, true, n_c, P, reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
     }
     // the last workgroup of the image: tile offsets (prefix over the classes), counters back to zero
@@ -1101,55 +1073,7 @@ __global__ __launch_bounds__(1024) void bucket_sort_kernel(const float* __restri
             }
             tile_off[(size_t)b * (C + 1) + C] = tiles;
             ctr[b * 2] = 0; ctr[b * 2 + 1] = 0;
-            if (seg_slot) {
-                const int ns = __hip_atomic_load(&ctr[2 * gridDim.y + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                slot_list[(size_t)b * (slot_cap + 1)] = ns < slot_cap ? ns : slot_cap;
-                ctr[2 * gridDim.y + b] = 0;
-            }
         }
-    }
-}
-
-// ---- rank sort of the LARGE segments of a few-segment batch (bucket_sort_kernel collected them unsorted, with their keys) -------------
-// position of item i in the descending (score, id) order = number of keys greater than its own: n^2 compares, but spread over
-// ceil(n / 64) workgroups per segment on an otherwise idle chip (one to three images) instead of one workgroup's serial network.
-// The (score, id) keys are unique, so this is the same total order sort_segment produces.  Lane = one item (the same 64 items in all
-// four wavefronts of the workgroup); wavefront w counts over its quarter of the keys, which arrive through SCALAR loads (the address
-// is wave-uniform: eight keys per s_load, compared from SGPRs - the first form read them as LDS broadcasts at one wavefront per SIMD:
-// 40 cycles per key, 84 us for 5 000 boxes); the four partial counts meet in LDS.
-// grid (ceil(N / 64), C, B), 256 threads.
-__global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
-                                                        const int32_t* __restrict__ unsorted, const u64* __restrict__ keys, size_t keys_stride,
-                                                        int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C, int rank_min)
-{
-    __shared__ int part[4][64];
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int n = seg_count[(size_t)b * C + c];
-    const int i0 = blockIdx.x * 64;
-    if (n <= rank_min || i0 >= n) return;
-    const int off = seg_off[(size_t)b * C + c];
-    const u64* K = keys + (size_t)b * keys_stride + off;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int i = i0 + lane;
-    const u64 my_key = i < n ? K[i] : ~0ull;                // idle lanes: nothing is greater
-    const int q = (((n + 3) >> 2) + 7) & ~7;                // keys per wavefront, a multiple of 8
-    const int j_lo = wave * q, j_hi = min(n, j_lo + q);
-    int rank = 0;
-    for (int j = j_lo; j < j_hi; j += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const u64 k = (j + u < j_hi) ? K[j + u] : 0ull;  // (uniform; the read past the segment's end stays inside the scratch area)
-            rank += k > my_key ? 1 : 0;
-        }
-    }
-    part[wave][lane] = rank;
-    __syncthreads();
-    if (wave == 0 && i < n) {
-        rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        const int my_id = (int)(unsigned)(my_key & 0xffffffffu);
-        bucket[(size_t)b * N + off + rank] = my_id;
-        sbox[(size_t)b * N + off + rank] = *reinterpret_cast<const float4*>(boxes + ((size_t)b * N + my_id) * 4);
     }
 }
 
@@ -1157,6 +1081,12 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const float* __restrict_
 // Segment with T = ceil(n/64) chunks owns T(T+1)/2 tiles, stored by bands: band ri holds 64 rows x (T-ri) words,
 // word (row, ci-ri) at  band_off(ri) + row*(T-ri) + (ci-ri),  band_off(ri) = 64*(ri*T - ri*(ri-1)/2).
 __device__ __forceinline__ size_t band_off(int ri, int T) { return (size_t)64 * ((size_t)ri * T - (size_t)ri * (ri - 1) / 2); }
+// Segments ABOVE YN_SORT_SMALL boxes store their tiles column-major instead (round 4): tile (ri, ci) as 64 contiguous words (one per row)
+// at ctile_off(ri, ci) - all tiles of a column chunk ci back to back, ri ascending.  What chunk ci's resolve needs from every earlier band is
+// then ONE contiguous block (resolve_columns pulls it in with coalesced loads issued four steps ahead), and a tile store is 512 contiguous
+// bytes instead of 64 words strided by the band's width.  The same T (T + 1) / 2 * 64 words either way.
+__device__ __forceinline__ size_t ctile_off(int ri, int ci) { return ((size_t)ci * (ci + 1) / 2 + ri) * 64; }
+__device__ __forceinline__ bool nms_colmajor(int n) { return n > 1024; }
 
 // min / max as plain v_min_f32 / v_max_f32: fminf / fmaxf on operands loaded from LDS cost a canonicalising v_max each (4.5 of the
 // 24 VALU instructions per pair in the tile loop below); NaN operands only reach the exact path (union is NaN, not > 0)
@@ -1247,12 +1177,13 @@ __device__ __forceinline__ u64 tile_word(const float4* __restrict__ sb, int n, i
     return tile_word_boxes<DIOU>(bx, cb, n, ri, ci, thresh, cbox, carea);
 }
 
-template <bool DIOU>
+template <bool DIOU, bool COLM = false>
 __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n, int T, int ri, int ci, float thresh,
                                             u64* __restrict__ M, float4* cbox, float* carea)
 {
     const u64 mask = tile_word<DIOU>(sb, n, ri, ci, thresh, cbox, carea);
-    M[band_off(ri, T) + (size_t)(threadIdx.x & 63) * (T - ri) + (ci - ri)] = mask;
+    if (COLM) M[ctile_off(ri, ci) + (threadIdx.x & 63)] = mask;
+    else M[band_off(ri, T) + (size_t)(threadIdx.x & 63) * (T - ri) + (ci - ri)] = mask;
 }
 
 // grid (G, B), block 64: block g of image b walks tiles g, g+G, ... of that image
@@ -1279,8 +1210,10 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
         int rem = t - toff[c], ri = 0;
         while (rem >= T - ri) { rem -= T - ri; ++ri; }
         const int ci = ri + rem;
-        matrix_tile<DIOU>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
-                          M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
+        if (nms_colmajor(n)) matrix_tile<DIOU, true>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
+                                                     M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
+        else matrix_tile<DIOU>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
+                               M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
     }
 }
 
@@ -1420,6 +1353,184 @@ __device__ __forceinline__ int resolve_bands(const int32_t* __restrict__ ids, in
     return L.nk;
 }
 
+// ---- the walk of a LARGE segment (column-major tiles): what chunk c needs is pulled, not pushed ------------------------------------------
+// resolve_bands pushes band ri's words forward into the masks of later chunks and reads them where the matrix kernel left them: 64 rows x
+// (T - ri) words strided by the band's width, requested two bands ahead - 1.4 us per band, 116 us for the 79 bands of the 5 000-box class
+// of one 608 x 608 image (its latency is the loaded words', not the 37 serial steps').  Here chunk c PULLS: removed(c) = OR over the kept
+// rows of every earlier band of that band's word for c - with column-major tiles ONE contiguous block of 64 c words, requested FOUR steps
+// ahead with coalesced loads (wavefronts 1-7: a thread's words of a block sit in four rotating register sets), masked with the earlier
+// chunks' kept masks (complete by then) and OR-ed into rem[c + 1] one step before wavefront 0 needs it; wavefront 0 only walks the
+// diagonal tiles (resolve_diag) and adds the one tile that depends on the chunk it has just resolved (band c -> chunk c + 1).
+// One barrier per step, no load on the serial path.  512 threads; NB words per thread and block: T <= 7 NB + 1 chunks.
+// Measured (one stream, HIP-event brackets, resolve launches of a step): 608 x 608 one image 116 -> 104 us, 416 x 416 one image 45 -> 34,
+// 608 x 608 bs 32 115 -> 102, 416 x 416 bs 32 45 -> 35.
+// OR of a 64-bit value over the wavefront (wave-uniform result): rotations inside the rows of 16 lanes (DPP row_ror 8 / 4 / 2 / 1), then the
+// four rows through readlane.  ~30 instructions; 64 lanes' atomicOr on ONE LDS word serialise to over a thousand cycles.
+__device__ __forceinline__ unsigned row_or16(unsigned v)
+{
+    v |= (unsigned)dpp_i<0x128>((int)v); v |= (unsigned)dpp_i<0x124>((int)v); v |= (unsigned)dpp_i<0x122>((int)v); v |= (unsigned)dpp_i<0x121>((int)v);
+    return v;
+}
+__device__ __forceinline__ u64 wave_or64(u64 v)
+{
+    const unsigned lo = row_or16((unsigned)(v & 0xffffffffu)), hi = row_or16((unsigned)(v >> 32));
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)lo, 0) | (unsigned)__builtin_amdgcn_readlane((int)lo, 16) |
+                       (unsigned)__builtin_amdgcn_readlane((int)lo, 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 48);
+    const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hi, 0) | (unsigned)__builtin_amdgcn_readlane((int)hi, 16) |
+                       (unsigned)__builtin_amdgcn_readlane((int)hi, 32) | (unsigned)__builtin_amdgcn_readlane((int)hi, 48);
+    return ((u64)h << 32) | (u64)l;
+}
+
+template <int NB>
+struct ColPre { ulonglong2 nb[NB / 2]; u64 diag, prev; };     // a thread's words of a block: NB / 2 pairs (16-byte loads)
+
+template <int NB>
+__device__ __forceinline__ void column_prefetch(ColPre<NB>& p, const u64* __restrict__ M, int T, int cc, int lane, int q)
+{
+    // EVERY thread issues the same NB / 2 + 2 loads, at clamped addresses, outside any branch: wavefront 0 does not use its block words, the
+    // others not their diagonal words, steps past the walk's end re-read the last column - the compiler can then count the loads in flight
+    // (s_waitcnt vmcnt(36 .. 51) where a step's words are used; with the loads inside `if (wave == 0) ... else ...` / `if (cc < T)` every
+    // join was a vmcnt(0)).  Measured on the 5 400-box class of one 608 x 608 image, in the order tried: first form 187 us; counted waits
+    // 187 (the wait was not the bound); 16-byte loads 133; one atomic per wavefront instead of one per lane (wave_or64) 104 - against 116
+    // for resolve_bands.  What is left is the block traffic itself: 1.85 MB of freshly written tiles through ONE CU.
+    cc = cc < T ? cc : T - 1;
+    p.diag = M[ctile_off(cc, cc) + lane];
+    p.prev = M[ctile_off(cc >= 1 ? cc - 1 : 0, cc) + lane];
+    // (16-byte loads, two words per lane; pairs past the block's end all read pair 0: one cache line per wavefront)
+    const int pairs = 32 * (cc - 1);                        // tiles ri <= cc - 2 of column cc: contiguous, 32 pairs each
+    const ulonglong2* blk = reinterpret_cast<const ulonglong2*>(M + ctile_off(0, cc));
+#pragma unroll
+    for (int u = 0; u < NB / 2; ++u) {
+        const int idx = q + 448 * u;
+        p.nb[u] = blk[(idx >= 0 && idx < pairs) ? idx : 0];
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ int resolve_columns(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                               int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform for the compiler too: the role branches below are scalar
+    const int T = (n + 63) >> 6;
+    const int q = tid - 64;                                 // wavefronts 1-7: 448 threads share a block's words
+    ColPre<NB> P0, P1, P2, P3;
+    column_prefetch<NB>(P0, M, T, 0, lane, q);
+    column_prefetch<NB>(P1, M, T, 1, lane, q);
+    column_prefetch<NB>(P2, M, T, 2, lane, q);
+    column_prefetch<NB>(P3, M, T, 3, lane, q);
+    __syncthreads();
+    int picked = 0;
+#ifdef YN_EXP_TIMING
+    long long t_work = 0, t_pre = 0, t_bar = 0, t_all0 = __builtin_readcyclecounter();
+#define YN_T0() long long tt0 = __builtin_readcyclecounter()
+#define YN_T1() long long tt1 = __builtin_readcyclecounter()
+#define YN_T2() long long tt2 = __builtin_readcyclecounter()
+#define YN_T3() { long long tt3 = __builtin_readcyclecounter(); t_work += tt1 - tt0; t_pre += tt2 - tt1; t_bar += tt3 - tt2; }
+#else
+#define YN_T0()
+#define YN_T1()
+#define YN_T2()
+#define YN_T3()
+#endif
+    // step c: wavefront 0 resolves chunk c (set P) and pushes tile (c, c + 1) (set PN.prev) into rem[c + 1]; the others apply the block of
+    // column c + 1 (set PN.nb: tiles ri <= c - 1, whose kept masks stand in rem[ri] since the barrier that ended step c - 1); P is then
+    // refilled with column c + 4.  The walk runs in whole rounds of four steps: steps past the last chunk only load.
+#define YN_COL(P, PN, c_)                                                                                    \
+    {                                                                                                        \
+        const int c = (c_);                                                                                  \
+        YN_T0();                                                                                             \
+        if (c < T) {                                                                                         \
+            if (wave == 0) {                                                                                 \
+                const u64 km = resolve_diag<true>(P.diag, 0, n, c, lane, picked, keep_flags, pick_list, L);  \
+                picked += __popcll(km);                                                                      \
+                if (c + 1 < T) {                             /* tile (c, c + 1) of the kept rows: one atomic, not one per lane */ \
+                    const u64 pv = ((km >> lane) & 1ull) ? PN.prev : 0ull;                                   \
+                    if (__ballot(pv != 0ull)) { const u64 r = wave_or64(pv); if (lane == 0) atomicOr(&L.rem[c + 1], r); } \
+                }                                                                                            \
+            } else if (c >= 1 && c + 1 < T) {                                                                \
+                const int pairs = 32 * c;                                                                    \
+                u64 any = 0;                                                                                 \
+                _Pragma("unroll") for (int u = 0; u < NB / 2; ++u) any |= (q + 448 * u < pairs) ? (PN.nb[u].x | PN.nb[u].y) : 0ull; \
+                if (__ballot(any != 0ull)) {                 /* (wave-uniform) most rows suppress nothing */  \
+                    u64 v = 0;                                                                               \
+                    _Pragma("unroll") for (int u = 0; u < NB / 2; ++u) {                                     \
+                        const int idx = 2 * (q + 448 * u);   /* word index of .x: row idx & 63 of tile idx >> 6 */ \
+                        if (idx < 2 * pairs) {                                                               \
+                            const u64 km = L.rem[idx >> 6];                                                  \
+                            if ((km >> (idx & 63)) & 1ull) v |= PN.nb[u].x;                                  \
+                            if ((km >> ((idx & 63) + 1)) & 1ull) v |= PN.nb[u].y;                            \
+                        }                                                                                    \
+                    }                                                                                        \
+                    if (__ballot(v != 0ull)) { const u64 r = wave_or64(v); if (lane == 0) atomicOr(&L.rem[c + 1], r); } \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+        YN_T1();                                                                                             \
+        column_prefetch<NB>(P, M, T, c + 4, lane, q);                                                        \
+        YN_T2();                                                                                             \
+        __syncthreads();                                                                                     \
+        YN_T3();                                                                                             \
+    }
+    for (int c0 = 0; c0 < T; c0 += 4) {
+        YN_COL(P0, P1, c0)
+        YN_COL(P1, P2, c0 + 1)
+        YN_COL(P2, P3, c0 + 2)
+        YN_COL(P3, P0, c0 + 3)
+    }
+#undef YN_COL
+#ifdef YN_EXP_TIMING
+    if ((tid == 0 || tid == 64) && T > 30)
+        printf("resolvecol n %d T %d wave %d work %lld prefetch %lld barrier %lld total %lld per step %lld\n", n, T, wave, t_work, t_pre, t_bar,
+               (long long)__builtin_readcyclecounter() - t_all0, ((long long)__builtin_readcyclecounter() - t_all0) / T);
+#endif
+    if (tid == 0) L.nk = picked;
+    __syncthreads();
+    // rem[c] now holds chunk c's kept mask: the keep flags / the pick list in one coalesced pass
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int ri = i >> 6, l = i & 63;
+        const u64 km = L.rem[ri];
+        if ((km >> l) & 1ull) {
+            const int id = ids[i];
+            if (keep_flags) keep_flags[id] = 1;
+            if (pick_list) pick_list[L.pbase[ri] + __popcll(km & ((1ull << l) - 1ull))] = id;
+        }
+    }
+    return L.nk;
+}
+
+// any T: the same pull without register staging (segments above 7 232 boxes: chunk c's block is read when it is needed)
+__device__ __forceinline__ int resolve_columns_unstaged(const int32_t* __restrict__ ids, int n, const u64* __restrict__ M,
+                                                        int32_t* __restrict__ keep_flags, int32_t* __restrict__ pick_list, ResolveLds& L)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int T = (n + 63) >> 6;
+    __syncthreads();
+    int picked = 0;
+    for (int c = 0; c < T; ++c) {
+        const u64* blk = M + ctile_off(0, c);
+        for (int idx = tid; idx < 64 * c; idx += nthr) {
+            const u64 w = blk[idx];
+            if (w && ((L.rem[idx >> 6] >> (idx & 63)) & 1ull)) atomicOr(&L.rem[c], w);
+        }
+        __syncthreads();
+        if (wave == 0) picked += __popcll(resolve_diag<true>(M[ctile_off(c, c) + lane], 0, n, c, lane, picked, keep_flags, pick_list, L));
+        __syncthreads();
+    }
+    if (tid == 0) L.nk = picked;
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) {
+        const int ri = i >> 6, l = i & 63;
+        const u64 km = L.rem[ri];
+        if ((km >> l) & 1ull) {
+            const int id = ids[i];
+            if (keep_flags) keep_flags[id] = 1;
+            if (pick_list) pick_list[L.pbase[ri] + __popcll(km & ((1ull << l) - 1ull))] = id;
+        }
+    }
+    return L.nk;
+}
+
 // MODE selects the staged walks a kernel instantiates (its register count is the largest one's): 0 = 256 threads, T <= 17 only
 // (resolve_kernel: segments up to 1 024 boxes); 1 = 512 threads, eight per matrix row, up to 129 chunks (resolve_large_kernel); 2 = 256
 // threads, up to 65 chunks (single_resolve_kernel).  Anything larger takes the unstaged loop below.
@@ -1438,10 +1549,14 @@ __device__ __forceinline__ int resolve_segment(const int32_t* __restrict__ ids, 
         if (T <= 33) return resolve_bands<8>(ids, n, M, keep_flags, pick_list, L);
         if (T <= 65) return resolve_bands<16>(ids, n, M, keep_flags, pick_list, L);
     }
-    if (MODE == 1 && nthr == 512) {                         // eight threads per matrix row: 129 chunks (8 256 boxes) in the staged walk
-        if (T <= 33) return resolve_bands<4, 8>(ids, n, M, keep_flags, pick_list, L);
-        if (T <= 65) return resolve_bands<8, 8>(ids, n, M, keep_flags, pick_list, L);
-        if (T <= 129) return resolve_bands<16, 8>(ids, n, M, keep_flags, pick_list, L);
+    if (MODE == 1 && nthr == 512) {
+        if (nms_colmajor(n)) {                              // above YN_SORT_SMALL boxes: column-major tiles, the pulling walk
+            if (T <= 29) return resolve_columns<4>(ids, n, M, keep_flags, pick_list, L);
+            if (T <= 57) return resolve_columns<8>(ids, n, M, keep_flags, pick_list, L);
+            if (T <= 113) return resolve_columns<16>(ids, n, M, keep_flags, pick_list, L);
+            return resolve_columns_unstaged(ids, n, M, keep_flags, pick_list, L);
+        }
+        return resolve_bands<4, 8>(ids, n, M, keep_flags, pick_list, L);       // (few-segment batches: the small segments ride along; T <= 17)
     }
     // very large segments (n > 4160): no register staging, the kept rows' words are read when they are needed
     u64 diag_next = 0;
@@ -1493,69 +1608,6 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int32_t* __restrict_
                     M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
 
-// ---- parallel resolve of the large segments of a few-segment batch ------------------------------------------------------------------
-// The band walk is a serial chain of T = n / 64 steps of ~1.4 us (79 steps for the 5 000-box class of one 608 x 608 image: 116 us of its
-// 690) on ONE workgroup while the chip idles.  The kept set is the unique solution of  keep[t] = not OR_{j < t} (keep[j] and M[j][t])
-// (induction on t), so it can also be reached by iterating  R_it = OR over the rows kept under R_{it-1} of their words,  keep = valid & ~R,
-// from R_0 = 0: R_1 >= R_3 >= ... >= R_true >= ... >= R_4 >= R_2, and the first R_it == R_{it-1} IS the fixed point - exact, not an
-// approximation.  Each iteration is one chip-wide pass over the segment's matrix (wavefront = one band; lane = one word of the band's rows,
-// the 64 rows streamed through it with unconditional, coalesced loads) ending in atomic ORs into the next mask; YN_NMS_ITER_K iterations
-// are launched, each exits at once when an earlier one has reached the fixed point; the depth of random boxes' suppression chains is 4-8.
-// resolve_large_kernel takes the fixed point when one was reached, else falls back to the band walk (adversarial chains of boxes).
-// grid (ceil(iter_T / 4), slots, B), 256 threads.  masks: [YN_NMS_ITER_K + 1][B][slot_cap][iter_T].
-__global__ __launch_bounds__(256) void resolve_iter_kernel(int it, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ tile_off,
-                                                           int C, const u64* __restrict__ M, size_t m_stride,
-                                                           const int32_t* __restrict__ slot_list, int slot_cap, u64* __restrict__ iter,
-                                                           int32_t* __restrict__ iter_last, int iter_T)
-{
-    const int b = blockIdx.z, slot = blockIdx.y;
-    if (slot >= slot_list[(size_t)b * (slot_cap + 1)]) return;
-    const int c = slot_list[(size_t)b * (slot_cap + 1) + 1 + slot];
-    const int n = seg_count[(size_t)b * C + c];
-    const int T = (n + 63) >> 6;
-    if ((int)blockIdx.x * 4 >= T || n <= 64) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t per_it = (size_t)gridDim.z * slot_cap * iter_T;
-    u64* base = iter + ((size_t)b * slot_cap + slot) * iter_T;
-    const u64* Rprev = base + (size_t)(it - 1) * per_it;
-    u64* Rcur = base + (size_t)it * per_it;
-    if (iter_last[(size_t)b * slot_cap + slot] < it - 1) return;         // an earlier iteration stopped at the fixed point
-    if (it >= 2) {
-        const u64* Rpp = base + (size_t)(it - 2) * per_it;
-        int diff = 0;
-        for (int w = tid; w < T; w += 256) diff |= Rprev[w] != Rpp[w] ? 1 : 0;
-        if (!__syncthreads_or(diff)) return;                              // R_{it-1} == R_{it-2}: the fixed point; iter_last stays it - 1
-    }
-    if (blockIdx.x == 0 && tid == 0) iter_last[(size_t)b * slot_cap + slot] = it;
-    if (it < YN_NMS_ITER_K) {                                             // the next iteration's target mask: this workgroup's four chunks
-        u64* Rnext = base + (size_t)(it + 1) * per_it;
-        if (tid < 4 && (int)blockIdx.x * 4 + tid < T) Rnext[blockIdx.x * 4 + tid] = 0ull;
-    }
-    const int ri = blockIdx.x * 4 + wave;
-    if (ri >= T) return;
-    const u64* Ms = M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64;
-    const int cnt = min(64, n - ri * 64);
-    const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-    const u64 kprev = valid & ~Rprev[ri];                                 // rows of this band kept under the previous mask (wave-uniform)
-    if (kprev == 0ull) return;
-    const int W = T - ri;
-    const size_t boff = band_off(ri, T);
-    for (int w0 = 0; w0 < W; w0 += 64) {
-        const int wl = w0 + lane;
-        const int wc = wl < W ? wl : W - 1;                               // clamped column: ignored below
-        u64 acc = 0ull;
-#pragma unroll 1
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            u64 v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = Ms[boff + (size_t)(r0 + u) * W + wc];     // all 16 rows' loads in flight
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc |= v[u] & (0ull - ((kprev >> (r0 + u)) & 1ull));
-        }
-        if (wl < W && acc) atomicOr(&Rcur[ri + wl], acc);
-    }
-}
-
 // The segments of bucket_kernel's large list (more than 1 024 boxes before the prefilter) that still hold more than YN_SORT_SMALL boxes:
 // ONE launch of 512-thread workgroups, eight threads per matrix row, so that the few long walks of an image run side by side (a
 // 256-thread walk up to 65 chunks followed by a second kernel for the larger ones ran the two longest walks of a 608 x 608 image one
@@ -1564,9 +1616,7 @@ __global__ __launch_bounds__(256) void resolve_iter_kernel(int it, const int32_t
 __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                              const int32_t* __restrict__ tile_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, const u64* __restrict__ M, size_t m_stride, int32_t* __restrict__ keep,
-                                                             const int32_t* __restrict__ large_list, int large_cap, int n_min,
-                                                             const int32_t* __restrict__ seg_slot, const u64* __restrict__ iter,
-                                                             const int32_t* __restrict__ iter_last, int iter_T)
+                                                             const int32_t* __restrict__ large_list, int large_cap, int n_min)
 {
     __shared__ ResolveLds L;
     const int b = blockIdx.y;
@@ -1578,24 +1628,6 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
     }
     const int n = seg_count[(size_t)b * C + c];
     if (n <= n_min) return;
-    if (seg_slot) {                                         // a segment of the parallel resolve: take its fixed point if one was reached
-        const int slot = seg_slot[(size_t)b * C + c];
-        const int k = slot >= 0 ? iter_last[(size_t)b * large_cap + slot] : 0;
-        if (slot >= 0 && k >= 1 && n > 64) {
-            const int T = (n + 63) >> 6;
-            const size_t per_it = (size_t)gridDim.y * large_cap * iter_T;
-            const u64* Rk = iter + ((size_t)b * large_cap + slot) * iter_T + (size_t)k * per_it;
-            const u64* Rp = Rk - per_it;
-            int diff = 0;
-            for (int w = threadIdx.x; w < T; w += 512) diff |= Rk[w] != Rp[w] ? 1 : 0;
-            if (!__syncthreads_or(diff)) {                  // (block-uniform)
-                const int32_t* ids = bucket + (size_t)b * N + seg_off[(size_t)b * C + c];
-                for (int i = threadIdx.x; i < n; i += 512)
-                    if (!((Rk[i >> 6] >> (i & 63)) & 1ull)) keep[(size_t)b * N + ids[i]] = 1;
-                return;
-            }
-        }
-    }
     resolve_segment<1>(bucket + (size_t)b * N + seg_off[(size_t)b * C + c], n,
                        M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64, keep + (size_t)b * N, nullptr, L);
 }
@@ -1902,28 +1934,14 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     u64* M = reinterpret_cast<u64*>(wk.matrix);
     static const int fuse_bs = getenv("YN_NMS_FUSE_BUCKET") ? atoi(getenv("YN_NMS_FUSE_BUCKET")) : 1;       // A/B: 0 = bucket_kernel + sort_kernel also for few segments
     const bool few = (long)B * C <= 256;
-    // few segments: the large ones resolve by chip-wide fixed-point iterations instead of one workgroup's band walk (YN_NMS_ITER=0: off)
-    static const int iter_env = getenv("YN_NMS_ITER") ? atoi(getenv("YN_NMS_ITER")) : 1;
-    const int iT = (N + 63) / 64;
-    const bool iter_on = few && fuse_bs && iter_env && wk.ctr && wk.iter && wk.iter_last && wk.seg_slot && wk.large_list && large_cap > 0 && N > YN_NMS_ITER_MIN &&
-                         iT <= wk.iter_T && !(skip & 1);
     const int32_t* seg_order = wk.seg_order;                // bucket_kernel's size ranking; the fused kernel does not produce one (few segments: nothing to order)
     if (few && fuse_bs && wk.ctr && !(skip & 1)) {
         seg_order = nullptr;
         static unsigned long long attr_bs = 0;
         if (attr_pending(attr_bs)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SORT_LARGE * 8);
         mark("bucket_sort_kernel");
-        // segments above rank_min boxes: collected by bucket_sort_kernel, ordered by rank_sort_kernel over the whole chip (YN_NMS_RANK_MIN=0: never)
-        static const int rank_env = getenv("YN_NMS_RANK_MIN") ? atoi(getenv("YN_NMS_RANK_MIN")) : 1024;
-        const bool by_rank = rank_env > 0 && N > rank_env && wk.bucket2 != nullptr;
         hipLaunchKernelGGL(bucket_sort_kernel, dim3(C, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket,
-                           wk.keep, sbox, M, wk.matrix_stride, wk.ctr, by_rank ? wk.bucket2 : (int32_t*)nullptr, rank_env,
-                           iter_on ? wk.seg_slot : (int32_t*)nullptr, wk.large_list, large_cap, iter_on ? reinterpret_cast<u64*>(wk.iter) : (u64*)nullptr, wk.iter_last, iT);
-        if (by_rank) {
-            mark("rank_sort_kernel");
-            hipLaunchKernelGGL(rank_sort_kernel, dim3((N + 63) / 64, C, B), dim3(256), 0, s, boxes, wk.seg_count, wk.seg_off, wk.bucket2, (const u64*)M, wk.matrix_stride,
-                               wk.bucket, sbox, N, C, rank_env);
-        }
+                           wk.keep, sbox, M, wk.matrix_stride, wk.ctr);
     } else {
     mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
@@ -1972,21 +1990,13 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     if (!(skip & 4) && (long)B * C <= 256) {
         // few segments (bs <= 3 at 80 classes): all of them on the 512-thread kernel in ONE launch — the short walks ride along with the long
         // ones instead of preceding them (one image: -20 us)
-        if (iter_on) {
-            mark("resolve_iter_kernel");
-            for (int it = 1; it <= YN_NMS_ITER_K; ++it)
-                hipLaunchKernelGGL(resolve_iter_kernel, dim3((iT + 3) / 4, large_cap, B), dim3(256), 0, s, it, m_count, m_toff, C, (const u64*)M, wk.matrix_stride,
-                                   (const int32_t*)wk.large_list, large_cap, reinterpret_cast<u64*>(wk.iter), wk.iter_last, iT);
-            mark("resolve_kernel");
-        }
         hipLaunchKernelGGL(resolve_large_kernel, dim3(C, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
-                           wk.keep, (const int32_t*)nullptr, iter_on ? large_cap : 0, 0, iter_on ? (const int32_t*)wk.seg_slot : (const int32_t*)nullptr,
-                           (const u64*)wk.iter, (const int32_t*)wk.iter_last, iT);
+                           wk.keep, (const int32_t*)nullptr, 0, 0);
     } else if (!(skip & 4)) {
         hipLaunchKernelGGL(resolve_kernel, dim3(B, C), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
                            split ? YN_SORT_SMALL : 1 << 30, seg_order);
         if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
-                                      wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL, (const int32_t*)nullptr, (const u64*)nullptr, (const int32_t*)nullptr, 0);
+                                      wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
     mark("compact_kernel");
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count, wk.ovf);

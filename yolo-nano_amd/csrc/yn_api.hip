@@ -97,7 +97,6 @@ struct yn_handle {
     size_t nms_cap = 0;           // elements B*N currently allocated
     size_t nms_seg_cap = 0;       // B*(C+1)
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
-    size_t nms_iter_cap = 0;      // uint64 words of the parallel resolve's mask sequence
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
     float* fwd_only[3] = {nullptr, nullptr, nullptr};     // yn_train_forward: the training executors stop after the forward pass and copy the raw heads here
@@ -363,10 +362,8 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_order, need_seg * sizeof(int32_t)));
-        HIPCHK(h, hipMalloc((void**)&h->nms.ctr, (need_seg + 4 * (size_t)B) * sizeof(int32_t)));          // >= 3 * B ints
-        HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, (need_seg + 4 * (size_t)B) * sizeof(int32_t), h->stream));
-        if (h->nms.seg_slot) { HIPCHK(h, hipFree(h->nms.seg_slot)); h->nms.seg_slot = nullptr; }
-        HIPCHK(h, hipMalloc((void**)&h->nms.seg_slot, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.ctr, need_seg * sizeof(int32_t)));          // >= 2 * B ints
+        HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, need_seg * sizeof(int32_t), h->stream));
         h->nms_seg_cap = need_seg;
         drop_graphs(h);
     }
@@ -379,21 +376,6 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     }
     h->nms.matrix_stride = m_stride;
     h->nms.large_cap = (N / 1024 + 1) < C ? (N / 1024 + 1) : C;       // at most N/1024 segments can exceed 1024 items
-    // the parallel resolve of the large segments of a few-segment batch (one to three images): its removed-mask sequence
-    if ((long)B * C <= 256) {
-        const size_t cap = (size_t)(N / 1024 + 1), T = (size_t)(N + 63) / 64;
-        const size_t need_it = (size_t)(YN_NMS_ITER_K + 1) * B * cap * T;
-        if (need_it > h->nms_iter_cap) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (h->nms.iter) { HIPCHK(h, hipFree(h->nms.iter)); h->nms.iter = nullptr; }
-            if (h->nms.iter_last) { HIPCHK(h, hipFree(h->nms.iter_last)); h->nms.iter_last = nullptr; }
-            HIPCHK(h, hipMalloc(&h->nms.iter, need_it * sizeof(unsigned long long)));
-            HIPCHK(h, hipMalloc((void**)&h->nms.iter_last, (size_t)B * cap * sizeof(int32_t)));
-            h->nms_iter_cap = need_it;
-            drop_graphs(h);
-        }
-        h->nms.iter_T = (int)T;
-    }
     return 0;
 }
 
@@ -1240,7 +1222,7 @@ void yn_destroy(yn_handle* h)
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
-                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr, h->nms.iter, h->nms.iter_last, h->nms.seg_slot};
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);

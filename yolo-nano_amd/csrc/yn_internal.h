@@ -159,16 +159,9 @@ struct NmsWork {                                // per-handle scratch, sized for
     int32_t* ctr;                               // [B][2]  bucket_sort_kernel's position cursor / finished-workgroup count (zero between launches)
     int      prefilter;                         // 0 off, 1 for batches of >= 4 images, 2 always
     int      large_cap;
-    void*    iter;                              // few-segment batches (B * C <= 256): removed-mask sequence of the parallel resolve (resolve_iter_kernel),
-                                                // uint64 [YN_NMS_ITER_K + 1][B][large_cap][iter_T]; null: not allocated
-    int32_t* iter_last;                         // [B][large_cap]  last iteration that ran for the slot
-    int32_t* seg_slot;                          // [B][C]  slot of a segment above YN_NMS_ITER_MIN boxes, else -1
-    int      iter_T;                            // words per slot (ceil(N / 64) of the allocation)
     const unsigned* ovf;                        // yn_infer: the split-f16 range flag of the network kernels that produced the candidates, or null.
                                                 // Set => compact_kernel reports count[b] = -1 - kept (the results are invalid: yn_range_status)
 };
-#define YN_NMS_ITER_K 12                        // iterations launched per call (each exits at once after the fixed point is reached)
-#define YN_NMS_ITER_MIN 2048                    // smallest segment that takes the parallel resolve
 size_t nms_matrix_words_per_image(int N, int C);
 int nms_max_segment();                      // largest per-class segment resolve_segment() can hold (its removed-mask lives in LDS)
 // optional per-kernel hook of launch_nms_pipeline: called with the kernel's name right before each launch (profiling brackets)
