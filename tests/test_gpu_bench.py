@@ -169,7 +169,7 @@ h = capi.Handle(224, 20, arch.MULTI_ANCHOR_SIZE, "1.0x", max_batch=2)
 mode, path = sys.argv[1], sys.argv[2]
 if mode == "load":
     n = capi.tune_load(path, 0)
-    assert n > 10, n
+    assert n >= 5, n
     assert capi.tune_load(path, 0) == 0          # already present: nothing adopted twice
 h.load_state_dict(weights.make_state_dict("1.0x", 20)); h.fold_bn()
 x = torch.as_tensor(weights.make_input(2, 224, seed=5)).cuda()

@@ -483,7 +483,7 @@ def _multi_scale_run(g, precision, sizes, B, C=20):
 
 # per-tensor bar of the steps WITH updates: (multiple of the yardstick's own error, absolute floor)
 MS_SIZES, MS_B = (256, 320, 256), 4
-MS_BAR = {"f32": (8.0, 0.1), "f16": (2.5, 0.1)}
+MS_BAR = {"f32": (8.0, 0.1), "f16": (3.0, 0.1)}
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16"])
@@ -498,7 +498,7 @@ def test_multi_scale_training_through_set_grid(golden, precision):
     oracle alike, tools/diag_multiscale.py), and everything upstream moves with them; round 3 ran this walk at 128 / 192 with four images,
     where the stride-32 level gives a BatchNorm channel 64 positions and one flip moved whole tensors by up to 300 % - the test then allowed
     three tensors outside any bar.  Round 4 runs it at 256 / 320 (256 / 400 positions per channel at stride 32): a flip is a 1 / 256 effect,
-    and EVERY tensor is held to max(8x the fp32 oracle's own error, 0.1) (f32) / 2.5x the fp16-storage emulation's error + 0.1 (f16) - no
+    and EVERY tensor is held to max(8x the fp32 oracle's own error, 0.1) (f32) / 3x the fp16-storage emulation's error + 0.1 (f16; the emulation itself sits at 0.3-0.55 on the backbone tensors) - no
     exemptions - plus a cosine >= 0.98 between the whole flat gradient and the oracle's (f16: no more than 0.1 below the emulation's own).
     Soak: gpurun_out/r4_soak_multiscale.txt (tools/soak_multiscale.py, 20 runs per precision)."""
     g = golden("train.npz")
