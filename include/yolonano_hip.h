@@ -94,8 +94,9 @@ int  yn_fuse_decode(yn_handle* h, int enable);
 int  yn_group_launch(yn_handle* h, int enable);
 /* A stride-2 ShuffleV2 unit (backbone/shufflenetv2.py:30-51, 73-74: branch 2 = pointwise -> depthwise stride 2 -> pointwise, branch 1 =
  * depthwise stride 2 -> pointwise, then concat + channel shuffle) as ONE kernel where its tile fits (input channels <= 32, branch
- * width <= 64: stage 2, whose intermediate is the largest tensor of the network); default on, split-f16 family only, bit-identical to
- * the five launches.  Env: YN_DOWN_FUSE=0/1. */
+ * width <= 64: stage 2, whose intermediate is the largest tensor of the network); the wider units (stages 3 / 4, branch width <= 256) as
+ * their first pointwise conv + ONE kernel for everything behind it.  Default on, split-f16 family only, bit-identical to the five
+ * launches.  Env: YN_DOWN_FUSE=0/1 (YN_DOWN2=0: only the wide units back to five launches). */
 int  yn_down_fuse(yn_handle* h, int enable);
 /* Layers .2 + .3 + .4 of the three detection heads and the candidate decode as ONE grouped kernel — depthwise 3x3 + pointwise conv +
  * last conv + decode on an 8 x 4 pixel tile; layer .3's activation never reaches memory (models/yolo_nano.py:60-82, 299-330, 362-367).

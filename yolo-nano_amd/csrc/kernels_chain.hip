@@ -636,18 +636,19 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
 #ifndef YN_UC2_OCC_NARROW
 #define YN_UC2_OCC_NARROW 3                                 // workgroups per CU the 58-channel (stage 2) instantiation is compiled for
 #endif
-template <int WM, int WN, int NT, int V, int KC>
+#ifndef YN_UC2_TWO_WINDOWS
+#define YN_UC2_TWO_WINDOWS 1
+#endif
+template <int WM, int WN, int NT, int V, int D>             // D: 16-deep k-steps of weight fragments in flight per wavefront
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V == 2) ? YN_UC2_OCC_NARROW : 2))) void unit_chain2_kernel(ChainArgs a)
 {
     typedef typename VecT<V>::type vec;
-    constexpr int BM = 32 * WM, BN = 32 * NT * WN, OQ = KC / 8, NTHR = 64 * WM * WN;
-    constexpr int B_PER = (2 * OQ * BN + NTHR - 1) / NTHR;
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
     extern __shared__ __attribute__((aligned(16))) float uc2_smem[];
     const int bf = a.bf, W = a.W, H = a.H, HW = H * W;
-    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, nchunks = (bf + KC - 1) / KC;
+    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, S = (KQ + 1) >> 1;     // S: 16-deep k-steps of a GEMM
     uch16* Ph = reinterpret_cast<uch16*>(uc2_smem);                     // [BM][PS]
     uch16* Pl = Ph + BM * PS;
-    uch16* Bh = Pl + BM * PS;                                           // [OQ][BN][8], then the lo plane
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
@@ -662,29 +663,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
 #define YN_TS()
 #endif
     YN_TS();
-    uch16x8 b_reg[B_PER];
-    auto prefetch_b = [&](const void* Wh, const void* Wl, int c) {
+    // Round 4: the GEMM weights never pass through LDS (down2_kernel's finding): a lane's B fragment of a k-step is 16 contiguous bytes
+    // of the pre-split pack, so every wavefront streams the fragments of ITS columns straight from L2 into registers, D k-steps ahead - no
+    // chunk barriers, no staging pass, half the LDS (the first form walked K in chunks of 64 through LDS: two barrier rounds of ~2 k
+    // cycles per GEMM whatever they multiplied, and a 2.3 k staging pass between the GEMMs).  Same k order (16-deep steps in sequence):
+    // the same bits.
+    uch16x8 bq[D][NT][2];
+    auto load_b = [&](const void* Wh_, const void* Wl_, int s, uch16x8 (&dst)[NT][2]) {
+        const uch16* Wh = reinterpret_cast<const uch16*>(Wh_);
+        const uch16* Wl = reinterpret_cast<const uch16*>(Wl_);
+        const int kq = s * 2 + h;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int g = t + NTHR * i;
-            const int pl = g / (OQ * BN), r = g - pl * (OQ * BN);
-            const int o = r / BN, n = r - o * BN;
-            const int kq = c * OQ + o;
-            const bool ok = g < 2 * OQ * BN && kq < KQ && n < a.Npad;
-            uch16x8 v = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(pl ? Wl : Wh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8);
-            if (!ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (uch16)0.0f;
-            }
-            b_reg[i] = v;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = wn * NT * 32 + nt * 32 + l31;
+            const bool ok = s < S && kq < KQ && n < a.Npad;
+            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
+            const unsigned mk = opaque_mask(ok);
+            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
+            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
+            dst[nt][0] = *reinterpret_cast<uch16x8*>(&vh);
+            dst[nt][1] = *reinterpret_cast<uch16x8*>(&vl);
         }
     };
-    auto stage_b = [&]() {
+    auto prime_b = [&](const void* Wh, const void* Wl) {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int g = t + NTHR * i;
-            if (g < 2 * OQ * BN) *reinterpret_cast<uch16x8*>(Bh + (size_t)g * 8) = b_reg[i];
-        }
+        for (int j = 0; j < D; ++j) load_b(Wh, Wl, j, bq[j]);
     };
     float amax = 0.0f;                                                   // range guard (yn_device.h)
     auto split_store = [&](int r, int c, float v0, float v1) {           // two adjacent channels of row r -> both planes
@@ -773,20 +776,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
                 if (++x == W) { x = 0; if (++y == H) y = 0; }
             }
         };
-        vec win[3][R + 2];
         const int nruns = (nrows + R - 1) / R;
-        if (worker && pl < nruns) issue(pl, win);
-        prefetch_b(a.Ws2h, a.Ws2l, 0);
-        stage_b();
-        if (worker) {
-            for (int run = pl; run < nruns; run += ppl) {
-                finish(run, win);
-                if (run + ppl < nruns) issue(run + ppl, win);
+        if constexpr (!YN_UC2_TWO_WINDOWS) prime_b(a.Ws2h, a.Ws2l);     // (requested before the windows: they return first)
+        if constexpr (YN_UC2_TWO_WINDOWS) {
+            // both windows of a thread in flight at once (a 64-row tile is two runs per thread): one memory round trip for the whole
+            // depthwise phase instead of two.  The registers are there since the weights stopped passing through b_reg + LDS.
+            vec win0[3][R + 2], win1[3][R + 2];
+            if (worker) {
+                for (int run = pl; run < nruns; run += 2 * ppl) {
+                    issue(run, win0);
+                    if (run + ppl < nruns) issue(run + ppl, win1);
+                    finish(run, win0);
+                    if (run + ppl < nruns) finish(run + ppl, win1);
+                }
+            }
+            prime_b(a.Ws2h, a.Ws2l);                        // (after the windows: 144 window registers and the fragments do not fit side by side)
+        } else {
+            vec win[3][R + 2];
+            if (worker && pl < nruns) issue(pl, win);
+            if (worker) {
+                for (int run = pl; run < nruns; run += ppl) {
+                    finish(run, win);
+                    if (run + ppl < nruns) issue(run + ppl, win);
+                }
             }
         }
         // requested only now: the window registers are free again, and these loads (x1 is a quarter of the unit's traffic) fly during
         // the first GEMM, when the memory system would otherwise sit idle
-        if (nchunks > 1) prefetch_b(a.Ws2h, a.Ws2l, 1);
         x1_prefetch();
         // K tail: the columns [bf, PS) of both planes are zero (they meet zero weight rows, but must not be NaN bit patterns)
         const int padn = PS - bf;
@@ -796,36 +812,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
     YN_TS();
 
     f32x16 acc0[NT], acc1[NT];
-    // entry state: chunk 0 staged (visible), chunk 1 requested into b_reg
+    // entry state: the fragments of steps 0 .. D-1 of this matrix are in flight (prime_b).  Steps past the last one (at most D - 1 of them)
+    // multiply a valid A fragment by zero weights: exact zeros, no branch around the loads
     auto gemm = [&](const void* Wh, const void* Wl) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
-        for (int c = 0; c < nchunks; ++c) {
-            const uch16* Ahb = Ph + (wm * 32 + l31) * PS + c * KC + h * 8;
-            const uch16* Alb = Pl + (wm * 32 + l31) * PS + c * KC + h * 8;
-            const uch16* Bhb = Bh + (size_t)(h * BN + wn * NT * 32 + l31) * 8;
-            const uch16* Blb = Bhb + OQ * BN * 8;
+        for (int s0 = 0; s0 < S; s0 += D) {
 #pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks) {
-                if (c * OQ + ks * 2 >= KQ) break;                       // wave-uniform: this 16-deep step lies beyond the (zero-padded) K
-                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
-                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+            for (int j = 0; j < D; ++j) {
+                const int s = s0 + j;
+                const int ks = s < S ? s : S - 1;
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ph + (wm * 32 + l31) * PS + ks * 16 + h * 8);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Pl + (wm * 32 + l31) * PS + ks * 16 + h * 8);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const uch16x8 bh = *reinterpret_cast<const uch16x8*>(Bhb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                    const uch16x8 bl = *reinterpret_cast<const uch16x8*>(Blb + (size_t)(ks * 2 * BN + nt * 32) * 8);
-                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][1], acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[j][nt][0], acc1[nt], 0, 0, 0);
                 }
-            }
-            if (c + 1 < nchunks) {
-                __syncthreads();                                        // every wave is done with this chunk's weights
-                stage_b();
-                __syncthreads();
-                if (c + 2 < nchunks) prefetch_b(Wh, Wl, c + 2);
+                load_b(Wh, Wl, s + D, bq[j]);                   // (masked to zeros beyond the last step)
             }
         }
 #pragma unroll
@@ -835,8 +842,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
     };
     gemm(a.Ws2h, a.Ws2l);
     YN_TS();
-    if (a.Wp1n) prefetch_b(a.Ws1h, a.Ws1l, 0);
-    __syncthreads();                                                    // all waves are done reading the planes and the weights
+    if (a.Wp1n) prime_b(a.Ws1h, a.Ws1l);                               // the next GEMM's first fragments fly during the epilogue
+    __syncthreads();                                                    // all waves are done reading the planes
 #ifdef YN_EXP_TIMING
     const long long t_bar = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -888,8 +895,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
     }
     YN_TS();
     if (last) { range_report(a.ovf, amax); return; }
-    stage_b();
-    if (nchunks > 1) prefetch_b(a.Ws1h, a.Ws1l, 1);
     __syncthreads();
 
     // ---- 3. the next unit's pw1 on x2' -> global -------------------------------------------------------------------------------
@@ -909,10 +914,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
 #undef YN_TS
 }
 
-static size_t unit_chain2_lds(int bf, int BM, int BN, int KC)
+static size_t unit_chain2_lds(int bf, int BM)
 {
     const int PS = ((bf + 7) / 8) * 8 + 8;
-    return ((size_t)2 * BM * PS + (size_t)2 * (KC / 8) * BN * 8) * 2;
+    return (size_t)2 * BM * PS * 2;                          // the two operand planes; the weights go through registers
 }
 
 static size_t unit_chain_split_lds(int bf, int BM, int BN)
@@ -960,7 +965,7 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
 #define YN_UC2(WMv, WNv, NTv, Vv, KCv)                                                                                 \
     {                                                                                                                  \
         constexpr int BM = 32 * WMv, BN = 32 * NTv * WNv;                                                              \
-        const size_t lds = unit_chain2_lds(a.bf, BM, BN, KCv);                                                         \
+        const size_t lds = unit_chain2_lds(a.bf, BM);                                                                  \
         if (lds > 160 * 1024) return false;                                                                            \
         if (dry) return true;                                                                                          \
         static unsigned long long attr = 0;                                                                            \
@@ -972,16 +977,16 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
     }
     static const int chain_v = getenv("YN_CHAIN_V") ? atoi(getenv("YN_CHAIN_V")) : 2;      // 1: the round-2 kernel (A/B runs); 2: unit_chain2_kernel
     if (a.Ws2h && chain_v >= 2) {
-        if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 64)
-        if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 64)
+        if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 4)
+        if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 4)
         // small maps (one image): 32-row tiles - twice the workgroups, and a workgroup's serial chain (one depthwise round instead of two,
         // half the epilogue rows) is what a launch of a few dozen workgroups costs
         static const int small_m = getenv("YN_CHAIN_SMALL_M") ? atoi(getenv("YN_CHAIN_SMALL_M")) : 4096;
-        if (a.Npad == 128 && v4 && a.M <= small_m) YN_UC2(1, 4, 1, 4, 64)
-        if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 64)
-        if (a.Npad == 256 && v4) YN_UC2(1, 4, 2, 4, 32)          // 32-row tiles, four wavefronts x 64 columns (NT = 4 would need 128 accumulator + 64 pass-through registers)
-        if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 32)
-        if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 32)
+        if (a.Npad == 128 && v4 && a.M <= small_m) YN_UC2(1, 4, 1, 4, 4)
+        if (a.Npad == 128 && v4) YN_UC2(2, 2, 2, 4, 3)
+        if (a.Npad == 256 && v4) YN_UC2(1, 4, 2, 4, 3)          // 32-row tiles, four wavefronts x 64 columns (NT = 4 would need 128 accumulator + 64 pass-through registers)
+        if (a.Npad == 32 && v4) YN_UC2(4, 1, 1, 4, 4)
+        if (a.Npad == 96 && v4) YN_UC2(4, 1, 3, 4, 2)
         return false;
     }
 #undef YN_UC2
