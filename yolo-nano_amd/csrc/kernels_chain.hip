@@ -636,9 +636,6 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
 #ifndef YN_UC2_OCC_NARROW
 #define YN_UC2_OCC_NARROW 3                                 // workgroups per CU the 58-channel (stage 2) instantiation is compiled for
 #endif
-#ifndef YN_UC2_TWO_WINDOWS
-#define YN_UC2_TWO_WINDOWS 1
-#endif
 template <int WM, int WN, int NT, int V, int D>             // D: 16-deep k-steps of weight fragments in flight per wavefront
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V == 2) ? YN_UC2_OCC_NARROW : 2))) void unit_chain2_kernel(ChainArgs a)
 {
@@ -777,28 +774,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
             }
         };
         const int nruns = (nrows + R - 1) / R;
-        if constexpr (!YN_UC2_TWO_WINDOWS) prime_b(a.Ws2h, a.Ws2l);     // (requested before the windows: they return first)
-        if constexpr (YN_UC2_TWO_WINDOWS) {
-            // both windows of a thread in flight at once (a 64-row tile is two runs per thread): one memory round trip for the whole
-            // depthwise phase instead of two.  The registers are there since the weights stopped passing through b_reg + LDS.
-            vec win0[3][R + 2], win1[3][R + 2];
-            if (worker) {
-                for (int run = pl; run < nruns; run += 2 * ppl) {
-                    issue(run, win0);
-                    if (run + ppl < nruns) issue(run + ppl, win1);
-                    finish(run, win0);
-                    if (run + ppl < nruns) finish(run + ppl, win1);
-                }
-            }
-            prime_b(a.Ws2h, a.Ws2l);                        // (after the windows: 144 window registers and the fragments do not fit side by side)
-        } else {
-            vec win[3][R + 2];
-            if (worker && pl < nruns) issue(pl, win);
-            if (worker) {
-                for (int run = pl; run < nruns; run += ppl) {
-                    finish(run, win);
-                    if (run + ppl < nruns) issue(run + ppl, win);
-                }
+        prime_b(a.Ws2h, a.Ws2l);                            // (requested before the windows: they return first)
+        // (both windows of a thread in flight at once - the registers are there since the weights stopped passing through LDS - measured
+        //  the same: 24.5 vs 25.1 us per stage-3 unit, 40.8 vs 41.2 k images/s; one window keeps the kernel at 203 registers)
+        vec win[3][R + 2];
+        if (worker && pl < nruns) issue(pl, win);
+        if (worker) {
+            for (int run = pl; run < nruns; run += ppl) {
+                finish(run, win);
+                if (run + ppl < nruns) issue(run + ppl, win);
             }
         }
         // requested only now: the window registers are free again, and these loads (x1 is a quarter of the unit's traffic) fly during

@@ -856,11 +856,11 @@ int run_network(yn_handle* h, const float* x, int B, float* const heads[3], int 
                                    ldw.stride == 2 && ldw.cout == bf && l1d.stride == 2 && l1d.cout == curC && l1p.cin == curC && l1p.cout == bf && l1p.Npad == lp2.Npad &&
                                    down2_covers(d2);
             // when the stride-1 units behind it run as a chain, the kernel also computes unit 1's pw1 (on channels [bf, 2bf) of its own output)
-            // ... in the launch-latency regime only (fewer 32-pixel tiles than CUs: small batches - one 608 x 608 image saves two 10-15 us
-            // launches).  With every CU holding several workgroups the extra k-steps stream their weights at the CU's L1 rate (each 32-row
-            // workgroup pulls the whole matrix): 42 us against 30 + 13 at stage 3, 59 against 34 + 17 at stage 4 of a 32-image batch.
+            // ... in the launch-latency regime only (at most 64 tiles of 32 pixels: one to a few images - one 608 x 608 image saves two 10-15 us
+            // launches).  Beyond that the extra k-steps stream their weights at the CU's L1 rate (each 32-row workgroup pulls the whole
+            // matrix): 42 us against 30 + 13 at stage 3 (676 tiles), 58 against 34 + 17 at stage 4 (169 tiles) of a 32-image batch.
             static const int down2_next = getenv("YN_DOWN2_NEXT") ? atoi(getenv("YN_DOWN2_NEXT")) : 1;     // 0: never, 2: always (A/B runs, tests)
-            const bool next_pays = down2_next == 2 || (down2_next == 1 && Mo <= 32 * 256);
+            const bool next_pays = down2_next == 2 || (down2_next == 1 && Mo <= 32 * 64);
             if (use_down2 && next_pays && STAGE_REP[si] > 1 && run_unit_chain(h, si + 2, STAGE_REP[si], oA, B, Ho, Ho, C, oB, t2, t1, nullptr, true) == 1) {
                 snprintf(nm, sizeof nm, "backbone.stage%d.1.b2.pw1", si + 2);
                 const Layer& l1n = L(h, nm);
