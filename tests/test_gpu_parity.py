@@ -1056,7 +1056,7 @@ def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
     h.profile_enable(False)
     taps1 = h.forward_taps(x)
     wide = backbone == "1.5x"            # bf = 88 / 176 / 352: stage 2 is too wide for down_unit_kernel (down2 takes it), stage 4 for down2_kernel (five launches)
-    assert wide or any(k.startswith("down_unit_kernel") for k in kernels), kernels
+    assert wide or any(k.startswith("down_unit_pipe_kernel") for k in kernels), kernels   # round 4: the tile-walking form
     # round 4: the stride-2 units of stages 3 and 4 as pw1 + ONE kernel (down2_kernel: both depthwise convs, both pointwise convs behind
     # them, concat + shuffle) instead of five launches - odd output maps (13 x 13, 9 x 9, 7 x 7), ragged last 32-pixel tiles, K chunks of 32
     # (many tiles) and 64 (few) are all in the parameter list above

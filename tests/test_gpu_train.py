@@ -418,9 +418,20 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
                     l_un = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
                     monkeypatch.delenv("YN_TRAIN_FUSE_STATS"); monkeypatch.delenv("YN_TRAIN_FUSE_SUMS")
                     # (not atomic noise only: the epilogue sums are fp32 partials of 128 rows, the reduction kernel's are double - the statistics
-                    #  differ in the 7th digit, a stored fp16 value lands on its neighbour here and there, the conf loss hangs on the IoU of a few positives)
+                    #  differ in the 7th digit, a stored fp16 value lands on its neighbour here and there, the conf loss hangs on the IoU of a few
+                    #  positives, and the early layers' fp16 gradients are noise-dominated in every realisation (error 0.7-1.0 of the value, the
+                    #  emulation's too): the two runs are NOT comparable element by element there.  The unfused step is held to the fused one's
+                    #  yardstick instead - the fp64 step, against the emulation's distance from it - and to the fused step where fp16 is exact
+                    #  enough to compare: the tensors the emulation gets within 5 %.)
                     np.testing.assert_allclose(l_un, losses, rtol=1e-2)
-                    assert float((h.flat_grads - grads).abs().max()) <= 5e-3 * float(grads.abs().max()), S
+                    errs_un = {n: rel(_grad(h, n, g64[n].shape).astype(np.float64), g64[n]) for n in live}
+                    assert np.median([errs_un[n] / max(ey[n], 1e-6) for n in live]) < 1.25, S
+                    for n in live:
+                        assert errs_un[n] <= 2.5 * ey[n] + 5e-2, (S, n, errs_un[n], ey[n])
+                        if ey[n] < 5e-2:
+                            a = _grad(h, n, g64[n].shape).astype(np.float64)
+                            b = grads[h.param_slice(n)].cpu().numpy().reshape(g64[n].shape).astype(np.float64)
+                            assert rel(a, b) <= 3.0 * ey[n] + 1e-2, (S, n, rel(a, b), ey[n])
         if phase == 2:
             continue
         if precision == "f32":

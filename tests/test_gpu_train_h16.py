@@ -297,8 +297,12 @@ def test_h16_step_is_as_exact_as_fp16_storage_allows(golden, backbone, S, C, B):
     # A SECOND, independent realisation of "fp16 storage": the same storage points on float32 arithmetic (other summation orders, other
     # roundings in front of every fp16 rounding point - the stored values land on neighbouring fp16 numbers here and there, as they do in
     # the HIP step).  The two emulations span what fp16 storage does to this step; the HIP gradient has to sit INSIDE that span, tensor by
-    # tensor: no further from either emulation than 1.5x their distance from each other (+ 2e-2), and no further from exact than the worse of
-    # the two (x1.3 + 2e-2) - a yardstick that does not depend on one emulation's rounding points being the builder's own choice.
+    # tensor - a yardstick that does not depend on one emulation's rounding points being the builder's own choice.  Three realisations of a
+    # noise-dominated tensor (the early backbone's fp16 gradients are 0.7-1.0 of their value off in every one of them) are three samples of
+    # the same noise: max(d(hip,e64), d(hip,e32)) / d(e64,e32) has median 1.11-1.12, 90th percentile 1.35-1.40 and a largest value of
+    # 1.8-2.1 over the ~150 tensors (six runs on one box, two boxes - the fp32 emulation's summation order follows the host CPU).  So: the
+    # distribution is gated (median < 1.2, 90th percentile < 1.6), and each tensor at 2.5x the emulations' distance (+ 5e-2) and 2x the
+    # worse emulation's error (+ 5e-2), the same factors as the single-emulation bar above.
     from oracle.torch_port import TrainNet
     _, gq32 = TrainNet(sd, backbone, C, anchors=arch.MULTI_ANCHOR_SIZE, dtype=torch.float32, fp16_storage=True).train_step(x, target, S)
     bad2, span = [], []
@@ -311,10 +315,12 @@ def test_h16_step_is_as_exact_as_fp16_storage_allows(golden, backbone, S, C, B):
         d_h64, d_h32 = rel(got_g, gq[name]), rel(got_g, e32)
         worse = max(rel(gq[name], exact), rel(e32, exact))
         span.append(max(d_h64, d_h32) / max(d_ee, 1e-6))
-        if max(d_h64, d_h32) > 1.5 * d_ee + 2e-2 or rel(got_g, exact) > 1.3 * worse + 2e-2:
+        if max(d_h64, d_h32) > 2.5 * d_ee + 5e-2 or rel(got_g, exact) > 2.0 * worse + 5e-2:
             bad2.append((name, d_h64, d_h32, d_ee, rel(got_g, exact), worse))
+    worst = sorted(((max(r[1], r[2]) / max(r[3], 1e-6), r[0]) for r in bad2), reverse=True)[:3]
+    print("span: median %.2f p90 %.2f max %.2f, outside: %d %s" % (np.median(span), np.percentile(span, 90), max(span), len(bad2), worst))
     assert not bad2, "outside the span of two fp16-storage realisations (name, d(hip,e64), d(hip,e32), d(e64,e32), err, worse emulation err): %s" % bad2[:8]
-    assert np.median(span) < 1.2, np.median(span)
+    assert np.median(span) < 1.2 and np.percentile(span, 90) < 1.6, (np.median(span), np.percentile(span, 90))
     # the loss scale is removed again, and a clean step leaves it in place
     assert h.skipped_steps() == 0
     h.close()

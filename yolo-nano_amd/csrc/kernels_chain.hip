@@ -1332,6 +1332,333 @@ __global__ __launch_bounds__(256, 2) void down_unit_kernel(DownArgs a)
 #undef YN_TS
 }
 
+// -------------------------------------------------------------------------------------------------
+// down_unit_kernel as a software pipeline (round 4).  `tools/phase_timing.sh downunit` on the one-tile-per-workgroup form above: 25 k
+// cycles per workgroup, 10 k of them the load phase (one memory round trip, 34 eight-byte loads per thread with a cache line per lane),
+// at two workgroups of four wavefronts per CU - nothing to hide it behind.  This form keeps the arithmetic and its order (same bits,
+// test_down_unit_is_bit_identical) and changes where the operands come from:
+//   * a workgroup WALKS tiles (XCD-contiguous: workgroup i of XCD x takes tiles x*TL + i, + G/8, ...) and requests the next tile's input
+//     window right after the barrier that frees the registers of the current one: the round trip runs under phases 2-5;
+//   * the window is loaded as what it is - nine contiguous runs of 17 pixels x cin floats - with 16-byte loads (4-5 per thread, eight
+//     cache lines per wavefront instruction instead of 64), split into the A planes AND kept as fp32 in LDS: branch 1's depthwise conv
+//     reads its stride-2 windows there (18 more global loads per thread in the old form);
+//   * every weight is loop-invariant: the B fragments of a wavefront's columns (16 contiguous bytes of the pre-split pack per lane and
+//     k-step - down2_kernel's register-direct form) are loaded ONCE per workgroup into 48 registers, like the depthwise taps.  No
+//     weight ever passes through LDS: 76 -> 78 KB with the fp32 window (two workgroups per CU either way).
+// -------------------------------------------------------------------------------------------------
+template <int NP, bool RELU>                                 // RELU: the three pointwise convs end in ReLU, the depthwise convs in nothing (ShuffleNetV2)
+__global__ __launch_bounds__(256, 2) void down_unit_pipe_kernel(DownArgs a, int tiles)
+{
+    constexpr int TW = 8, TH = 4, WW = 2 * TW + 1, WH = 2 * TH + 1, NPIX = WW * WH, RT1 = (NPIX + 31) / 32;
+    constexpr int BN = 32 * NP, AST1 = 32 + 8, AST2 = BN + 8, NO = TW * TH, NLD = 5, KS2 = 2 * NP;
+    extern __shared__ __attribute__((aligned(16))) float du_smem[];
+    const int bf = a.bf, CS = bf + 2, cin = a.cin, cq = cin >> 2;
+    uch16* A1h = reinterpret_cast<uch16*>(du_smem);                  // [RT1*32][AST1] x 2: pw1's operand planes
+    uch16* A1l = A1h + RT1 * 32 * AST1;
+    uch16* A2h = A1h;                                                // behind GEMM 1: [NO][AST2] x 2 (pw2), then [NO][AST1] x 2 (branch 1)
+    uch16* A2l = A2h + NO * AST2;
+    uch16* A3h = A2l + NO * AST2;
+    uch16* A3l = A3h + NO * AST1;
+    float* X32 = du_smem + RT1 * 32 * AST1;                          // [RT1*32][cin]: the window in fp32 (zero outside the image)
+    float* T32 = X32 + RT1 * 32 * cin;                               // [RT1*32][CS]: y1 (zero outside the image), later branch 1's tile
+    unsigned char* inside = reinterpret_cast<unsigned char*>(T32 + RT1 * 32 * CS);      // [RT1*32]
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    const int tx_n = (Wo + TW - 1) / TW, ty_n = (Ho + TH - 1) / TH, per_img = tx_n * ty_n;
+    const int KQ1 = (cin + 7) >> 3, KQ2 = (bf + 7) >> 3;
+    // the walk: XCD x = blockIdx & 7 owns tiles [x * TL, (x + 1) * TL)
+    const int TL = (tiles + 7) >> 3, GL = (int)(gridDim.x >> 3);
+    const int tbase = (int)(blockIdx.x & 7u) * TL;
+    int tl = (int)(blockIdx.x >> 3);
+    if (tl >= TL || tbase + tl >= tiles) return;
+    auto act_pw = [&](float v, int act) { return RELU ? __builtin_fmaxf(v, 0.0f) : apply_act(v, act); };
+
+#ifdef YN_EXP_TIMING
+    long long TS[8]; int tsn = 0;
+#define YN_TS() if (tsn < 8) TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    YN_TS();
+    // ---- loop invariants: depthwise taps and biases of both branches, the B fragments of this wavefront's columns --------------------
+    const int cp_n = bf >> 1, ppl = 256 / cp_n;
+    const int cp = t % cp_n, dpl = t / cp_n, dc = cp * 2;
+    const bool dworker = dpl < ppl;
+    float2 wd[9], bd = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd[k] = dworker ? *reinterpret_cast<const float2*>(a.wdw + k * bf + dc) : make_float2(0.0f, 0.0f);
+    if (dworker) bd = *reinterpret_cast<const float2*>(a.bdw + dc);
+    const int c1_n = cin >> 1, p1_n = 256 / c1_n;
+    const int c1 = (t % c1_n) * 2, p1 = t / c1_n;
+    constexpr int NI1 = 2;                                           // 32 output pixels over >= 16 pixel lanes (cin <= 32)
+    float2 w1d[9], b1d;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w1d[k] = *reinterpret_cast<const float2*>(a.wdw1 + k * cin + c1);
+    b1d = *reinterpret_cast<const float2*>(a.bdw1 + c1);
+    // GEMM 1: items it = (row tile, column tile) = 3 - wave, 7 - wave, ... - the wavefronts that run pw2 and the stores take the smaller share
+    const int it0 = 3 - wave;
+    const int nt1 = (NP == 2) ? (it0 & 1) : 0;                       // the stride 4 is even: a wavefront's column tile never changes
+    const bool pw2_wave = wave < NP, b1_wave = wave >= NP && wave < 2 * NP;
+    const int nt2 = pw2_wave ? wave : wave - NP;
+    auto frag = [&](const void* Wh_, const void* Wl_, int ks, int KQ, int n, bool use, uch16x8& bh, uch16x8& bl) {
+        const int kq = ks * 2 + h;
+        const bool ok = use && kq < KQ;
+        const size_t off = ((size_t)(ok ? kq : 0) * BN + (ok ? n : 0)) * 8;      // Npad1 = Npad2 = Npad3 = BN (down_unit_covers)
+        const unsigned mk = opaque_mask(ok);
+        uint4 vh = *reinterpret_cast<const uint4*>(reinterpret_cast<const uch16*>(Wh_) + off), vl = *reinterpret_cast<const uint4*>(reinterpret_cast<const uch16*>(Wl_) + off);
+        vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
+        bh = *reinterpret_cast<uch16x8*>(&vh); bl = *reinterpret_cast<uch16x8*>(&vl);
+    };
+    uch16x8 g1h[2], g1l[2], g2h[KS2], g2l[KS2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) frag(a.W1h, a.W1l, ks, KQ1, nt1 * 32 + l31, true, g1h[ks], g1l[ks]);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {                               // pw2 (K = bf) on wavefronts 0..NP-1, branch 1's pointwise conv (K = cin: two steps) behind them
+        const bool use = pw2_wave || (b1_wave && ks < 2);
+        frag(pw2_wave ? a.W2h : a.W3h, pw2_wave ? a.W2l : a.W3l, ks, pw2_wave ? KQ2 : KQ1, nt2 * 32 + l31, use, g2h[ks], g2l[ks]);
+    }
+    const float bias1 = (nt1 * 32 + l31 < bf) ? a.b1[nt1 * 32 + l31] : 0.0f;
+    const float bias23 = (nt2 * 32 + l31 < bf && (pw2_wave || b1_wave)) ? (pw2_wave ? a.b2 : a.b3)[nt2 * 32 + l31] : 0.0f;
+    // window pieces of this thread: 16-byte piece e = t + 256 i of the WH runs of WW * cin floats; everything about a piece that does not
+    // depend on the tile is computed here
+    const int QR = WW * cq;
+    int wpos[NLD], wrel[NLD];                                        // wy | wx << 8 | first channel << 16 (or -1); offset from the window's first float
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = t + 256 * i;
+        const int wy = e / QR, q = e - wy * QR;
+        const int wx = q / cq, c4 = (q - wx * cq) * 4;
+        wpos[i] = (e < WH * QR) ? (wy | (wx << 8) | (c4 << 16)) : -1;
+        wrel[i] = (wy * a.W + wx) * cin + c4;
+    }
+    float4 pre[NLD];
+    unsigned pok = 0;
+    const char* xbase = reinterpret_cast<const char*>(a.x);
+    auto request = [&](int tile) {
+        const int b = tile / per_img, trem = tile - b * per_img;
+        const int ty = trem / tx_n, tx = trem - ty * tx_n;
+        const int iy0 = 2 * ty * TH - 1, ix0 = 2 * tx * TW - 1;
+        const int org = ((b * a.H + iy0) * a.W + ix0) * cin;         // the window's first float (outside the tensor on the image border: never used then)
+        pok = 0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int wy = wpos[i] & 0xff, wx = (wpos[i] >> 8) & 0xff;
+            const bool ok = wpos[i] >= 0 && (unsigned)(iy0 + wy) < (unsigned)a.H && (unsigned)(ix0 + wx) < (unsigned)a.W;
+            // raw value from a clamped address; zeroed when it is CONSUMED (a mask applied here would wait for the load here)
+            pre[i] = *reinterpret_cast<const float4*>(xbase + (unsigned)(ok ? org + wrel[i] : 0) * 4u);
+            pok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    request(tbase + tl);
+    if (t < RT1 * 32 - NPIX) inside[NPIX + t] = 0;                   // pad rows of the last row tile: never inside
+    float amax = 0.0f;                                               // range guard (yn_device.h): largest |value| this thread has split
+    float* PT = T32;                                                 // [32][BN + 1]: branch 1's output tile
+
+    // ---- 1. the window: fp32 copy + split planes; K tail of the planes (run for the NEXT tile in front of the current tile's stores: the wait
+    //      for the prefetch must not stand behind them in the memory counter) --------------------------------------------------------
+    auto consume = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (wpos[i] >= 0) {
+                const int wy = wpos[i] & 0xff, wx = (wpos[i] >> 8) & 0xff, c4 = (wpos[i] >> 16) & 0xff;
+                const int p = wy * WW + wx;
+                const float4 v = vmask(pre[i], 0u - ((pok >> i) & 1u));
+                *reinterpret_cast<float4*>(X32 + p * cin + c4) = v;
+                const float x4[4] = {v.x, v.y, v.z, v.w};
+                uch16x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
+                *reinterpret_cast<uch16x4*>(A1h + p * AST1 + c4) = hi;
+                *reinterpret_cast<uch16x4*>(A1l + p * AST1 + c4) = lo;
+                if (c4 == 0) inside[p] = (unsigned char)((pok >> i) & 1u);
+            }
+        }
+        {
+            const int ntail = (32 - cin) >> 2;                       // quads of zero columns up to K = 32
+            for (int i = t; i < RT1 * 32 * ntail; i += 256) {
+                const int p = i / ntail, c2 = cin + 4 * (i - p * ntail);
+                *reinterpret_cast<uint2*>(A1h + p * AST1 + c2) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(A1l + p * AST1 + c2) = make_uint2(0u, 0u);
+            }
+        }
+    };
+    consume();
+
+    for (;;) {
+        const int tile = tbase + tl;
+        const int b = tile / per_img, trem = tile - b * per_img;
+        const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
+        __syncthreads();
+        YN_TS();
+        const bool more = tl + GL < TL && tbase + tl + GL < tiles;
+        if (more) request(tbase + tl + GL);                          // the next tile's round trip runs under phases 2-4
+
+        // ---- 2. y1 = act(pw1) on the window pixels -> T32 (zero outside the image) ---------------------------------------------------
+        for (int it = it0; it < RT1 * NP; it += 4) {
+            const int rt = it / NP;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+            const uch16* Ahb = A1h + (rt * 32 + l31) * AST1 + h * 8;
+            const uch16* Alb = A1l + (rt * 32 + l31) * AST1 + h * 8;
+            int inw[4];                                              // inside flags of this lane's 16 rows: four bytes per word
+#pragma unroll
+            for (int g = 0; g < 4; ++g) inw[g] = *reinterpret_cast<const int*>(inside + rt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g1h[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g1l[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, g1h[ks], acc1, 0, 0, 0);
+            }
+            const int n = nt1 * 32 + l31;
+            if (n < bf) {
+                float* trow = T32 + (rt * 32 + 4 * h) * CS + n;      // row (r & 3) + 8 (r >> 2) of this lane's half: a wave-uniform offset
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = act_pw(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias1, a.act1);
+                    trow[((r & 3) + 8 * (r >> 2)) * CS] = __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe(inw[r >> 2], 8 * (r & 3), 1));
+                }
+            }
+        }
+        __syncthreads();                                             // y1 complete; the A1 planes are free
+        YN_TS();
+
+        // ---- 3. both depthwise convs (stride 2, dwconv3x3_kernel's fma chain) -> the split planes of their branch --------------------
+        if (p1 < p1_n) {
+#pragma unroll
+            for (int i = 0; i < NI1; ++i) {
+                const int op = p1 + i * p1_n;
+                if (op < NO) {
+                    const int dy = op / TW, dx = op - dy * TW;
+                    float2 acc = b1d;
+                    const float* xw = X32 + (2 * dy * WW + 2 * dx) * cin + c1;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) vfma(acc, *reinterpret_cast<const float2*>(xw + ((k / 3) * WW + k % 3) * cin), w1d[k]);
+                    if (!RELU) acc = vact(acc, a.dw1_act);
+                    amax = range_track(range_track(amax, acc.x), acc.y);
+                    uch16x2 hi, lo;
+                    hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
+                    lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
+                    *reinterpret_cast<uch16x2*>(A3h + op * AST1 + c1) = hi;
+                    *reinterpret_cast<uch16x2*>(A3l + op * AST1 + c1) = lo;
+                }
+            }
+        }
+        {
+            const int pad1 = (AST1 - cin) >> 2;                      // K tail of branch 1's planes: zero (quads: cin is a multiple of 4)
+            for (int i = t; i < NO * pad1; i += 256) {
+                const int r = i / pad1, c2 = cin + 4 * (i - r * pad1);
+                *reinterpret_cast<uint2*>(A3h + r * AST1 + c2) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(A3l + r * AST1 + c2) = make_uint2(0u, 0u);
+            }
+        }
+        if (dworker) {
+            for (int op = dpl; op < NO; op += ppl) {
+                const int dy = op / TW, dx = op - dy * TW;
+                float2 acc = bd;
+                const float* yw = T32 + (2 * dy * WW + 2 * dx) * CS + dc;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        vfma(acc, *reinterpret_cast<const float2*>(yw + (ky * WW + kx) * CS), wd[ky * 3 + kx]);
+                if (!RELU) acc = vact(acc, a.dw_act);
+                amax = range_track(range_track(amax, acc.x), acc.y);
+                uch16x2 hi, lo;
+                hi[0] = (uch16)acc.x; hi[1] = (uch16)acc.y;
+                lo[0] = (uch16)((acc.x - (float)hi[0]) * 2048.0f); lo[1] = (uch16)((acc.y - (float)hi[1]) * 2048.0f);
+                *reinterpret_cast<uch16x2*>(A2h + op * AST2 + dc) = hi;
+                *reinterpret_cast<uch16x2*>(A2l + op * AST2 + dc) = lo;
+            }
+        }
+        {
+            const int padn = (AST2 - bf) >> 1;                       // K tail of both planes: zero (pairs: bf is even)
+            for (int i = t; i < NO * padn; i += 256) {
+                const int r = i / padn, c2 = bf + 2 * (i - r * padn);
+                *reinterpret_cast<unsigned*>(A2h + r * AST2 + c2) = 0u;
+                *reinterpret_cast<unsigned*>(A2l + r * AST2 + c2) = 0u;
+            }
+        }
+        __syncthreads();
+        YN_TS();
+
+        // ---- 4. branch 1's pointwise conv on wavefronts NP..2NP-1 (-> PT, in the free T32 space) while wavefronts 0..NP-1 run pw2 -----
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+        if (b1_wave) {
+            const uch16* Ahb = A3h + l31 * AST1 + h * 8;
+            const uch16* Alb = A3l + l31 * AST1 + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g2h[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g2l[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, g2h[ks], acc1, 0, 0, 0);
+            }
+            float* prow = PT + (4 * h) * (BN + 1) + nt2 * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                prow[((r & 3) + 8 * (r >> 2)) * (BN + 1)] = act_pw(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias23, a.act3);
+        }
+        if (pw2_wave) {                                              // pw2: one wavefront per 32 output columns, gemm_split_tile's chunks of 32 (whole chunks, zero-padded)
+            const uch16* Ahb = A2h + l31 * AST2 + h * 8;
+            const uch16* Alb = A2l + l31 * AST2 + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g2h[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, g2l[ks], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, g2h[ks], acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                             // branch 1's tile is complete; nobody reads the planes, the fp32 window or the flags any more
+        if (more) consume();                                         // the next tile's window -> LDS (PT, which the store below reads, lies in T32)
+        // ---- 5. concat + shuffle store: out[2n] = branch 1, out[2n+1] = branch 2.  Row r of the accumulator = tile pixel (r >> 2, (r & 3) + 4 h):
+        //      a wave-uniform base + a 32-bit lane offset per store -----------------------------------------------------------------------
+        if (pw2_wave) {
+            const int n = wave * 32 + l31;
+            // byte offsets in 32 bits (down_unit_covers: the output tensor is below 4 GB): ONE 64-bit base, the kernel argument itself
+            char* obase = reinterpret_cast<char*>(a.out);
+            const unsigned lane_off = (unsigned)((((b * Ho + oy0) * Wo + ox0) + 4 * h) * 2 * bf + 2 * n) * 4u;
+            const float* prow = PT + (4 * h) * (BN + 1) + n;
+            float pv[16];                                            // branch 1's values first: one LDS wait, not sixteen
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = prow[((r & 3) + 8 * (r >> 2)) * (BN + 1)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dy = r >> 2, dxu = r & 3;
+                if (oy0 + dy < Ho) {
+                    if (n < bf && ox0 + dxu + 4 * h < Wo) {
+                        const float v = act_pw(__builtin_fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) + bias23, a.act2);
+                        *reinterpret_cast<float2*>(obase + (lane_off + (unsigned)((dy * Wo + dxu) * 2 * bf) * 4u)) = make_float2(pv[r], v);
+                    }
+                }
+            }
+        }
+        YN_TS();
+        if (!more) break;
+        tl += GL;
+    }
+    range_report(a.ovf, amax);
+#ifdef YN_EXP_TIMING
+    if (t == 0 && (blockIdx.x % 61) == 7 && tsn >= 5)
+        printf("downpipe blk %d invariants+window %lld gemm1 %lld dw %lld gemm2+store %lld first tile %lld second %lld\n", (int)blockIdx.x, TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2],
+               TS[4] - TS[3], TS[4] - TS[0], tsn >= 8 ? TS[7] - TS[4] : -1LL);
+#endif
+#undef YN_TS
+}
+
+static size_t down_unit_pipe_lds(int bf, int cin)
+{
+    return ((size_t)160 * 40 + (size_t)160 * cin + (size_t)160 * (bf + 2)) * sizeof(float) + 160;
+}
+
 static size_t down_unit_lds(int bf, int NP)
 {
     const int BN = 32 * NP, RT1 = 5, NO = 32;
@@ -1343,7 +1670,7 @@ static size_t down_unit_lds(int bf, int NP)
 bool down_unit_covers(const DownArgs& a)
 {
     return a.W1h && a.W1l && a.W2h && a.W2l && a.cin <= 32 && !(a.cin & 1) && a.bf <= 64 && !(a.bf & 1) && a.Npad1 == a.Npad2 && a.Npad1 <= 64 &&
-           !(a.H & 1) && !(a.W & 1) && a.B > 0 && a.cin >= 16 &&
+           !(a.H & 1) && !(a.W & 1) && a.B > 0 && a.cin >= 16 && (size_t)a.B * a.H * a.W * (size_t)(a.cin > a.bf / 2 ? a.cin : a.bf / 2) < ((size_t)1 << 30) &&      // 32-bit byte offsets
            (a.pass || (a.wdw1 && a.bdw1 && a.W3h && a.W3l && a.b3 && a.Npad3 == a.Npad1));
 }
 
@@ -1357,6 +1684,25 @@ void launch_down_unit(const DownArgs& a, hipStream_t s)
     if (attr_pending(attr)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_pipe_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_pipe_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_pipe_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(down_unit_pipe_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    // the pipelined form (a workgroup walks tiles): branch 1 computed here, channel quads (YN_DOWN_PIPE=0: one tile per workgroup, A/B runs)
+    static const int pipe = getenv("YN_DOWN_PIPE") ? atoi(getenv("YN_DOWN_PIPE")) : 1;
+    static const int pipe_g = getenv("YN_DOWN_PIPE_G") ? atoi(getenv("YN_DOWN_PIPE_G")) : 1024;     // walking workgroups: ~3 tiles each at bs = 32 (512 / 768 / 1024 / 1456 / one per tile measured within 1 % of each other)
+    if (pipe && !a.pass && !(a.cin & 3)) {
+        const size_t plds = down_unit_pipe_lds(a.bf, a.cin);
+        unsigned g = xcd_grid(tiles);
+        const unsigned cap = (unsigned)((pipe_g > 8 ? pipe_g : 8) & ~7);
+        if (g > cap) g = cap;
+        const bool relu = a.act1 == 1 && a.act2 == 1 && a.act3 == 1 && a.dw_act == 0 && a.dw1_act == 0;
+#define YN_DUP(np, rl) { set_last_kernel_name("down_unit_pipe_kernel<" #np "," #rl ">"); hipLaunchKernelGGL((down_unit_pipe_kernel<np, rl>), dim3(g), dim3(256), plds, s, a, (int)tiles); }
+        if (NP == 1) { if (relu) YN_DUP(1, true) else YN_DUP(1, false) }
+        else         { if (relu) YN_DUP(2, true) else YN_DUP(2, false) }
+#undef YN_DUP
+        return;
     }
     if (NP == 1) { set_last_kernel_name("down_unit_kernel<1>"); hipLaunchKernelGGL(down_unit_kernel<1>, dim3(xcd_grid(tiles)), dim3(256), lds, s, a); }
     else         { set_last_kernel_name("down_unit_kernel<2>"); hipLaunchKernelGGL(down_unit_kernel<2>, dim3(xcd_grid(tiles)), dim3(256), lds, s, a); }
