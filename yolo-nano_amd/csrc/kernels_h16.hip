@@ -529,11 +529,155 @@ __global__ __launch_bounds__(256) void hdw_kernel(HDwArgs a)
     sth8(o, r);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Stride-1 depthwise 3x3 as RUNS (round 4): thread = one channel octet of R = 4 consecutive output pixels of a row.  hdw_kernel<1>
+// loads nine 16-byte vectors per output (9x the tensor through L1 / L2: 20 us for an 11 MB stage-3 map, twice the BatchNorm apply pass
+// beside it); a run shares its 3 x 6 window: 4.5 loads per output.  Same fma chain per output (taps 0..8 onto the bias): same bits.
+// A workgroup is PB = 256 / OC runs x OC octets and walks NR blocks of runs, so the launch has a few hundred workgroups and the optional
+// statistics cost 2 C double atomics each (HColStat, as in hgemm_kernel's epilogue - the separate hcol_reduce launch and its pass over
+// the tensor disappear):
+//   STAT 1 (forward):        acc[0][c] += sum out, acc[1][c] += sum out^2 of the fp16 values just stored - the BatchNorm statistics;
+//   STAT 2 (input gradient): the output is dz of the layer BELOW (its BN + activation fed this conv); with that layer's pre-BN output y:
+//                            acc[0][c] += sum d, acc[1][c] += sum d * xhat, d = dz * act'(BN(y))     (hcol_reduce_kernel<2>'s sums).
+// -------------------------------------------------------------------------------------------------
+template <int STAT>
+__global__ __launch_bounds__(256) void hdw_run_kernel(HDwArgs a, int NR)
+{
+    constexpr int R = 4;
+    const int OC = a.Cp >> 3, PB = 256 / OC;
+    const int RW = (a.W + R - 1) / R;
+    const long runs = (long)a.B * a.H * RW;
+    const int t = threadIdx.x;
+    const int oc = t % OC, rl = t / OC, c = oc * 8;
+    const bool worker = rl < PB;
+    f32x2 s0[4], s1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { s0[p] = splat2(0.0f); s1[p] = splat2(0.0f); }
+    f32x2 mu[4], is[4], ga[4], be[4];
+    float negslope = 1.0f;
+    if (STAT == 2) {
+        negslope = act_negslope(a.st.act);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c0 = logical_of(c + 2 * p, a.st.C, a.st.half, a.st.gap), c1 = logical_of(c + 2 * p + 1, a.st.C, a.st.half, a.st.gap);
+            mu[p].x = c0 >= 0 ? a.st.mean[c0] : 0.0f; is[p].x = c0 >= 0 ? a.st.invstd[c0] : 0.0f; ga[p].x = c0 >= 0 ? a.st.gamma[c0] : 0.0f; be[p].x = c0 >= 0 ? a.st.beta[c0] : 0.0f;
+            mu[p].y = c1 >= 0 ? a.st.mean[c1] : 0.0f; is[p].y = c1 >= 0 ? a.st.invstd[c1] : 0.0f; ga[p].y = c1 >= 0 ? a.st.gamma[c1] : 0.0f; be[p].y = c1 >= 0 ? a.st.beta[c1] : 0.0f;
+        }
+    }
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias[j] = a.bias ? a.bias[c + j] : 0.0f;
+    const long blk = (long)xcd_block(blockIdx.x, gridDim.x);
+    for (int n = 0; n < NR; ++n) {
+        const long run = (blk * NR + n) * PB + rl;
+        if (!worker || run >= runs) continue;
+        const int xr = (int)(run % RW); const long q = run / RW;
+        const int oy = (int)(q % a.H), b = (int)(q / a.H);
+        const int x0 = xr * R;
+        h16x8 v[3][R + 2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            const bool yok = iy >= 0 && iy < a.H;
+            const h16* rowp = a.in + ((size_t)(b * a.H + (yok ? iy : 0)) * a.W) * a.in_ld + a.in_off + c;
+#pragma unroll
+            for (int i = 0; i < R + 2; ++i) {
+                const int ix = x0 - 1 + i;
+                const bool ok = yok && ix >= 0 && ix < a.W;
+                v[ky][i] = keep8(ldh8(rowp + (size_t)(ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix)) * a.in_ld), ok);
+            }
+        }
+        const size_t p0 = ((size_t)(b * a.H + oy)) * a.W + x0;            // first output pixel of the run
+        h16x8 yv[STAT == 2 ? R : 1], old[R];
+        if (STAT == 2) {
+#pragma unroll
+            for (int o = 0; o < R; ++o) yv[o] = ldh8(a.st.y + (p0 + (x0 + o < a.W ? o : 0)) * a.st.y_ld + c);
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int o = 0; o < R; ++o) old[o] = ldh8(a.out + (p0 + (x0 + o < a.W ? o : 0)) * a.out_ld + a.out_off + c);
+        }
+        float acc[R][8];
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o][j] = bias[j];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const float4 w0 = *reinterpret_cast<const float4*>(a.w + (size_t)tp * a.Cp + c);
+            const float4 w1 = *reinterpret_cast<const float4*>(a.w + (size_t)tp * a.Cp + c + 4);
+            const float w8[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int o = 0; o < R; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] = __builtin_fmaf((float)v[tp / 3][o + tp % 3][j], w8[j], acc[o][j]);
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            if (x0 + o >= a.W) continue;
+            h16x8 r;
+            if (a.accumulate) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (h16)(acc[o][j] + (float)old[o][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (h16)acc[o][j];
+            }
+            sth8(a.out + (p0 + o) * a.out_ld + a.out_off + c, r);
+            if (STAT == 1) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { const f32x2 x = pair_of(r, p); s0[p] += x; s1[p] = __builtin_elementwise_fma(x, x, s1[p]); }
+            } else if (STAT == 2) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2 xh = bn_xhat2(pair_of(yv[o], p), mu[p], is[p]);
+                    const f32x2 d = act_grad2(pair_of(r, p), bn_value2(xh, ga[p], be[p]), negslope);
+                    s0[p] += d; s1[p] = __builtin_elementwise_fma(d, xh, s1[p]);
+                }
+            }
+        }
+    }
+    if (STAT != 0) {
+        // the workgroup's runs -> one value per (sum, channel): [PB][OC * 16] floats through LDS, then 2 C double atomics into this block's slot
+        __shared__ float red[256 * 16];
+        if (worker) {
+            float* rp = red + (rl * OC + oc) * 16;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { rp[2 * p] = s0[p].x; rp[2 * p + 1] = s0[p].y; rp[8 + 2 * p] = s1[p].x; rp[8 + 2 * p + 1] = s1[p].y; }
+        }
+        __syncthreads();
+        for (int e = t; e < OC * 16; e += 256) {                         // e = (octet, which sum, channel in octet)
+            const int o8 = e >> 4, k = e & 15;
+            const int lc = logical_of(o8 * 8 + (k & 7), a.st.C, a.st.half, a.st.gap);
+            if (lc < 0) continue;
+            float s = 0.0f;
+            for (int r = 0; r < PB; ++r) s += red[(r * OC + o8) * 16 + k];
+            double* acc = a.st.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * a.st.C;
+            atomicAdd(acc + (k >> 3) * a.st.C + lc, (double)s);
+        }
+    }
+}
+
 void launch_hdw(const HDwArgs& a, hipStream_t s)
 {
     const int Ho = (a.H - 1) / a.stride + 1, Wo = (a.W - 1) / a.stride + 1;
     const long total = (long)a.B * Ho * Wo * (a.Cp >> 3);
     const dim3 grid(xcd_grid((unsigned)((total + 255) / 256)));
+    static const int runs_on = getenv("YN_HDW_RUNS") ? atoi(getenv("YN_HDW_RUNS")) : 1;        // 0: one output per thread (A/B runs; no statistics then)
+    if (a.stride == 1 && (runs_on || a.st.acc) && a.Cp <= 256) {
+        const int OC = a.Cp >> 3, PB = 256 / OC;
+        const long runs = (long)a.B * a.H * ((a.W + 3) / 4);
+        const long nb1 = (runs + PB - 1) / PB;                              // workgroups at one block of runs each
+        static const int gtarget = getenv("YN_HDW_G") ? atoi(getenv("YN_HDW_G")) : 512;      // with statistics: two workgroups per CU (2 C double atomics each)
+        const long cap = a.st.acc ? gtarget : 4096;
+        const int NR = (int)((nb1 + cap - 1) / cap);
+        const dim3 g2(xcd_grid((unsigned)((nb1 + NR - 1) / NR)));
+        const int stat = !a.st.acc ? 0 : (a.st.y ? 2 : 1);
+        if (stat == 0) hipLaunchKernelGGL(hdw_run_kernel<0>, g2, dim3(256), 0, s, a, NR);
+        else if (stat == 1) hipLaunchKernelGGL(hdw_run_kernel<1>, g2, dim3(256), 0, s, a, NR);
+        else hipLaunchKernelGGL(hdw_run_kernel<2>, g2, dim3(256), 0, s, a, NR);
+        return;
+    }
     if (a.stride == 1) hipLaunchKernelGGL(hdw_kernel<1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(hdw_kernel<2>, grid, dim3(256), 0, s, a);
 }

@@ -50,6 +50,7 @@ struct HDwArgs {
     const float* w; const float* bias;          // [9][Cp], [Cp] or null
     h16* out; int out_ld, out_off;
     int B, H, W, Cp, stride, accumulate;
+    HColStat st;                                // stride 1 only: statistics of the output / BatchNorm-backward sums of the layer below (st.acc == null: none)
 };
 void launch_hdw(const HDwArgs& a, hipStream_t s);
 void launch_hdw_dgrad_s2(const h16* dy, int dy_ld, const float* w, int B, int H, int W, int Cp, h16* dx, int dx_ld, int dx_off, int accumulate, hipStream_t s);
