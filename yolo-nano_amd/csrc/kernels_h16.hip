@@ -459,7 +459,8 @@ __global__ __launch_bounds__(1024) void hwgrad_reduce_kernel(const float* __rest
 void launch_hwgrad(const HWgradArgs& a, hipStream_t s)
 {
     const int gn = (a.Np + 63) / 64, gk = (a.Kp + 63) / 64 * a.taps;
-    int slices = 1024 / (gn * gk);
+    static const int wg_blocks = getenv("YN_WG_BLOCKS") ? atoi(getenv("YN_WG_BLOCKS")) : 1024;
+    int slices = wg_blocks / (gn * gk);
     if (slices > 512) slices = 512;
     const int max_slices = (a.M + 511) / 512;
     if (slices > max_slices) slices = max_slices;
@@ -668,7 +669,7 @@ void launch_hdw(const HDwArgs& a, hipStream_t s)
         const int OC = a.Cp >> 3, PB = 256 / OC;
         const long runs = (long)a.B * a.H * ((a.W + 3) / 4);
         const long nb1 = (runs + PB - 1) / PB;                              // workgroups at one block of runs each
-        static const int gtarget = getenv("YN_HDW_G") ? atoi(getenv("YN_HDW_G")) : 512;      // with statistics: two workgroups per CU (2 C double atomics each)
+        static const int gtarget = getenv("YN_HDW_G") ? atoi(getenv("YN_HDW_G")) : 256;      // with statistics: one workgroup per CU - 2 C double atomics each (7.56 / 7.62 / 7.66 / 7.72 / 7.77 ms per step at 256 / 512 / 1 024 / 2 048 / 4 096)
         const long cap = a.st.acc ? gtarget : 4096;
         const int NR = (int)((nb1 + cap - 1) / cap);
         const dim3 g2(xcd_grid((unsigned)((nb1 + NR - 1) / NR)));
@@ -1087,7 +1088,10 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
 static int hstream_blocks(long M, int rowsPer)
 {
     long b = (M + (long)rowsPer * 4 - 1) / ((long)rowsPer * 4);
-    if (b > 256 * 6) b = 256 * 6;
+    // three workgroups per CU: every workgroup of these launches first adds up the HACC_SLOTS double copies of its layer's sums (60 KB for 116
+    // channels), so the prologue traffic grows with the grid - 7.79 ms per 608 / bs-32 step at 1 536 workgroups, 7.68 at 768 and at 512
+    static const int cap = getenv("YN_STREAM_CAP") ? atoi(getenv("YN_STREAM_CAP")) : 256 * 3;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -1613,6 +1617,251 @@ void launch_hmaxpool_bwd(const h16* dy, const uint8_t* idx, int B, int H, int W,
 {
     const long total = (long)B * H * W * (Cp >> 3);
     hipLaunchKernelGGL(hmaxpool_bwd_kernel, dim3(xcd_grid((unsigned)((total + 255) / 256))), dim3(256), 0, s, dy, idx, B, H, W, Cp, dx);
+}
+
+// =================================================================================================
+// The stem's BatchNorm + activation + max pool without the 142 MB tensors between them (608 x 608, bs 32; round 4).
+//   forward  (hstem_apply_pool_kernel): a1 = maxpool3x3s2(act(BN(y))) and the arg-max positions straight from the stem conv's output y:
+//            the normalised full-resolution tensor a0 is never stored (hbn_apply wrote it, hmaxpool_idx read it back: 284 MB);
+//   backward (hstem_bwd_kernel<0 / 1>): the gradient of a0 is the max pool's gather of a1's gradient - four candidate windows per pixel
+//            (hmaxpool_bwd_kernel's body) - and is formed where it is consumed, rounded to fp16 as the stored tensor was: <0> takes the
+//            BatchNorm-backward sums, <1> writes dy in place over y (hbn_bwd_kernel's arithmetic).  hmaxpool_bwd's 142 MB write and
+//            the two reads of it are gone.
+// Thread = one channel octet (of 3: C = Cp = 24) of a pixel; a workgroup is 85 pixels x 3 octets and walks pixel blocks, so a thread's
+// channel constants stay in registers.
+// =================================================================================================
+struct HStemCst { f32x2 mu[4], is[4], ga[4], be[4]; };
+__device__ __forceinline__ void hstem_cst_load(const float (*cst)[32], int oc, HStemCst& k)
+{
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = oc * 8 + 2 * p;
+        k.mu[p].x = cst[0][c]; k.mu[p].y = cst[0][c + 1]; k.is[p].x = cst[1][c]; k.is[p].y = cst[1][c + 1];
+        k.ga[p].x = cst[2][c]; k.ga[p].y = cst[2][c + 1]; k.be[p].x = cst[3][c]; k.be[p].y = cst[3][c + 1];
+    }
+}
+__global__ __launch_bounds__(256) void hstem_apply_pool_kernel(HBnApplyArgs a, int B, int H, int W, h16* __restrict__ out, uint8_t* __restrict__ idx)
+{
+    constexpr int C = 24, PB = 85;
+    __shared__ float cst[4][32];
+    const double invM = 1.0 / (double)a.M;
+    if (threadIdx.x < C) {                                      // hbn_apply_kernel's prologue: mean / invstd from the double sums; block 0 saves them
+        const int c = threadIdx.x;
+        double m = 0.0, q = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < HACC_SLOTS; ++sl) { m += a.acc[((size_t)sl * 2) * C + c]; q += a.acc[((size_t)sl * 2 + 1) * C + c]; }
+        m *= invM;
+        double var = q * invM - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)a.eps));
+        cst[0][c] = mu; cst[1][c] = is; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+        if (blockIdx.x == 0) {
+            a.mean[c] = mu; a.invstd[c] = is;
+            if (a.rmean) {
+                const float unbiased = (float)(a.M > 1 ? var * ((double)a.M / (double)(a.M - 1)) : var);
+                a.rmean[c] = (1.0f - a.momentum) * a.rmean[c] + a.momentum * mu;
+                a.rvar[c] = (1.0f - a.momentum) * a.rvar[c] + a.momentum * unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const int oc = threadIdx.x % 3, pl = threadIdx.x / 3;
+    if (pl >= PB) return;
+    HStemCst k;
+    hstem_cst_load(cst, oc, k);
+    const float negslope = act_negslope(a.act);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long npix = (long)B * Ho * Wo;
+    for (long p = (long)blockIdx.x * PB + pl; p < npix; p += (long)gridDim.x * PB) {
+        const int ox = (int)(p % Wo); const long q = p / Wo;
+        const int oy = (int)(q % Ho), b = (int)(q / Ho);
+        h16x8 v[9];
+        bool ok[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                ok[ky * 3 + kx] = yok && ix >= 0 && ix < W;
+                v[ky * 3 + kx] = ldh8(a.y + ((size_t)(b * H + (yok ? iy : 0)) * W + (ix < 0 ? 0 : (ix >= W ? W - 1 : ix))) * C + oc * 8);
+            }
+        }
+        float m[8]; int best[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; best[j] = -1; }
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {                    // bn_apply_emit's value, rounded to fp16 as the stored a0 was
+                const f32x2 zz = bn_value2(bn_xhat2(pair_of(v[t9], pp), k.mu[pp], k.is[pp]), k.ga[pp], k.be[pp]);
+                f32x2 mlt;
+                mlt.x = zz.x > 0.0f ? 1.0f : negslope;
+                mlt.y = zz.y > 0.0f ? 1.0f : negslope;
+                const f32x2 r = zz * mlt + splat2(0.0f);
+                const float z2[2] = {(float)(h16)r.x, (float)(h16)r.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * pp + e;
+                    const bool take = ok[t9] && (z2[e] > m[j] || best[j] < 0);      // first maximum in window order, as hmaxpool_idx_kernel
+                    m[j] = take ? z2[e] : m[j];
+                    best[j] = take ? t9 : best[j];
+                }
+            }
+        }
+        h16x8 r;
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r[j] = (h16)m[j];
+            if (j < 4) lo |= (unsigned)(best[j] & 0xff) << (8 * j); else hi |= (unsigned)(best[j] & 0xff) << (8 * (j - 4));
+        }
+        *reinterpret_cast<uint2*>(idx + (size_t)p * C + oc * 8) = make_uint2(lo, hi);
+        sth8(out + (size_t)p * C + oc * 8, r);
+    }
+}
+
+void launch_hstem_apply_pool(const HBnApplyArgs& a, int B, int H, int W, h16* out, uint8_t* idx, hipStream_t s)
+{
+    const long npix = (long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    long G = (npix + 84) / 85;
+    static const int gmax = getenv("YN_STEMPOOL_G") ? atoi(getenv("YN_STEMPOOL_G")) : 2048;
+    if (G > gmax) G = gmax;
+    hipLaunchKernelGGL(hstem_apply_pool_kernel, dim3((unsigned)(G < 1 ? 1 : G)), dim3(256), 0, s, a, B, H, W, out, idx);
+}
+
+// the max pool's input gradient at pixel (b, iy, ix), channel octet oc: hmaxpool_bwd_kernel's gather (H x W = the pool INPUT), fp16-rounded
+__device__ __forceinline__ h16x8 hpool_gather(const h16* __restrict__ dy, const uint8_t* __restrict__ idx, int b, int iy, int ix, int H, int W, int Ho, int Wo, int Cp, int oc)
+{
+    int oy[2], ox[2]; bool vy[2], vx[2];
+    oy[0] = (iy + 1) >> 1; vy[0] = oy[0] < Ho; oy[1] = oy[0] - 1; vy[1] = (iy & 1) && oy[1] >= 0;
+    ox[0] = (ix + 1) >> 1; vx[0] = ox[0] < Wo; ox[1] = ox[0] - 1; vx[1] = (ix & 1) && ox[1] >= 0;
+    h16x8 g[4];
+    uint2 cd[4];
+    unsigned me[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = u >> 1, f = u & 1;
+        const size_t o = ((size_t)(b * Ho + (vy[e] ? oy[e] : 0)) * Wo + (vx[f] ? ox[f] : 0)) * Cp + oc * 8;
+        g[u] = ldh8(dy + o);
+        cd[u] = *reinterpret_cast<const uint2*>(idx + o);
+        me[u] = (vy[e] && vx[f]) ? (unsigned)((iy - (2 * oy[e] - 1)) * 3 + (ix - (2 * ox[f] - 1))) : 0xffu;
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned c = ((j < 4 ? cd[u].x : cd[u].y) >> (8 * (j & 3))) & 0xffu;
+            acc[j] += c == me[u] ? (float)g[u][j] : 0.0f;
+        }
+    h16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (h16)acc[j];
+    return r;
+}
+
+// a: y / mean / invstd / gamma / beta / act / acc (the BACKWARD sums) / M of the stem's BatchNorm; dz = gather(pool gradient g1, idx)
+template <int PHASE>                                            // 0: the sums -> acc;  1: dy (may be y: in place), dgamma / dbeta
+__global__ __launch_bounds__(256) void hstem_bwd_kernel(HRedArgs a, const h16* __restrict__ g1, const uint8_t* __restrict__ idx, int B, int H, int W,
+                                                         h16* dy, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    constexpr int C = 24, PB = 85;
+    __shared__ float cst[6][32];
+    const double invM = 1.0 / (double)a.M;
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        cst[0][c] = a.mean[c]; cst[1][c] = a.invstd[c]; cst[2][c] = a.gamma[c]; cst[3][c] = a.beta[c];
+        if (PHASE == 1) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < HACC_SLOTS; ++sl) { s0 += a.acc[((size_t)sl * 2) * C + c]; s1 += a.acc[((size_t)sl * 2 + 1) * C + c]; }
+            cst[4][c] = (float)(s0 * invM); cst[5][c] = (float)(s1 * invM);
+            if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+        }
+    }
+    __syncthreads();
+    const int oc = threadIdx.x % 3, pl = threadIdx.x / 3;
+    const bool worker = pl < PB;
+    HStemCst k;
+    hstem_cst_load(cst, oc, k);
+    f32x2 m0[4], m1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        m0[p] = m1[p] = splat2(0.0f);
+        if (PHASE == 1) { const int c = oc * 8 + 2 * p; m0[p].x = cst[4][c]; m0[p].y = cst[4][c + 1]; m1[p].x = cst[5][c]; m1[p].y = cst[5][c + 1]; }
+    }
+    const float negslope = act_negslope(a.act);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long npix = (long)B * H * W;
+    double s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    f32x2 t0[4], t1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { t0[p] = splat2(0.0f); t1[p] = splat2(0.0f); }
+    int batch = 0;
+    if (worker) {
+        for (long pi = (long)blockIdx.x * PB + pl; pi < npix; pi += (long)gridDim.x * PB) {
+            const int ix = (int)(pi % W); const long q = pi / W;
+            const int iy = (int)(q % H), b = (int)(q / H);
+            const h16x8 v = ldh8(a.y + (size_t)pi * C + oc * 8);
+            const h16x8 g = hpool_gather(g1, idx, b, iy, ix, H, W, Ho, Wo, C, oc);
+            h16x8 r;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x2 xh = bn_xhat2(pair_of(v, p), k.mu[p], k.is[p]);
+                const f32x2 d = act_grad2(pair_of(g, p), bn_value2(xh, k.ga[p], k.be[p]), negslope);
+                if (PHASE == 0) { t0[p] += d; t1[p] = __builtin_elementwise_fma(d, xh, t1[p]); }
+                else { const f32x2 o = (k.ga[p] * k.is[p]) * (d - m0[p] - xh * m1[p]); r[2 * p] = (h16)o.x; r[2 * p + 1] = (h16)o.y; }
+            }
+            if (PHASE == 1) sth8(dy + (size_t)pi * C + oc * 8, r);
+            else if (++batch == 4) {                            // fp32 over four pixels, then into the double accumulators (hcol_reduce_kernel's batches)
+                batch = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    s0[2 * p] += (double)t0[p].x; s0[2 * p + 1] += (double)t0[p].y; s1[2 * p] += (double)t1[p].x; s1[2 * p + 1] += (double)t1[p].y;
+                    t0[p] = splat2(0.0f); t1[p] = splat2(0.0f);
+                }
+            }
+        }
+    }
+    if (PHASE == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { s0[2 * p] += (double)t0[p].x; s0[2 * p + 1] += (double)t0[p].y; s1[2 * p] += (double)t1[p].x; s1[2 * p + 1] += (double)t1[p].y; }
+        // the workgroup's 85 pixel lanes -> one double per (sum, channel): fp32 is not enough here (a lane has added ~70 values), so the
+        // lanes are combined in double, through LDS as two floats (hi + lo)
+        __shared__ double dred[PB * 3 * 2];
+        double tot[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { tot[j] = s0[j]; tot[8 + j] = s1[j]; }
+        for (int kk = 0; kk < 16; kk += 2) {                    // two of the 16 values per round: 4 KB of LDS
+            __syncthreads();
+            if (worker) { dred[(pl * 3 + oc) * 2] = tot[kk]; dred[(pl * 3 + oc) * 2 + 1] = tot[kk + 1]; }
+            __syncthreads();
+            if (threadIdx.x < 6) {                              // (octet, which of the two)
+                const int o3 = threadIdx.x >> 1, w = threadIdx.x & 1;
+                double s = 0.0;
+                for (int r2 = 0; r2 < PB; ++r2) s += dred[(r2 * 3 + o3) * 2 + w];
+                const int kidx = kk + w, c = o3 * 8 + (kidx & 7);
+                double* acc = a.acc + (size_t)(blockIdx.x & (HACC_SLOTS - 1)) * 2 * C;
+                atomicAdd(acc + (kidx >> 3) * C + c, s);
+            }
+        }
+    }
+}
+
+void launch_hstem_bwd(const HRedArgs& a, const h16* g1, const uint8_t* idx, int B, int H, int W, h16* dy, float* dgamma, float* dbeta, hipStream_t s)
+{
+    const long npix = (long)B * H * W;
+    static const int g0 = getenv("YN_STEMBWD_G0") ? atoi(getenv("YN_STEMBWD_G0")) : 2048, g1n = getenv("YN_STEMBWD_G1") ? atoi(getenv("YN_STEMBWD_G1")) : 2048;
+    long G = (npix + 84) / 85;
+    const long G0 = G > g0 ? g0 : G, G1 = G > g1n ? g1n : G;
+    hipLaunchKernelGGL(hstem_bwd_kernel<0>, dim3((unsigned)G0), dim3(256), 0, s, a, g1, idx, B, H, W, dy, dgamma, dbeta);
+    hipLaunchKernelGGL(hstem_bwd_kernel<1>, dim3((unsigned)G1), dim3(256), 0, s, a, g1, idx, B, H, W, dy, dgamma, dbeta);
 }
 
 // ---- element-wise glue of the FPN / PAN adds (models/yolo_nano.py:291-296), dense Cp-channel h16 tensors; modes as resample_kernel

@@ -84,6 +84,9 @@ void launch_hstem(const float* x_nchw, int B, int H, int W, const float* w, cons
 void launch_hstem_wgrad(const h16* dy, const float* x_nchw, int B, int H, int W, float* dw_slots, size_t slot_stride, hipStream_t s);
 void launch_hmaxpool_idx(const h16* x, int B, int H, int W, int Cp, h16* y, uint8_t* idx /* window position of the maximum */, hipStream_t s);
 void launch_hmaxpool_bwd(const h16* dy, const uint8_t* idx, int B, int H, int W, int Cp, h16* dx, hipStream_t s);
+// the stem's BatchNorm + activation + max pool fused (no full-resolution normalised tensor, no full-resolution gradient): kernels_h16.hip
+void launch_hstem_apply_pool(const HBnApplyArgs& a, int B, int H, int W, h16* out, uint8_t* idx, hipStream_t s);
+void launch_hstem_bwd(const HRedArgs& a, const h16* pool_grad, const uint8_t* idx, int B, int H, int W, h16* dy, float* dgamma, float* dbeta, hipStream_t s);
 void launch_hresample(const h16* a, const h16* b, h16* out, int B, int H, int W, int Cp, int mode, hipStream_t s);
 void launch_hgather(const h16* src, int src_ld, int src_off, int src_cs, int src_half, int src_gap,
                     h16* dst, int dst_ld, int dst_off, int dst_cs, int dst_half, int dst_gap, long M, int n, int npad, hipStream_t s);
