@@ -288,6 +288,10 @@ int  yn_allreduce_grads(yn_handle* h, void* nccl_comm);
  * raw NHWC head tensors as dense float32 [B,S/8,S/8,A(5+C)], [B,S/16,..], [B,S/32,..].  Parity hook for the train-mode network. */
 int  yn_train_forward(yn_handle* h, const float* x_dev, int B, float* head_s8_dev, float* head_s16_dev, float* head_s32_dev);
 int  yn_train_skipped_steps(yn_handle* h, int64_t* count_host);
+/* The fp16 step forks the head towers of levels 3 / 4 onto streams of their own when that measured faster on this device (a handle's
+ * steps 3-6 time the step both ways, so the choice - and with it the order of some atomic sums - depends on the machine).  Query the
+ * decision (force = 0; *decision: -1 undecided, 0 one stream, 1 forked) or pin it for reproducible runs (force = 1: one stream, 2: forked). */
+int  yn_train_head_fork(yn_handle* h, int force, int* decision_host);
 /* Arithmetic of yn_train_step (BASELINE configs[2] names fp16; train.py itself runs fp32).  YN_F32 (default): fp32 end to end.
  * YN_F16: activations and activation gradients are STORED as fp16 (channel-padded NHWC, half the HBM bytes), every GEMM-shaped
  * conv (forward, input gradient, weight gradient) runs on the f16 MFMA with fp32 accumulation, BatchNorm statistics / parameter

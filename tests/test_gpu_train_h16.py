@@ -347,6 +347,65 @@ def test_h16_step_matches_fp32_step_on_a_shallow_path(golden):
         assert cos > 0.98, (k, cos)
 
 
+@pytest.mark.parametrize("S,B", [(128, 8), (160, 3)])
+def test_h16_fused_stem_is_the_separate_launches(golden, monkeypatch, S, B):
+    """Round 4: the stem's BatchNorm + activation + max pool run as ONE kernel (the full-resolution normalised tensor is never stored) and the
+    backward pass forms the full-resolution gradient - the max pool's gather - where it is consumed (hstem_apply_pool_kernel, hstem_bwd_kernel).
+    Every value keeps its rounding points, so against the separate launches (YN_TRAIN_STEM_FUSE=0: hbn_apply + hmaxpool_idx, hmaxpool_bwd +
+    hcol_reduce + hbn_bwd) the step is the same to the order of its atomic sums: the losses and every gradient at 1e-5 (the bar the step
+    holds against its own repetition), the stem's own parameter gradients - the only ones that see the re-ordered backward sums - at 1e-4.
+    160 x 160: an odd 40 x 40 -> 20 x 20 pool geometry with border windows on every side, batch 3: a ragged last pixel block."""
+    g = golden("train.npz")
+    C = 20
+    x = torch.as_tensor(weights.make_input(B, S, seed=31)).cuda()
+    t = torch.as_tensor(_targets(S, C, B, seed=32)).cuda()
+    h, _ = _handle(S, C, B, float(g["init_bias_value"]))
+    h.train_precision("f16")
+    out = {}
+    for fuse in ("1", "0", "1"):
+        monkeypatch.setenv("YN_TRAIN_STEM_FUSE", fuse)
+        losses = h.train_step(x, t, update=False).cpu().numpy()
+        out.setdefault(fuse, []).append((losses, h.flat_grads.clone()))
+    monkeypatch.delenv("YN_TRAIN_STEM_FUSE")
+    (l1, g1), (l1b, g1b) = out["1"]
+    l0, g0 = out["0"][0]
+    gmax = float(g0.abs().max())
+    np.testing.assert_allclose(l1b, l1, rtol=1e-5)                       # the bar: the fused step against itself
+    assert float((g1b - g1).abs().max()) <= 1e-5 * gmax
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    stem = ("backbone.conv1.0.weight", "backbone.conv1.1.weight", "backbone.conv1.1.bias")
+    mask = torch.ones_like(g0, dtype=torch.bool)
+    for k in stem:
+        mask[h.param_slice(k)] = False
+    assert float(((g1 - g0).abs() * mask).max()) <= 1e-5 * gmax
+    assert float((g1 - g0).abs().max()) <= 1e-4 * gmax
+    h.close()
+
+
+def test_h16_head_fork_decision_can_be_read_and_pinned(golden):
+    """yn_train_head_fork: the fp16 step decides from its own timing (steps 3-6) whether the head towers of levels 3 / 4 run on fork
+    streams - a machine-dependent choice.  It can be read (-1 until decided) and pinned either way; the two forms of the step agree to the
+    order of their atomic sums."""
+    g = golden("train.npz")
+    S, C, B = 128, 20, 4
+    x = torch.as_tensor(weights.make_input(B, S, seed=41)).cuda()
+    t = torch.as_tensor(_targets(S, C, B, seed=42)).cuda()
+    h, _ = _handle(S, C, B, float(g["init_bias_value"]))
+    h.train_precision("f16")
+    assert h.head_fork() == -1
+    res = {}
+    for pin in (False, True, False):
+        assert h.head_fork(pin) == int(pin)
+        for _ in range(3):                                                # (the first steps of a handle allocate; the fork streams exist from the third)
+            losses = h.train_step(x, t, update=False).cpu().numpy()
+        assert h.head_fork() == int(pin)
+        res.setdefault(pin, (losses, h.flat_grads.clone()))
+    (l0, g0), (l1, g1) = res[False], res[True]
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    h.close()
+
+
 def test_h16_loss_scale_overflow_is_skipped_and_backed_off(golden, monkeypatch):
     """An absurd initial loss scale overflows the fp16 gradients: the step's bucket is non-finite, yn_sgd_step skips it, the scale
     is halved on the device each time, and training proceeds once it fits — no host round trip decides any of this."""

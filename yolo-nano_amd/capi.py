@@ -79,6 +79,7 @@ SIGNATURES = {
     "yn_read_param": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_int64]),
     "yn_train_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "yn_train_skipped_steps": (_i32, [_vp, _i64p]),
+    "yn_train_head_fork": (_i32, [_vp, _i32, ctypes.POINTER(ctypes.c_int)]),
     "yn_train_precision": (_i32, [_vp, _i32]),
     "yn_train_graph": (_i32, [_vp, _i32, _vp]),
     "yn_train_get_loss_scale": (_i32, [_vp, ctypes.POINTER(_f32), ctypes.POINTER(_f32)]),
@@ -585,6 +586,12 @@ class Handle:
         n = ctypes.c_int64(0)
         self._ck(self.lib.yn_train_skipped_steps(self.h, ctypes.byref(n)), "yn_train_skipped_steps")
         return int(n.value)
+
+    def head_fork(self, force=None):
+        """The fp16 step's head-tower fork decision (yn_train_head_fork): None = query, False / True = pin it.  -> -1 undecided, 0, 1."""
+        d = ctypes.c_int(-1)
+        self._ck(self.lib.yn_train_head_fork(self.h, 0 if force is None else (2 if force else 1), ctypes.byref(d)), "yn_train_head_fork")
+        return int(d.value)
 
     def param_slice(self, key):
         off, num = ctypes.c_int64(), ctypes.c_int64()
