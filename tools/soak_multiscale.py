@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_train as T                                     # noqa: E402
 
-runs = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 8          # (a run takes 20-70 s of host time for its float64 oracles: 20 + 20 runs overran a 40-minute box)
 g = np.load(os.path.join(ROOT, "tests", "golden", "train.npz"), allow_pickle=True)
 for precision in ("f32", "f16"):
     k_mul, k_abs = T.MS_BAR[precision]
