@@ -1069,6 +1069,26 @@ def test_down_unit_is_bit_identical(capi, backbone, C, S, B):
     h.close()
 
 
+@pytest.mark.parametrize("S,B", [(416, 3), (320, 2), (224, 1)])
+def test_tile_walking_kernels_are_bit_identical_to_one_tile_per_workgroup(S, B):
+    """Round 4: `down_unit_pipe_kernel` and `dwpw_pipe_group_kernel` walk tiles with register-resident weights; the forms they replace
+    (one tile per workgroup, weights through LDS) are kept behind YN_DOWN_PIPE=0 / YN_DWPW_PIPE=0 - switches a process reads once, so the
+    comparison runs tools/ab_hash.py in two child processes: raw heads and detections of one seeded call, byte for byte.  320: head maps of
+    40 / 20 / 10 pixels (ragged 8 x 4 tiles at every level), 224: 28 / 14 / 7."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for env in ({}, {"YN_DOWN_PIPE": "0", "YN_DWPW_PIPE": "0"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_hash.py"), str(S), str(B)], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append([ln for ln in r.stdout.splitlines() if ln.startswith("hash ")][-1])
+    assert lines[0] == lines[1] and int(lines[0].split()[5]) > 0, lines
+
+
 def _rel_rms(y, ref):
     return float(np.sqrt(((y.astype(np.float64) - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
 

@@ -2126,6 +2126,148 @@ __global__ __launch_bounds__(256, (TH == 4 ? 3 : 2)) void dwpw_group_kernel(Grou
     dwpw_block<TH>(g.a[p], reinterpret_cast<uch16*>(dwpw_smem), local, nb);
 }
 
+// -------------------------------------------------------------------------------------------------
+// dwpw_block as a tile walk (round 4, after down_unit_pipe_kernel): 192 threads (the fourth wavefront of dwpw_block only helped staging
+// the weight matrix), the 96 x 96 split weights register-resident (a lane's B fragments of its wavefront's 32 columns: 48 registers, loaded
+// once per workgroup - nothing of them in LDS: 50 -> 13 KB), a workgroup walks ~3 tiles (XCD-contiguous) and requests the next tile's
+// depthwise windows right behind the barrier that ends the depthwise phase - the round trip runs under the GEMM and the stores.  Same
+// arithmetic in the same order: bit-identical (test_dwpw_fused_is_bit_identical).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dwpw_pipe_block(const DwPwArgs& a, uch16* smem, unsigned bid, unsigned nblocks)
+{
+    constexpr int TW = 8, TH = 4, NO = TW * TH, C = 96, KQ = C / 8, KS = KQ / 2, AST = C + 8, R = 4;
+    uch16* Ah = smem;                                       // [NO][AST]
+    uch16* Al = Ah + NO * AST;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+    const int tx_n = (a.W + TW - 1) / TW, ty_n = (a.H + TH - 1) / TH, per_img = tx_n * ty_n;
+    const int tiles = a.B * per_img;
+    const int TL = (tiles + 7) >> 3, GL = (int)(nblocks >> 3);
+    const int tbase = (int)(bid & 7u) * TL;
+    int tl = (int)(bid >> 3);
+    if (tl >= TL || tbase + tl >= tiles) return;
+
+    // ---- loop invariants: the thread's depthwise taps and bias, the B fragments and bias of its GEMM columns --------------------------
+    const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs of 4 pixels (2 per tile row) = 192 workers
+    const int c = cq * 4, ry = run >> 1, rx = (run & 1) * R;
+    float4 wd[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(a.wdw + k * C + c);
+    const float4 bd = *reinterpret_cast<const float4*>(a.bdw + c);
+    uch16x8 gh[KS], gl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const size_t off = ((size_t)(ks * 2 + h) * a.Npad + wave * 32 + l31) * 8;
+        gh[ks] = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(a.Wh) + off);
+        gl[ks] = *reinterpret_cast<const uch16x8*>(reinterpret_cast<const uch16*>(a.Wl) + off);
+    }
+    const float gbias = a.bias[wave * 32 + l31];
+    float4 win[3][R + 2];
+    unsigned wok = 0;                                       // validity of the 18 window positions of the pending request
+    const char* xbase = reinterpret_cast<const char*>(a.in);
+    auto request = [&](int tile) {
+        const int b = tile / per_img, trem = tile - b * per_img;
+        const int oy = (trem / tx_n) * TH + ry, ox = (trem % tx_n) * TW + rx;
+        wok = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+            const bool yok = oy < a.H && iy >= 0 && iy < a.H;
+#pragma unroll
+            for (int j = 0; j < R + 2; ++j) {
+                const int ix = ox - 1 + j;
+                const bool ok = yok && ix >= 0 && ix < a.W;
+                // raw value from a clamped address, zeroed where it is consumed (a mask applied here would wait for the load here)
+                win[ky][j] = *reinterpret_cast<const float4*>(xbase + (unsigned)(ok ? ((b * a.H + iy) * a.W + ix) * C + c : c) * 4u);
+                wok |= (ok ? 1u : 0u) << (ky * (R + 2) + j);
+            }
+        }
+    };
+    request(tbase + tl);
+    float amax = 0.0f;                                      // range guard (yn_device.h)
+    const int j4 = lane & 3;
+    const int nq = wave * 32 + (l31 & ~3);
+
+    for (;;) {
+        const int tile = tbase + tl;
+        const int b = tile / per_img, trem = tile - b * per_img;
+        const int oy0 = (trem / tx_n) * TH, ox0 = (trem % tx_n) * TW;
+        // ---- 1. depthwise (dwconv3x3_kernel's chain) -> split planes ---------------------------------------------------------------
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < R + 2; ++j) win[ky][j] = vmask(win[ky][j], 0u - ((wok >> (ky * (R + 2) + j)) & 1u));
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            float4 acc = bd;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) vfma(acc, win[ky][o + kx], wd[ky * 3 + kx]);
+            acc = vact(acc, a.dw_act);
+            const int op = ry * TW + rx + o;
+            const float x4[4] = {acc.x, acc.y, acc.z, acc.w};
+            uch16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { amax = range_track(amax, x4[j]); hi[j] = (uch16)x4[j]; lo[j] = (uch16)((x4[j] - (float)hi[j]) * 2048.0f); }
+            *reinterpret_cast<uch16x4*>(Ah + op * AST + c) = hi;
+            *reinterpret_cast<uch16x4*>(Al + op * AST + c) = lo;
+        }
+        __syncthreads();
+        const bool more = tl + GL < TL && tbase + tl + GL < tiles;
+        if (more) request(tbase + tl + GL);                 // the next tile's windows fly under the GEMM and the stores
+
+        // ---- 2. pointwise conv: 32 x 32 per wavefront, K = 96 in gemm_split_tile's order; bias, activation, 16-byte stores -------------
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+        const uch16* Ahb = Ah + l31 * AST + h * 8;
+        const uch16* Alb = Al + l31 * AST + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ahb + ks * 16);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>(Alb + ks * 16);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[ks], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[ks], acc1, 0, 0, 0);
+        }
+        // tile pixel of accumulator group g, lane (h, j4): row g, column 4 h + j4 - a wave-uniform row offset + one lane offset, 32-bit
+        char* obase = reinterpret_cast<char*>(a.out);
+        const unsigned lane_off = (unsigned)(((b * a.H + oy0) * a.W + ox0 + 4 * h + j4) * C + nq) * 4u;
+        const bool xin = ox0 + 4 * h + j4 < a.W;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = apply_act(__builtin_fmaf(acc1[4 * g + 0], 1.0f / 2048.0f, acc0[4 * g + 0]) + gbias, a.act);
+            float v1 = apply_act(__builtin_fmaf(acc1[4 * g + 1], 1.0f / 2048.0f, acc0[4 * g + 1]) + gbias, a.act);
+            float v2 = apply_act(__builtin_fmaf(acc1[4 * g + 2], 1.0f / 2048.0f, acc0[4 * g + 2]) + gbias, a.act);
+            float v3 = apply_act(__builtin_fmaf(acc1[4 * g + 3], 1.0f / 2048.0f, acc0[4 * g + 3]) + gbias, a.act);
+            {   // 2x2 blocks, then 4x4: lane j of the quad ends up with row j x 4 columns (gemm_epilogue's transpose)
+                const float s0 = (j4 & 1) ? v0 : v1, s1 = (j4 & 1) ? v2 : v3;
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
+                if (j4 & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            }
+            {
+                const float s0 = (j4 & 2) ? v0 : v2, s1 = (j4 & 2) ? v1 : v3;
+                const float r0 = quad_xor2(s0), r1 = quad_xor2(s1);
+                if (j4 & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
+            }
+            if (oy0 + g < a.H && xin)
+                *reinterpret_cast<float4*>(obase + (lane_off + (unsigned)(g * a.W * C) * 4u)) = make_float4(v0, v1, v2, v3);
+        }
+        if (!more) break;
+        tl += GL;
+        __syncthreads();                                    // every wavefront is done with the planes
+    }
+    range_report(a.ovf, amax);
+}
+
+__global__ __launch_bounds__(192, 2) void dwpw_pipe_group_kernel(Group<DwPwArgs> g)
+{
+    extern __shared__ __attribute__((aligned(16))) float dwpw_smem[];
+    unsigned local, nb;
+    const int p = group_problem(g.first, blockIdx.x, local, nb);
+    dwpw_pipe_block(g.a[p], reinterpret_cast<uch16*>(dwpw_smem), local, nb);
+}
+
 bool dwpw_group_ok(const DwPwArgs* a, int n)
 {
     if (n < 1 || n > YN_GROUP_MAX) return false;
@@ -2143,6 +2285,24 @@ void launch_dwpw_group(const DwPwArgs* a, int n, hipStream_t s)
     const int TH = th_env == 8 ? 8 : 4;                     // 64-pixel tiles (half the weight traffic) measured the same end to end, 43 vs 39 us alone: YN_DWPW_TH=8 keeps them for A/B runs
     Group<DwPwArgs> g{};
     unsigned tot = 0;
+    // the tile-walking form (8 x 4 tiles only; YN_DWPW_PIPE=0: one tile per workgroup; YN_DWPW_PIPE_T: tiles per walking workgroup)
+    static const int pipe = getenv("YN_DWPW_PIPE") ? atoi(getenv("YN_DWPW_PIPE")) : 1;
+    static const int pipe_t = getenv("YN_DWPW_PIPE_T") ? atoi(getenv("YN_DWPW_PIPE_T")) : 3;
+    if (pipe && TH == 4) {
+        bool fits = true;
+        for (int p = 0; p < n; ++p) fits = fits && (size_t)a[p].B * a[p].H * a[p].W * 96 < ((size_t)1 << 30);      // 32-bit byte offsets
+        if (fits) {
+            const unsigned per = (unsigned)(pipe_t > 0 ? pipe_t : 1);
+            for (int p = 0; p < YN_GROUP_MAX; ++p) {
+                g.first[p] = tot;
+                if (p < n) { g.a[p] = a[p]; const unsigned tiles = (unsigned)a[p].B * ((a[p].H + 3) / 4) * ((a[p].W + 7) / 8); tot += xcd_grid((tiles + per - 1) / per); }
+            }
+            g.first[YN_GROUP_MAX] = tot;
+            set_last_kernel_name("dwpw_pipe_group_kernel");
+            hipLaunchKernelGGL(dwpw_pipe_group_kernel, dim3(tot), dim3(192), (size_t)2 * 32 * 104 * 2, s, g);
+            return;
+        }
+    }
     for (int p = 0; p < YN_GROUP_MAX; ++p) {
         g.first[p] = tot;
         if (p < n) { g.a[p] = a[p]; tot += xcd_grid((unsigned)a[p].B * ((a[p].H + TH - 1) / TH) * ((a[p].W + 7) / 8)); }

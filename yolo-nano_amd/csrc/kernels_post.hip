@@ -13,6 +13,11 @@
 namespace ynk {
 
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+// exp(x) for the class softmax's x = logit - max <= 0: one multiply + v_exp_f32 instead of expf's ~15 instructions (range reduction, ldexp, overflow /
+// denormal selects - none of which x <= 0 needs: a result below 2^-126 adds nothing to a sum >= 1).  80 of these per candidate were a third of
+// head_tail_group_kernel's class pass, and that kernel is VALU-issue bound.  exp_le0(0) == 1 exactly (the arg-max rule relies on it); the
+// error against expf is <= 2 ulp near 0 and <= |x| * 1e-7 relative for the far classes - 1e-6 on a score, two orders inside the parity tolerance (1e-4).
+__device__ __forceinline__ float exp_le0(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 __device__ __forceinline__ void cand_location(const GridInfo& g, int n, int& s, int& cell, int& a)
 {
@@ -131,7 +136,7 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
 #pragma unroll
     for (int k = KMAX - 1; k >= 0; --k) {
         const int c = j + 16 * k;
-        v[k] = c < g.C ? expf(v[k] - mx) : 0.0f;
+        v[k] = c < g.C ? exp_le0(v[k] - mx) : 0.0f;
         if (v[k] == 1.0f) first = c;                                      // descending k: ends at this lane's lowest such class
         general = general | ((v[k] < 1.0f) & (v[k] > 0.99999f));           // bitwise: the short-circuit form compiled to an exec-mask branch per class slot
     }

@@ -584,10 +584,12 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
     const int bf = C / 2;
     const long M = (long)B * H * W;
     // Stages 2 and 3 (bf <= 128) chain at every size: on one image's maps the 32-row tiles of unit_chain2_kernel run a unit in 12 - 16 us
-    // against 8 + 6 + 8 for its three kernels (bs = 1: 0.620 -> 0.585 ms at 416 x 416, 0.757 -> 0.719 ms at 608 x 608).  Stage 4 (bf = 232: eight
-    // weight chunks per GEMM) chains from M = 4 096 pixels: 36 + 34 + 22 us against 3 x 40 at bs = 32 416 x 416 (M = 5 408), but 32 + 30 + 19
-    // against 3 x 29 on one image.  unit_chain == 2 (tests) skips the size rule.
-    static const long min4 = getenv("YN_CHAIN_MIN4") ? atol(getenv("YN_CHAIN_MIN4")) : 4096;       // A/B: smallest M that chains the bf > 128 stage
+    // against 8 + 6 + 8 for its three kernels (bs = 1: 0.620 -> 0.585 ms at 416 x 416, 0.757 -> 0.719 ms at 608 x 608).  Stage 4 (bf = 232) chained
+    // from M = 4 096 pixels only while the chain kernel staged its weights through LDS (eight chunk rounds per GEMM: 32 + 30 + 19 us against 3 x 29 on
+    // one image).  With the weights register-direct (round 4) the chain costs one image what its three launches did (0.5245 vs 0.5227 ms at 416,
+    // 0.653-0.660 either way at 608; bs 2 / 4 / 8 / 16: 0.554 / 0.622 / 0.714 / 0.847 vs 0.548 / 0.617 / 0.718 / 0.850 ms) and is six launches
+    // less: it chains at every size now (YN_CHAIN_MIN4=<M> restores a threshold).
+    static const long min4 = getenv("YN_CHAIN_MIN4") ? atol(getenv("YN_CHAIN_MIN4")) : 0;       // A/B: smallest M that chains the bf > 128 stage
     if (h->unit_chain != 2 && bf > 128 && M < min4) return 0;
     char nm[96];
     auto name = [&](int bi) { snprintf(nm, sizeof nm, "backbone.stage%d.%d", stage, bi); return std::string(nm); };
