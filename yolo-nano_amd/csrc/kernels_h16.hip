@@ -1088,9 +1088,10 @@ __global__ __launch_bounds__(256) void hbn_apply_kernel(HBnApplyArgs a)
 static int hstream_blocks(long M, int rowsPer)
 {
     long b = (M + (long)rowsPer * 4 - 1) / ((long)rowsPer * 4);
-    // three workgroups per CU: every workgroup of these launches first adds up the HACC_SLOTS double copies of its layer's sums (60 KB for 116
-    // channels), so the prologue traffic grows with the grid - 7.79 ms per 608 / bs-32 step at 1 536 workgroups, 7.68 at 768 and at 512
-    static const int cap = getenv("YN_STREAM_CAP") ? atoi(getenv("YN_STREAM_CAP")) : 256 * 3;
+    // two workgroups per CU: every workgroup of these launches first adds up the HACC_SLOTS double copies of its layer's sums (30 KB for 116
+    // channels at 16 copies), so the prologue traffic grows with the grid - with 32 copies 7.79 ms per 608 / bs-32 step at 1 536 workgroups, 7.68 at
+    // 768 and at 512; with 16 copies 7.42 / 7.37 / 7.29 / 7.25 / 7.25 / 7.26 ms at 1 536 / 1 024 / 768 / 512 / 384 / 256
+    static const int cap = getenv("YN_STREAM_CAP") ? atoi(getenv("YN_STREAM_CAP")) : 256 * 2;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;

@@ -6,8 +6,13 @@ namespace ynk {
 
 typedef _Float16 h16;
 // copies of every BatchNorm sum accumulator the fp16 step spreads its atomics over (same-address fp64 atomics serialise at the
-// memory side: with 8 copies and 512 blocks the tail of a reduction was longer than its streaming phase)
-constexpr int HACC_SLOTS = 32;
+// memory side: with 8 copies and 512 blocks the tail of a reduction was longer than its streaming phase).  Every workgroup of the
+// BatchNorm apply / backward launches adds the copies up again in its prologue, so more copies are not free either: 32 / 16 / 8 copies =
+// 7.42 / 7.29 / 7.32 ms per 608 x 608 bs-32 step (round 4, with the reductions at 256 workgroups and most sums taken in conv epilogues).
+#ifndef YN_HACC_SLOTS
+#define YN_HACC_SLOTS 16
+#endif
+constexpr int HACC_SLOTS = YN_HACC_SLOTS;
 
 // Column sums of an hgemm output tile, taken in the kernel's epilogue while the tile sits in LDS (one launch and one pass over the
 // tensor less per BatchNorm and direction):
