@@ -456,19 +456,153 @@ __global__ __launch_bounds__(1024) void hwgrad_reduce_kernel(const float* __rest
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// hwgrad_kernel with WIDER wave tiles (round 4): a wavefront owns 32 TN dY columns x 32 TK X columns, so every gathered fragment (eight
+// 2-byte LDS reads) feeds TK (TN) MFMAs instead of one - 8 gathers per MFMA at <2, 2> against 16 - and a 128 x 128 block covers a 116- /
+// 120-channel layer's whole dW: dY and X are read once per slice, not twice.  Timing experiment that pointed here: the fp16 step without its
+// GEMM-shaped weight-gradient launches runs in 6.51 ms against 7.28 - the side stream's 1.9 ms of them cost the critical path 0.77 ms.
+// Same partial layout as hwgrad_kernel ([slice][n][tap][k_phys] -> hwgrad_reduce_kernel).
+// -------------------------------------------------------------------------------------------------
+template <int TAPS, int TN, int TK>
+__global__ __launch_bounds__(256) void hwgrad2_kernel(HWgradArgs a)
+{
+    constexpr int MT = 64, NB = 64 * TN, KB = 64 * TK;
+    constexpr int STD = NB + 2, STX = KB + 2;                          // LDS row strides (halves): odd dword strides => column gathers spread over banks
+    constexpr int DOCT = NB / 8, XOCT = KB / 8;                        // 16-byte pieces per tile row
+    constexpr int DPER = MT * DOCT / 256, XPER = MT * XOCT / 256;      // pieces per thread and tile (2 / 4)
+    __shared__ __attribute__((aligned(16))) h16 Ds[MT * STD];
+    __shared__ __attribute__((aligned(16))) h16 Xs[MT * STX];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave & 1, wk = wave >> 1;
+    const int n0 = blockIdx.x * NB;
+    const int kblocks = (a.Kp + KB - 1) / KB;
+    const int tap = TAPS == 9 ? blockIdx.y / kblocks : 0;
+    const int k0 = (blockIdx.y - tap * kblocks) * KB;
+    const int dyy = TAPS == 9 ? tap / 3 - 1 : 0, dxx = TAPS == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int slices = gridDim.z;
+    const int rows = (((a.M + slices - 1) / slices) + MT - 1) / MT * MT;
+    const int m_begin = blockIdx.z * rows, m_end = min(a.M, m_begin + rows);
+    // column tiles of this wavefront that hold real columns (a 96-channel layer under a 128-wide block: the upper tiles are skipped)
+    bool ton[TN], tok[TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) ton[i] = n0 + (wn * TN + i) * 32 < a.Np;
+#pragma unroll
+    for (int i = 0; i < TK; ++i) tok[i] = k0 + (wk * TK + i) * 32 < a.Kp;
+    f32x16 acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    h16x8 dreg[DPER], xreg[XPER];
+    auto prefetch = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < DPER; ++i) {
+            const int g = t + 256 * i;
+            const int m = mt + g / DOCT, nn = n0 + (g % DOCT) * 8;
+            const bool ok = m < m_end && nn < a.Np;
+            dreg[i] = keep8(ldh8(a.dy + (size_t)(m < m_end ? m : m_begin) * a.dy_ld + (nn < a.Np ? nn : 0)), ok);
+        }
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int g = t + 256 * i;
+            const int m = mt + g / XOCT, kk = k0 + (g % XOCT) * 8;
+            const int mc = m < m_end ? m : m_begin;
+            bool ok = m < m_end && kk < a.Kp;
+            int src = mc;
+            if (TAPS == 9) {
+                const int rem = mc % (a.H * a.W);
+                const int y = rem / a.W + dyy, x = rem - (rem / a.W) * a.W + dxx;
+                const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+                ok = ok && in;
+                src = in ? mc + dyy * a.W + dxx : mc;
+            }
+            xreg[i] = keep8(ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0)), ok);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < DPER; ++i) {
+            const int g = t + 256 * i;
+            h16x2* d = reinterpret_cast<h16x2*>(Ds + (g / DOCT) * STD + (g % DOCT) * 8);      // the stride is not a multiple of 8 halves: four 4-byte pieces
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h16x2 v; v[0] = dreg[i][2 * j]; v[1] = dreg[i][2 * j + 1]; d[j] = v; }
+        }
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int g = t + 256 * i;
+            h16x2* x = reinterpret_cast<h16x2*>(Xs + (g / XOCT) * STX + (g % XOCT) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h16x2 v; v[0] = xreg[i][2 * j]; v[1] = xreg[i][2 * j + 1]; x[j] = v; }
+        }
+    };
+    if (m_begin < m_end) {
+        prefetch(m_begin);
+        for (int mt = m_begin; mt < m_end; mt += MT) {
+            __syncthreads();                                            // previous tile fully consumed
+            stage();
+            __syncthreads();
+            if (mt + MT < m_end) prefetch(mt + MT);
+#pragma unroll
+            for (int ks = 0; ks < MT / 16; ++ks) {
+                const int mrow = ks * 16 + hh * 8;
+                h16x8 av[TN], bv[TK];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[i][j] = Ds[(mrow + j) * STD + (wn * TN + i) * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TK; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[i][j] = Xs[(mrow + j) * STX + (wk * TK + i) * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j)
+                        if (ton[i] && tok[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // acc[i][j][r]: dY column n = n0 + (wn TN + i) 32 + (r&3) + 8 (r>>2) + 4 hh, X column k = k0 + (wk TK + j) 32 + l31
+    float* out = a.partial + (size_t)blockIdx.z * ((size_t)a.Np * a.Kp * TAPS);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + (wk * TK + j) * 32 + l31;
+            if (k >= a.Kp) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (n < a.Np) out[((size_t)n * TAPS + tap) * a.Kp + k] = acc[i][j][r];
+            }
+        }
+}
+
 void launch_hwgrad(const HWgradArgs& a, hipStream_t s)
 {
-    const int gn = (a.Np + 63) / 64, gk = (a.Kp + 63) / 64 * a.taps;
-    static const int wg_blocks = getenv("YN_WG_BLOCKS") ? atoi(getenv("YN_WG_BLOCKS")) : 1024;
+    // wider wave tiles where the layer has the columns for them (YN_WG_WIDE=0: the 64 x 64 blocks everywhere)
+    static const int wide = getenv("YN_WG_WIDE") ? atoi(getenv("YN_WG_WIDE")) : 1;
+    const int TN = (wide && a.Np > 64) ? 2 : 1, TK = (wide && a.Kp > 64) ? 2 : 1;
+    const int gn = (a.Np + 64 * TN - 1) / (64 * TN), gk = (a.Kp + 64 * TK - 1) / (64 * TK) * a.taps;
+    static const int wg_blocks = getenv("YN_WG_BLOCKS") ? atoi(getenv("YN_WG_BLOCKS")) : 2048;
     int slices = wg_blocks / (gn * gk);
     if (slices > 512) slices = 512;
-    const int max_slices = (a.M + 511) / 512;
+    static const int slice_rows = getenv("YN_WG_SLICE_ROWS") ? atoi(getenv("YN_WG_SLICE_ROWS")) : 512;
+    const int max_slices = (a.M + slice_rows - 1) / slice_rows;
     if (slices > max_slices) slices = max_slices;
     const long nk = (long)a.Np * a.Kp * a.taps;
     if ((long)slices * nk > (long)a.partial_cap) slices = (int)((long)a.partial_cap / nk);
     if (slices < 1) slices = 1;
-    if (a.taps == 9) hipLaunchKernelGGL(hwgrad_kernel<9>, dim3(gn, gk, slices), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(hwgrad_kernel<1>, dim3(gn, gk, slices), dim3(256), 0, s, a);
+    const dim3 grid(gn, gk, slices);
+#define YN_WG2(taps_, tn, tk) hipLaunchKernelGGL((hwgrad2_kernel<taps_, tn, tk>), grid, dim3(256), 0, s, a)
+    if (TN == 2 && TK == 2) { if (a.taps == 9) YN_WG2(9, 2, 2); else YN_WG2(1, 2, 2); }
+    else if (TN == 2) { if (a.taps == 9) YN_WG2(9, 2, 1); else YN_WG2(1, 2, 1); }
+    else if (TK == 2) { if (a.taps == 9) YN_WG2(9, 1, 2); else YN_WG2(1, 1, 2); }
+    else if (a.taps == 9) hipLaunchKernelGGL(hwgrad_kernel<9>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hwgrad_kernel<1>, grid, dim3(256), 0, s, a);
+#undef YN_WG2
     const long total = (long)a.N * a.taps * a.Kp;
     hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, a.partial, slices, a.Np, a.Kp, a.taps,
                        a.N, a.Cin, a.half, a.gap, a.dw);
