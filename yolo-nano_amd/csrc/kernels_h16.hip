@@ -1557,6 +1557,11 @@ void launch_hstem(const float* x, int B, int H, int W, const float* w, const flo
 // channels over the pixels pg, pg + 3, ... from LDS: one x value and 8 dy values per 8 FMAs.  (First version: the same thread roles
 // reading straight from global — 81 threads x 2 loads per pixel, 27-fold redundant: 725 us at 608 x 608, bs 32, at the very end of
 // the backward pass where nothing overlaps it.)
+// MFMA = true (round 4): the accumulation loop - 66 LDS reads and 176 FMAs per thread and 64-pixel chunk, ~70 us of the kernel's 170 at the very end
+// of the step - as dW[24 -> 32][27 -> 32] = dy^T x patch on the f16 MFMA: wavefront w takes the 16 pixels of k-step w of the chunk, gathers its
+// dy fragment (exact: dy IS fp16) and its patch fragment from the same LDS tiles, splits the fp32 patch values into hi + lo * 2^-11 (two MFMAs,
+// 2^-22 relative against the fp32 product) and keeps one 32 x 32 accumulator pair; the four wavefronts' tiles are added through LDS at the end.
+template <bool MFMA>
 __global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict__ dy, const float* __restrict__ x, int B, int H, int W,
                                                            float* __restrict__ dw /* slots, reference layout [24][3][3][3] */, size_t slot_stride)
 {
@@ -1617,13 +1622,31 @@ __global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict_
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    const int lane = t & 63, wave = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    f32x16 m0, m1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { m0[k] = 0.0f; m1[k] = 0.0f; }
     if (begin < end) fetch(begin);
     for (long base = begin; base < end; base += P) {
         __syncthreads();                                    // the previous chunk has been consumed
         stage();
         __syncthreads();
         if (base + P < end) fetch(base + P);
-        if (live) {
+        if (MFMA) {
+            // k-step `wave` of the chunk: pixels p0 .. p0 + 7 of this half-wave; lane = (dy channel | patch element) l31
+            const int p0 = wave * 16 + hh * 8;
+            h16x8 av, bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gv = l31 < 24 ? gs[(p0 + j) * 24 + l31] : 0.0f;
+                const float xv = l31 < 27 ? xs[(p0 + j) * 27 + l31] : 0.0f;
+                av[j] = (h16)gv;
+                const h16 hi = (h16)xv;
+                bh[j] = hi; bl[j] = (h16)((xv - (float)hi) * 2048.0f);
+            }
+            m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl, m1, 0, 0, 0);
+        } else if (live) {
 #pragma unroll 2
             for (int p = pg; p < P; p += 3) {
                 const float xv = xs[p * 27 + r];
@@ -1634,6 +1657,26 @@ __global__ __launch_bounds__(256) void hstem_wgrad_kernel(const h16* __restrict_
                 acc[6] = __builtin_fmaf(xv, g1.z, acc[6]); acc[7] = __builtin_fmaf(xv, g1.w, acc[7]);
             }
         }
+    }
+    if (MFMA) {
+        // m[k]: dy channel n = (k & 3) + 8 (k >> 2) + 4 hh, patch element l31; the four wavefronts' tiles through `red` ([256][8] floats) in two halves
+        float* rf = &red[0][0];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rf[(wave * 64 + lane) * 8 + k] = __builtin_fmaf(m1[half * 8 + k], 1.0f / 2048.0f, m0[half * 8 + k]);
+            __syncthreads();
+            if (wave == 0 && l31 < 27 && begin < end) {
+                float* out = dw + (size_t)(blockIdx.x & (GRAD_SLOTS - 1)) * slot_stride;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = half * 8 + k, n = (kk & 3) + 8 * (kk >> 2) + 4 * hh;
+                    if (n < 24) atomicAdd(out + (size_t)n * 27 + l31, (rf[lane * 8 + k] + rf[(64 + lane) * 8 + k]) + (rf[(128 + lane) * 8 + k] + rf[(192 + lane) * 8 + k]));
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[t][j] = acc[j];
@@ -1652,7 +1695,9 @@ void launch_hstem_wgrad(const h16* dy, const float* x, int B, int H, int W, floa
     static const int gmax = getenv("YN_STEM_G") ? atoi(getenv("YN_STEM_G")) : 2048;
     if (G > gmax) G = gmax;
     if (G < 1) G = 1;
-    hipLaunchKernelGGL(hstem_wgrad_kernel, dim3((unsigned)G), dim3(256), 0, s, dy, x, B, H, W, dw_slots, slot_stride);
+    static const int mfma = getenv("YN_STEM_WG_MFMA") ? atoi(getenv("YN_STEM_WG_MFMA")) : 1;        // 0: the FMA loop (A/B runs)
+    if (mfma) hipLaunchKernelGGL(hstem_wgrad_kernel<true>, dim3((unsigned)G), dim3(256), 0, s, dy, x, B, H, W, dw_slots, slot_stride);
+    else hipLaunchKernelGGL(hstem_wgrad_kernel<false>, dim3((unsigned)G), dim3(256), 0, s, dy, x, B, H, W, dw_slots, slot_stride);
 }
 
 // ---- 3x3 stride-2 max pool with recorded arg-max (first maximum in scan order, as ATen) and its gather-form backward; C = 24
