@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--spawn", action="store_true",
                     help="always go through the rank launcher (probe -> child torch.distributed.run), also for --gpus 1, and build the "
                          "process group even at world size 1: the N-GPU code path, RCCL included, on a one-GPU box")
+    ap.add_argument("--detail", metavar="PATH", default=None,
+                    help="where the detail blocks of the default run go (per-kernel table, extras, latency, NMS split); default: bench_detail.json next to bench.py")
     ap.add_argument("--latency", type=int, default=0, metavar="N",
                     help="latency mode (BASELINE config 5): N synchronous single-batch calls after warm-up; reports p50/p99 ms")
     return ap.parse_args()
@@ -549,13 +551,13 @@ def side_workload(args, dev, rank, world, dist, S, B, backbone, steps, warmup, n
     if exact:
         for hk in rig.handles:
             hk.exact_f32(True)
-    # two timed regions of `steps` steps, the faster one reported (a 30 ms region is at the mercy of one host hiccup: the same workload came out
-    # at 18.1 k and 40.8 k images/s in two runs of one build); both are kept in the entry
-    els = [timed_infer(rig, steps, warmup if i == 0 else 2, dev, dist) for i in range(2)]
-    el = min(els)
+    # three timed regions of `steps` steps, the MEDIAN reported (a 30 ms region is at the mercy of one host hiccup: the same workload came
+    # out at 18.1 k and 40.8 k images/s in two runs of one build); all three are kept in the entry
+    els = [timed_infer(rig, steps, warmup if i == 0 else 2, dev, dist) for i in range(3)]
+    el = sorted(els)[1]
     ms = el / steps * 1e3
     out = {"images_per_s": round(world * B * steps / el, 1), "ms_per_step": round(ms, 4), "steps": steps, "streams_per_gpu": ns,
-           "timed_regions_images_per_s": [round(world * B * steps / e, 1) for e in els],
+           "timed_regions_images_per_s": [round(world * B * steps / e, 1) for e in els], "reported_region": "median of three",
            "detections_per_step_rank0": rig.delivered // steps, "conf_thresh": wargs.conf, "nms_thresh": wargs.nms,
            "workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference + NMS + host delivery, conf %.3g / nms %.2f%s%s"
                        % (backbone, S, S, B, wargs.conf, wargs.nms, " (yn_exact_f32: f32 MFMA only)" if exact else "",
@@ -632,13 +634,43 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
-def emit(obj):
-    data = (json.dumps(obj) + "\n").encode()
+LINE_LIMIT = 4000      # the driver keeps an 8 KB tail of stdout: the contract line stays well inside it (round 4's 22.9 KB line was not parsed)
+
+
+def emit(obj, detail=None, detail_path=None):
+    """ONE JSON line on stdout, <= LINE_LIMIT bytes.  Everything beyond the contract keys (`detail`: per-kernel table, extras, latency and
+    NMS blocks) goes to bench_detail.json next to bench.py and, as one line, to stderr; the line names the file."""
+    if detail is not None:
+        path = detail_path or os.path.join(ROOT, "bench_detail.json")
+        full = dict(obj, **detail)
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            obj = dict(obj, detail_file=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)
+        except OSError as e:                                # read-only tree: the stderr copy remains
+            obj = dict(obj, detail_file=None, detail_error=str(e)[:80])
+        sys.stderr.write("bench_detail " + json.dumps(full) + "\n")
+        sys.stderr.flush()
+    data = json.dumps(obj)
+    if len(data) > LINE_LIMIT:                              # never silently: shed the optional blocks, largest first, and say so
+        obj = dict(obj)
+        for k in sorted((k for k in obj if k not in CONTRACT_KEYS), key=lambda k: -len(json.dumps(obj[k]))):
+            obj.pop(k)
+            obj["dropped_for_size"] = sorted(obj.get("dropped_for_size", []) + [k])
+            data = json.dumps(obj)
+            if len(data) <= LINE_LIMIT:
+                break
+    assert len(data) <= LINE_LIMIT, "bench.py: contract line is %d bytes" % len(data)
+    data = (data + "\n").encode()
     sys.stdout.flush()
     if _RESULT_FD is None:
         os.write(1, data)
     else:
         os.write(_RESULT_FD, data)
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
 def main():
@@ -830,6 +862,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     if rank == 0:
+        per_rank = [round(B * args.steps / t, 1) for t in rank_seconds]
+        frac_floor = round(pipeline["roofline_floor_ms"] / ms_per_step, 4) if pipeline else None
+        roof_line = None
+        if roof:                                            # the contract's keys + what prices them; the rest of the block is in the detail file
+            roof_line = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_us",
+                                              "share_of_step", "launches_per_step")}
         line = {
             "metric": "images/sec YOLO-Nano-%s %dx%d bs=%d inference (network + decode + NMS + host delivery)" % (args.backbone, S, S, B),
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -837,20 +875,24 @@ def main():
             "dtype": "f32 (split-f16 MFMA x3, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "YOLO-Nano-%s %dx%d bs=%d/GPU fp32 inference, COCO %d-class head + NMS (BASELINE configs[1]); inputs resident in HBM, "
                                    "kept detections delivered to pinned host memory inside the timed region" % (args.backbone, S, S, B, args.classes),
-                       "arithmetic": "fp32 storage and fp32 accumulation everywhere; the GEMM-shaped convs multiply on the f16 MFMA with every fp32 operand split "
-                                     "x = hi + lo*2^-11 (three MFMAs per product, error <= ~3*2^-22 per product: measured closer to float64 than the f32 MFMA; "
-                                     "operands must stay below 65504 - checked on the device, yn_range_status); depthwise / stem / decode / NMS in plain fp32. "
-                                     "extras.infer_exact_f32_* is the same workload on the f32 MFMA only (yn_exact_f32)",
+                       "arithmetic": "fp32 storage / accumulation; GEMM-shaped convs on the f16 MFMA with fp32 operands split hi + lo*2^-11 (3 MFMAs per product, fp32-class)",
                        "global_batch": world * B, "conf_thresh": args.conf, "nms_thresh": args.nms,
                        "parallelism": "image-sharded x%d, no collective" % world, "rccl_ranks": world, "backend": backend if dist is not None else None,
-                       "per_rank_images_per_s": [round(B * args.steps / t, 1) for t in rank_seconds],
-                       "hipgraph": bool(use_graph), "launch_mode": mode, "launch_calibration_rank0": calib,
-                       "streams_per_gpu": ns, "queue_depth_per_stream": rig_depth,
-                       "ms_per_step_is": "inverse throughput with up to %d batches in flight per GPU (%d streams x %d queued steps)" % (ns * rig_depth, ns, rig_depth),
+                       "per_rank_images_per_s": per_rank, "launch_mode": "hipgraph" if use_graph else "eager",
+                       "streams_per_gpu": ns, "ms_per_step_is": "inverse throughput, %d batches in flight per GPU" % (ns * rig_depth),
                        "detections_per_step_rank0": kept},
-            "roofline": roof,
+            "roofline": roof_line,
             "cpu_baseline": None if args.no_cpu_baseline or world > 1 else cpu_baseline(args, sd, anchors),
-            "pipeline": dict(pipeline or {}, frac_of_floor=round((pipeline["roofline_floor_ms"] / ms_per_step), 4) if pipeline else None),
+        }
+        # everything else: bench_detail.json + stderr (emit)
+        detail = {
+            "config_detail": {"arithmetic": "fp32 storage and fp32 accumulation everywhere; the GEMM-shaped convs multiply on the f16 MFMA with every fp32 operand split "
+                                            "x = hi + lo*2^-11 (three MFMAs per product, error <= ~3*2^-22 per product: measured closer to float64 than the f32 MFMA; "
+                                            "operands must stay below 65504 - checked on the device, yn_range_status); depthwise / stem / decode / NMS in plain fp32. "
+                                            "extras.infer_exact_f32_* is the same workload on the f32 MFMA only (yn_exact_f32)",
+                              "launch_mode_requested": mode, "launch_calibration_rank0": calib, "queue_depth_per_stream": rig_depth, "hipgraph": bool(use_graph)},
+            "roofline_detail": roof,
+            "pipeline": dict(pipeline or {}, frac_of_floor=frac_floor),
             "device_only_images_per_s": round(dev_only, 1),
             "kernels": kernels,
             "single_stream": single,
@@ -858,20 +900,24 @@ def main():
             "latency_bs1": latency,
         }
         if pipeline:
-            line["nms"] = nms_split(recs)
-        # the numbers of the named workloads once more, compact, as the LAST key of the line (a truncated tail of the output still shows them)
+            detail["nms"] = nms_split(recs)
+        # the numbers of the named workloads, compact, in the contract line itself
         ex = extras or {}
         pick = lambda k, f: (ex[k].get(f) if isinstance(ex.get(k), dict) else None)
         lat = latency or {}
+        short = lambda k: k.replace("infer_", "").replace("_%s_%d_bs%d" % (args.backbone, S, B), "")
         line["summary"] = {
-            "images_per_s": round(value, 1), "frac_of_hbm_floor": line["pipeline"].get("frac_of_floor"),
+            "images_per_s": round(value, 1), "frac_of_hbm_floor": frac_floor,
+            "hbm_floor_ms": pipeline["roofline_floor_ms"] if pipeline else None, "alg_mb_per_step": pipeline["alg_mb_per_step"] if pipeline else None,
+            "device_only_images_per_s": round(dev_only, 1),
             "single_stream_images_per_s": single["images_per_s"] if single else None,
-            "by_workload_images_per_s": {k: v.get("images_per_s", v.get("value")) for k, v in ex.items() if isinstance(v, dict)},
+            "nms_us_one_stream": detail["nms"]["total_us"] if pipeline else None,
+            "by_workload_images_per_s": {short(k): v.get("images_per_s", v.get("value")) for k, v in ex.items() if isinstance(v, dict)},
             "train_608_bs32_ms_per_step": {"f16": pick("train_608_bs32_f16", "ms_per_step"), "f32": pick("train_608_bs32_f32", "ms_per_step")},
             "latency_bs1_p50_ms": {k: {m: v[m]["p50_ms"] for m in v} for k, v in lat.items()},
-            "n_gpus": world, "allreduce_us_per_step": pick("train_608_bs32_f16", "allreduce_us_per_step"),
-            "per_rank_images_per_s_spread": [min(line["config"]["per_rank_images_per_s"]), max(line["config"]["per_rank_images_per_s"])]}
-        emit(line)
+            "allreduce_us_per_step": pick("train_608_bs32_f16", "allreduce_us_per_step"),
+            "per_rank_images_per_s_spread": [min(per_rank), max(per_rank)]}
+        emit(line, detail, args.detail)
     finish()
 
 

@@ -32,6 +32,9 @@ typedef struct yn_handle yn_handle;
 enum { YN_BACKBONE_0_5X = 0, YN_BACKBONE_1_0X = 1, YN_BACKBONE_1_5X = 2, YN_BACKBONE_2_0X = 3 };
 enum { YN_ACT_NONE = 0, YN_ACT_RELU = 1, YN_ACT_LEAKY = 2 };
 enum { YN_F32 = 0, YN_F16 = 1 };
+/* return values: 0 = success, 1 = failure (yn_last_error has the text), YN_STATUS_RANGE = yn_infer / yn_pack_detections refused because an EARLIER
+ * yn_infer on this handle left the split-f16 range and nobody has acknowledged it through yn_range_status yet (see there) */
+enum { YN_STATUS_OK = 0, YN_STATUS_ERROR = 1, YN_STATUS_RANGE = 2 };
 
 /* Mirrors YOLONano.__init__(device, input_size, num_classes, trainable, conf_thresh, nms_thresh,
  * anchor_size, backbone, diou_nms)  — models/yolo_nano.py:13-27. */
@@ -79,7 +82,9 @@ int  yn_exact_f32(yn_handle* h, int enable);
  *     (the host shim yolo_nano_amd.YOLONano does this by itself, once, and stays on the f32-MFMA family).
  *     yn_infer also delivers the flag WITH its results, at no extra synchronisation: while it is set every count_dev[b] comes back
  *     NEGATIVE (-1 - K_b), and yn_pack_detections carries the mark on as offsets_dev[B] = -1 - total.  The flag is sticky until
- *     yn_range_status clears it.
+ *     yn_range_status clears it.  The same fact OUT OF BAND, for callers that loop `i < count[b]` without looking at the sign: the kernel
+ *     that writes the negative counts also sets one word of pinned host memory, and from then on every yn_infer / yn_pack_detections
+ *     on the handle returns YN_STATUS_RANGE (checked on the host, no synchronisation) until yn_range_status has been called.
  * Tiny values need no guard: below the f16 normal range lo = (x - hi) * 2^11 still carries x. */
 int  yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow);
 /* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's

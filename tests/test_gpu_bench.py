@@ -47,15 +47,19 @@ def test_four_rank_default_run_walks_every_barrier():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])                 # the contract line stays small at N > 1 too
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["config"]["rccl_ranks"] == 4 and d["config"]["global_batch"] == 16 and d["cpu_baseline"] is None
     assert len(d["config"]["per_rank_images_per_s"]) == 4
-    ex = d["extras"]
+    det = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert det["value"] == d["value"]                          # the detail file repeats the line and adds the blocks
+    ex = det["extras"]
     for k in ("infer_608_bs32", "infer_0.5x_416_bs128", "train_608_bs32_f16", "train_608_bs32_f32"):
         assert k in ex and "error" not in ex[k], (k, ex.get(k))
     assert any(k.startswith("infer_conf0.1_nms0.45") for k in ex) and any(k.startswith("infer_initbias_conf0.1") for k in ex)
     assert len(ex["train_608_bs32_f16"]["per_rank_images_per_s"]) == 4 and ex["train_608_bs32_f16"]["allreduce_us_per_step"] > 0
-    assert list(d)[-1] == "summary" and d["summary"]["n_gpus"] == 4 and d["summary"]["allreduce_us_per_step"] > 0
+    assert "summary" in d and d["summary"]["allreduce_us_per_step"] > 0
+    assert "train_608_bs32_f16" in d["summary"]["by_workload_images_per_s"]
     assert len(d["summary"]["per_rank_images_per_s_spread"]) == 2
 
 
@@ -97,21 +101,61 @@ def _run_single(extra):
     return json.loads(lines[0])
 
 
-def test_single_gpu_contract_line():
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_driver_default_command_prints_one_small_parseable_line():
+    """EXACTLY what the driver runs at round end - `python3 bench.py --gpus 1 --steps 20 --warmup 5`, extras on, full sizes - must yield ONE
+    stdout line of fewer than 4096 bytes that json.loads accepts and that carries every contract key, roofline.frac and cpu_baseline.value
+    (round 4's line was 22.9 KB: the driver's record kept a tail of it and parsed nothing).  The detail blocks are in the named file."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout[-3000:]                     # nothing else on stdout
+    assert len(out[0]) < 4096, len(out[0])
+    d = json.loads(out[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["avg_us"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert "model" not in d["config"] and "workload" in d["config"] and d["config"]["rccl_ranks"] == 1
+    sm = d["summary"]
+    assert sm["images_per_s"] == d["value"] and 0 < sm["frac_of_hbm_floor"] < 1
+    assert sm["train_608_bs32_ms_per_step"]["f16"] > 0 and sm["train_608_bs32_ms_per_step"]["f32"] > 0
+    assert sm["latency_bs1_p50_ms"]["608x608"]["hipgraph"] > 0 and sm["latency_bs1_p50_ms"]["416x416"]["eager"] > 0
+    assert sm["by_workload_images_per_s"]["608_bs32"] > 0 and sm["by_workload_images_per_s"]["0.5x_416_bs128"] > 0
+    det = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    for k in ("kernels", "extras", "latency_bs1", "pipeline", "nms", "single_stream", "roofline_detail"):
+        assert k in det, k
+    for v in det["extras"].values():
+        if "timed_regions_images_per_s" in v:                  # every extra reports the MEDIAN of its timed regions, not the best
+            reg = sorted(v["timed_regions_images_per_s"])
+            assert len(reg) == 3 and v["images_per_s"] == reg[1]
+    assert "bench_detail " in r.stderr                         # and the same object went to stderr
+
+
+def test_single_gpu_contract_line(tmp_path):
     """The driver's contract for the default mode: one JSON line with the required keys, the roofline and cpu_baseline blocks and
     the bs=1 latency block (small workload here to keep the test short)."""
-    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2", "--no-extras", "--latency-calls", "60"])
+    dp = str(tmp_path / "detail.json")
+    d = _run_single(["--steps", "8", "--warmup", "3", "--batch", "4", "--size", "224", "--cpu-images", "2", "--no-extras", "--latency-calls", "60", "--detail", dp])
+    assert d["detail_file"] == dp
+    det = json.load(open(dp))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 3 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
-    assert d["latency_bs1"]["224x224"]["eager"]["p50_ms"] > 0 and d["latency_bs1"]["608x608"]["hipgraph"]["p50_ms"] > 0
+    assert det["latency_bs1"]["224x224"]["eager"]["p50_ms"] > 0 and det["latency_bs1"]["608x608"]["hipgraph"]["p50_ms"] > 0
+    assert d["summary"]["latency_bs1_p50_ms"]["224x224"]["eager"] == det["latency_bs1"]["224x224"]["eager"]["p50_ms"]
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["dtype"].startswith("f32") and "split-f16" in d["dtype"] and "arithmetic" in d["config"]      # the arithmetic is disclosed
-    assert d["latency_bs1"]["224x224"]["eager"]["calls"] == 60 and d["latency_bs1"]["224x224"]["eager"]["warmup"] == 50
-    assert d["device_only_images_per_s"] >= 0.9 * d["value"] and d["config"]["detections_per_step_rank0"] > 0
+    assert det["latency_bs1"]["224x224"]["eager"]["calls"] == 60 and det["latency_bs1"]["224x224"]["eager"]["warmup"] == 50
+    assert det["device_only_images_per_s"] >= 0.9 * d["value"] and d["config"]["detections_per_step_rank0"] > 0
 
 
 def test_preprocess_and_latency_modes():

@@ -1186,12 +1186,23 @@ def test_range_guard_whole_network_and_shim(capi):
     # yn_infer delivers the same flag with its counts (negative: -1 - kept), yn_pack_detections carries it on in offsets[B]; sticky until
     # yn_range_status clears it; under yn_exact_f32 the counts are plain again
     outb = hb.infer(dev(x_np))
-    assert int(outb[4][0]) < 0
+    assert int(outb[4][0]) < 0                                      # in band (this read synchronises: compact_kernel has run)
+    # ... and OUT OF BAND (advisor, round 4): compact_kernel also set the handle's pinned host word, so every later yn_infer /
+    # yn_pack_detections refuses with YN_STATUS_RANGE - no synchronisation involved - until yn_range_status acknowledges
+    with pytest.raises(capi.YnRangeError):
+        hb.pack_detections(outb)
+    with pytest.raises(capi.YnRangeError):
+        hb.infer(dev(x_np))
+    assert hb.range_status() == (False, True) and hb.range_status() == (False, False)
+    # pack_kernel carries a negative count on as offsets[B] = -1 - total (the in-band mark of a caller that packs without looking)
+    kept = -1 - int(outb[4][0])
     _, offb = hb.pack_detections(outb)
-    assert int(offb[1]) == int(outb[4][0]) and int(offb[0]) == 0
+    assert int(offb[1]) == -1 - kept and int(offb[0]) == 0
+    # detections_to_host: raises, and acknowledges the flag itself (the exception is the report)
+    outb = hb.infer(dev(x_np))
     with pytest.raises(capi.YnRangeError):
         hb.detections_to_host(outb)
-    assert hb.range_status() == (False, True) and hb.range_status() == (False, False)
+    assert hb.range_status() == (False, False)
     hb.exact_f32(True)
     outb = hb.infer(dev(x_np))
     assert int(outb[4][0]) >= 0 and hb.range_status() == (False, False)

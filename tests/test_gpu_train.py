@@ -366,7 +366,7 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
     LeakyReLU / ReLU slope flips against the float64 run, and where that element carries one of the few large loss gradients of a small map
     the layer's own parameter gradients move by 1e-2 ... 2e-1 (smooth_3 at 4 x 4 x 4 positions: HIP 0.2 / oracle 3e-5 on one seed, HIP 5e-5 /
     oracle 2.4e-3 on the next).  A wrong kernel is wrong on EVERY input, a flip only on the input that has it: each size is therefore run on
-    THREE seeds and a tensor passes on its best one - f32: relative L2 error against the float64 gradient <= max(4x the fp32 oracle's best,
+    THREE seeds, a tensor has to pass on TWO of them (round 4: on its best one), and every step is run twice and has to reproduce - f32: relative L2 error against the float64 gradient <= max(4x the fp32 oracle's best,
     2e-3); f16: <= 2x the fp16-storage emulation's error + 2e-2 on the same seed, median ratio < 1.25 on every seed; losses 1e-4 (f32) on
     every seed.  Returning to 128 must reproduce the first 128 step to the order of the atomic sums (1e-5 of max|g|), and - f16 - the step
     with the BatchNorm sums fused into the GEMM epilogues equals the step with separate reduction launches (YN_TRAIN_FUSE_STATS /
@@ -388,6 +388,11 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
             xd, td = torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda()
             losses = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
             grads = h.flat_grads.clone()
+            # the SAME step again on the same handle (advisor, round 4): an activation-sign flip is a property of the data and reproduces to the
+            # order of the atomic sums; a race or an uninitialised read in one of the fused kernels does not - and must not be excused as a "flip"
+            l_again = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
+            np.testing.assert_allclose(l_again, losses, rtol=1e-5, err_msg="S=%d seed %d: the step does not reproduce" % (S, xs))
+            assert float((h.flat_grads - grads).abs().max()) <= 1e-5 * float(grads.abs().max()), (S, xs)
             if phase == 0 and si == 0:
                 first = (losses, grads)
             if phase == 2:                                         # back at the first size: the first step again, to atomic-sum order
@@ -404,15 +409,15 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
                 ey = {n: rel(gy[n].double().numpy(), g64[n]) for n in live}
                 np.testing.assert_allclose(losses, l64, rtol=1e-4)
                 for n in live:
-                    best[n] = min(best.get(n, 1e9), errs[n]); best_y[n] = min(best_y.get(n, 1e9), ey[n])
+                    best.setdefault(n, []).append(errs[n]); best_y[n] = min(best_y.get(n, 1e9), ey[n])
             else:
                 lq, gy = mk(dtype=torch.float64, fp16_storage=True).train_step(x, target, S, lr=1e-4)
                 ey = {n: rel(gy[n].numpy(), g64[n]) for n in live}
                 for a, e, q in zip(losses, l64, lq):
                     assert abs(a - e) <= 2.0 * abs(q - e) + 2e-2 * abs(e), (S, losses, l64, lq)
                 assert np.median([errs[n] / max(ey[n], 1e-6) for n in live]) < 1.25, S
-                for n in live:                                     # excess over the same seed's bar; the best seed counts
-                    best[n] = min(best.get(n, 1e9), errs[n] - (2.0 * ey[n] + 2e-2))
+                for n in live:                                     # excess over the same seed's bar
+                    best.setdefault(n, []).append(errs[n] - (2.0 * ey[n] + 2e-2))
                 if si == 0:                                        # the fused BatchNorm statistics / backward sums against their separate reduction launches
                     monkeypatch.setenv("YN_TRAIN_FUSE_STATS", "0"); monkeypatch.setenv("YN_TRAIN_FUSE_SUMS", "0")
                     l_un = h.train_step(xd, td, lr=1e-4, update=False).cpu().numpy()
@@ -434,12 +439,14 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
                             assert rel(a, b) <= 3.0 * ey[n] + 1e-2, (S, n, rel(a, b), ey[n])
         if phase == 2:
             continue
+        # TWO of the three seeds have to pass (round 4 let a tensor pass on its best one): a flip is an event of one data draw
+        second = {n: sorted(v)[1] for n, v in best.items()}
         if precision == "f32":
-            bad = [(n, best[n], best_y[n]) for n in best if best[n] > max(4 * best_y[n], 2e-3)]
-            assert not bad, "S=%d (name, best err over the seeds, fp32 oracle's best): %s" % (S, bad[:8])
+            bad = [(n, best[n], best_y[n]) for n in best if second[n] > max(4 * best_y[n], 2e-3)]
+            assert not bad, "S=%d (name, errs over the seeds, fp32 oracle's best): %s" % (S, bad[:8])
         else:
-            bad = [(n, best[n]) for n in best if best[n] > 0.0]
-            assert not bad, "S=%d (name, best excess over 2x emulation + 2e-2): %s" % (S, bad[:8])
+            bad = [(n, best[n]) for n in best if second[n] > 0.0]
+            assert not bad, "S=%d (name, excess over 2x emulation + 2e-2 per seed): %s" % (S, bad[:8])
     h.close()
 
 
@@ -479,7 +486,12 @@ def _multi_scale_run(g, precision, sizes, B, C=20, seed_shift=0):
                 assert float((h.flat_grads - hf.flat_grads).abs().max()) <= 1e-5 * float(hf.flat_grads.abs().max())
                 hf.close()
             before = h.flat_params.clone()
+            # the step once WITHOUT its update: the updating step below has to reproduce these gradients to the order of the atomic sums - a tensor
+            # over its bar that is excused on another data draw has then at least been the same wrong number twice (a flip), not a race
+            h.train_step(torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda(), lr=1e-4, update=False)
+            g_dry = h.flat_grads.clone()
             losses = h.train_step(torch.as_tensor(x).cuda(), torch.as_tensor(target).cuda(), lr=1e-4, momentum=0.9, weight_decay=5e-4, update=True).cpu().numpy()
+            assert float((h.flat_grads - g_dry).abs().max()) <= 1e-5 * float(g_dry.abs().max()), ("step does not reproduce", phase, it)
             assert np.isfinite(losses).all() and h.skipped_steps() == 0, (phase, it, losses)
             assert not torch.equal(h.flat_params, before)                        # the update was applied
             gmax = max(float(np.abs(v).max()) for v in g64.values())

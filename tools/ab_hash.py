@@ -24,6 +24,8 @@ for t in h.forward_raw(x):
     m.update(t.contiguous().cpu().numpy().tobytes())
 out = h.infer(x)
 counts = out[4].cpu().tolist()
+if min(counts) < 0:                                         # yn_infer's range mark: the results are invalid, nothing to hash
+    raise SystemExit("ab_hash: yn_infer flagged an activation outside the split-f16 range (negative counts)")
 for b in range(B):
     for t in out[:4]:
         m.update(t[b, :counts[b]].contiguous().cpu().numpy().tobytes())

@@ -13,6 +13,8 @@ gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
 x = torch.randn((B, 3, S, S), generator=gen, device="cuda")
 out = h.infer(x)
 counts = out[4].cpu().numpy()
+if counts.min() < 0:                                        # yn_infer's range mark: the results are invalid
+    raise SystemExit("nms_stats: yn_infer flagged an activation outside the split-f16 range (negative counts)")
 print("kept per image: min %d median %d max %d total %d" % (counts.min(), np.median(counts), counts.max(), counts.sum()))
 heads = h.forward_raw(x)
 bbox, cls = h.score_full(heads)

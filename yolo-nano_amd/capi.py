@@ -222,6 +222,8 @@ class Handle:
         return c
 
     def _ck(self, rc, what):
+        if rc == 2:                                             # YN_STATUS_RANGE: an earlier yn_infer's range mark has not been acknowledged
+            raise YnRangeError("%s: %s" % (what, self.lib.yn_last_error(self.h).decode()))
         if rc:
             raise YnError("%s: %s" % (what, self.lib.yn_last_error(self.h).decode()))
 
@@ -425,7 +427,7 @@ class Handle:
         x = self._in(x)
         out = self.alloc_outputs(B, device=x.device) if out is None else out
         self._ck(self.lib.yn_infer(self.h, x.data_ptr(), B, *[o.data_ptr() for o in out]), "yn_infer")
-        return out
+        return out                                              # out[4] (counts) NEGATIVE = range mark (yn_range_status): check before slicing with it
 
     def pack_detections(self, out, rec=None, offsets=None):
         """Kept rows of all images of `out` (infer / postprocess outputs) as one record list rec [B*N, 6] = x1,y1,x2,y2,score,class
@@ -441,10 +443,14 @@ class Handle:
     def detections_to_host(self, out):
         """models/yolo_nano.py:370-376 for a whole batch with two device-to-host copies: -> list of B (bboxes [K,4] f32,
         scores [K] f32, cls_inds [K] i64) numpy triples, fresh and writable."""
-        rec, offsets = self.pack_detections(out)
-        off = offsets.cpu().numpy()
-        if int(off[-1]) < 0:                                    # compact_kernel's range mark, carried through pack_kernel
-            raise YnRangeError("yn_infer: an activation exceeded the split-f16 range (|x| >= 65504); results invalid, re-run under exact_f32")
+        try:
+            rec, offsets = self.pack_detections(out)
+            off = offsets.cpu().numpy()
+            if int(off[-1]) < 0:                                # compact_kernel's range mark, carried through pack_kernel
+                raise YnRangeError("yn_infer: an activation exceeded the split-f16 range (|x| >= 65504); results invalid, re-run under exact_f32")
+        except YnRangeError:
+            self.range_status()                                 # the exception IS the report: acknowledge, so that the flag does not poison later calls
+            raise
         host = rec[: int(off[-1])].cpu().numpy()
         res = []
         for b in range(len(off) - 1):

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void unit_chain_split_kernel(ChainArgs a)
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float ucs_smem[];
     const int bf = a.bf, CS = bf + 2, W = a.W, H = a.H, HW = H * W;
-    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, nchunks = (bf + KC - 1) / KC;
+    const int KQ = (bf + 7) >> 3, PS = plane_stride(bf), nchunks = (bf + KC - 1) / KC;
     float* T32 = ucs_smem;                                              // [BM][CS]
     uch16* Ph = reinterpret_cast<uch16*>(ucs_smem + ((BM * CS + 3) & ~3));  // [BM][PS]
     uch16* Pl = Ph + BM * PS;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
     constexpr int BM = 32 * WM, BN = 32 * NT * WN, NTHR = 64 * WM * WN;
     extern __shared__ __attribute__((aligned(16))) float uc2_smem[];
     const int bf = a.bf, W = a.W, H = a.H, HW = H * W;
-    const int KQ = (bf + 7) >> 3, PS = KQ * 8 + 8, S = (KQ + 1) >> 1;     // S: 16-deep k-steps of a GEMM
+    const int KQ = (bf + 7) >> 3, PS = plane_stride(bf), S = (KQ + 1) >> 1;     // S: 16-deep k-steps of a GEMM
     uch16* Ph = reinterpret_cast<uch16*>(uc2_smem);                     // [BM][PS]
     uch16* Pl = Ph + BM * PS;
 
@@ -900,13 +900,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
 
 static size_t unit_chain2_lds(int bf, int BM)
 {
-    const int PS = ((bf + 7) / 8) * 8 + 8;
+    const int PS = plane_stride(bf);
     return (size_t)2 * BM * PS * 2;                          // the two operand planes; the weights go through registers
 }
 
 static size_t unit_chain_split_lds(int bf, int BM, int BN)
 {
-    const int PS = ((bf + 7) / 8) * 8 + 8;
+    const int PS = plane_stride(bf);
     return (size_t)((BM * (bf + 2) + 3) & ~3) * sizeof(float) + ((size_t)2 * BM * PS + (size_t)2 * 4 * BN * 8) * 2;
 }
 
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
     constexpr int BM = 32;
     extern __shared__ __attribute__((aligned(16))) float d2_smem[];
     const int bf = a.bf, cin = a.cin;
-    const int KQ2 = (bf + 7) >> 3, KQ1 = (cin + 7) >> 3, PS2 = KQ2 * 8 + 8, PS1 = KQ1 * 8 + 8;
+    const int KQ2 = (bf + 7) >> 3, KQ1 = (cin + 7) >> 3, PS2 = plane_stride(bf), PS1 = plane_stride(cin);
     const int S2 = (KQ2 + 1) >> 1, S1 = (KQ1 + 1) >> 1, S = S2 + S1;    // 16-deep k-steps of pw2, of branch 1's pointwise conv
     const bool chain = a.W1nh != nullptr;                               // + the next unit's pw1 (K = bf: S2 steps more, after the store)
     uch16* A2h = reinterpret_cast<uch16*>(d2_smem);                     // [BM][PS2]
@@ -1951,7 +1951,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
 
 static size_t down2_lds(int bf, int cin)
 {
-    const int PS2 = ((bf + 7) / 8) * 8 + 8, PS1 = ((cin + 7) / 8) * 8 + 8;
+    const int PS2 = plane_stride(bf), PS1 = plane_stride(cin);
     return ((size_t)2 * 32 * PS2 + (size_t)2 * 32 * PS1) * 2;
 }
 

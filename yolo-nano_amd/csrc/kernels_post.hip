@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ cls, const int32_t* __restrict__ keep, int N,
                                                         float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                         int32_t* __restrict__ out_cls, int32_t* __restrict__ out_index,
-                                                        int32_t* __restrict__ count, const unsigned* __restrict__ ovf)
+                                                        int32_t* __restrict__ count, const unsigned* __restrict__ ovf, unsigned* __restrict__ ovf_host)
 {
     // 32 chunks of 1024 candidates per pass: every keep flag of the pass is requested in one batch, the per-chunk wavefront counts go to
     // LDS, ONE barrier, then every thread derives the positions of its (up to 32) kept candidates.  (First version: load, ballot,
@@ -1873,7 +1873,13 @@ __global__ __launch_bounds__(1024) void compact_kernel(const float* __restrict__
     }
     // range guard of the split-f16 family, delivered with the result every caller reads anyway: a NEGATIVE count (-1 - kept) says an
     // activation left the split's range somewhere in the network that produced these candidates (yn_range_status; re-run under yn_exact_f32)
-    if (threadIdx.x == 0) count[b] = (ovf && *ovf) ? -1 - base : base;
+    // The same fact out of band (advisor, round 4): one word of pinned host memory per handle, which every later C-ABI call of the handle
+    // checks without synchronising - it returns YN_STATUS_RANGE until yn_range_status() acknowledges (and clears) the flag.
+    if (threadIdx.x == 0) {
+        const bool flagged = ovf && *ovf;
+        count[b] = flagged ? -1 - base : base;
+        if (flagged && ovf_host) __hip_atomic_store(ovf_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int nms_max_segment() { return 64 * YN_RESOLVE_MAX_T; }
@@ -2004,7 +2010,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                                       wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
     mark("compact_kernel");
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count, wk.ovf);
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(1024), 0, s, boxes, scores, cls, wk.keep, N, out_boxes, out_scores, out_cls, out_index, count, wk.ovf, wk.ovf_host);
 }
 
 // scratch: ids[n] int32, sbox[n] float4, M[nms_matrix_words_per_image(n,1)] u64 — all provided by the handle

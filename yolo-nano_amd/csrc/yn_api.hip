@@ -138,6 +138,8 @@ struct yn_handle {
     int fuse_decode_mode = 1;              // 1 = when the stride-8 head has >= 8192 pixels, 2 = always
     bool exact_f32 = false;                // yn_exact_f32 / YN_EXACT_F32=1: GEMM-shaped convs on the f32 MFMA only (no split-f16 operands)
     bool range_fallback = false;           // yn_fold_bn found a folded GEMM weight outside the split's range (|w| >= 65504): same effect as exact_f32
+    unsigned* range_host = nullptr;        // one word of pinned host memory: set by compact_kernel beside the negative counts (the range flag, out of band);
+    unsigned* range_host_dev = nullptr;    // its device view.  While set, yn_infer / yn_pack_detections return YN_STATUS_RANGE; yn_range_status clears it
     unsigned* range_flags = nullptr;       // device uint[3]: [0] weights out of range (fold_pack_kernel), [1] an activation >= 65504 was split
                                            // (range_report, yn_device.h; read and cleared by yn_range_status), [2] the same as [0] for a yn_op_* call
     bool autotune = true;
@@ -1204,6 +1206,11 @@ int yn_create(const yn_config* cfg, yn_handle** out)
         hipMemsetAsync(h->range_flags, 0, 3 * sizeof(unsigned), h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         g_create_error = "yn_create: out of device memory"; delete h; return 1;
     }
+    if (hipHostMalloc((void**)&h->range_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->range_host_dev, h->range_host, 0) != hipSuccess) {
+        g_create_error = "yn_create: no pinned host memory for the range flag"; delete h; return 1;
+    }
+    *h->range_host = 0;
     *out = h;
     return 0;
 }
@@ -1233,6 +1240,7 @@ void yn_destroy(yn_handle* h)
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     for (TrainPack& pk : h->tpacks) { if (pk.wp) (void)hipFree(pk.wp); if (pk.bias) (void)hipFree(pk.bias); if (pk.wp_bwd) (void)hipFree(pk.wp_bwd); }
     if (h->range_flags) (void)hipFree(h->range_flags);
+    if (h->range_host) (void)hipHostFree(h->range_host);
     if (h->zeros) (void)hipFree(h->zeros);
     for (TrainGraph& g : h->train_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (h->train_side) (void)hipStreamDestroy(h->train_side);
@@ -1526,6 +1534,18 @@ int yn_fold_bn(yn_handle* h)
     return 0;
 }
 
+// The out-of-band form of yn_infer's range mark: compact_kernel set the handle's pinned word, nobody has acknowledged it through
+// yn_range_status yet.  No synchronisation: the word is host memory.
+static int range_pending(yn_handle* h, const char* who)
+{
+    if (h->range_host && __atomic_load_n(h->range_host, __ATOMIC_RELAXED)) {
+        fail(h, "%s: an earlier yn_infer split an activation >= 65504 (split-f16 range): its results are invalid - call yn_range_status to acknowledge, "
+                "then yn_exact_f32(h, 1) and run again", who);
+        return YN_STATUS_RANGE;
+    }
+    return 0;
+}
+
 int yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow)
 {
     YN_ENTER(h);
@@ -1533,6 +1553,7 @@ int yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overf
     HIPCHK(h, hipMemcpyAsync(&f, h->range_flags + 1, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (f) HIPCHK(h, hipMemsetAsync(h->range_flags + 1, 0, sizeof(unsigned), h->stream));
+    if (h->range_host) __atomic_store_n(h->range_host, 0u, __ATOMIC_RELAXED);      // acknowledged (the stream is idle: no compact_kernel can still set it)
     if (weights_exceed_f16) *weights_exceed_f16 = h->range_fallback ? 1 : 0;
     if (activation_overflow) *activation_overflow = f ? 1 : 0;
     return 0;
@@ -1686,6 +1707,7 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
 {
     YN_ENTER(h);
     if (check_ready(h, B)) return 1;
+    if (int rp = range_pending(h, "yn_infer")) return rp;
     GridInfo g = h->grid;
     g.head_ld = (h->head_ch + 3) & ~3;
     if (ensure_arena(h, B, g.S) || ensure_post(h, B, g.N, g.C) || ensure_heads(h, B)) return 1;
@@ -1712,6 +1734,7 @@ int yn_infer(yn_handle* h, const float* x_dev, int B, float* out_boxes, float* o
             }, &ctx};
             NmsWork wk = h->nms;
             wk.ovf = exact(h) ? nullptr : h->range_flags + 1;         // the network's range flag rides out with the counts (compact_kernel)
+            wk.ovf_host = exact(h) ? nullptr : h->range_host_dev;     // ... and into the handle's pinned word (range_pending)
             launch_nms_pipeline(h->cand_boxes, h->cand_scores, h->cand_cls, B, g.N, g.C, h->cfg.nms_thresh, h->cfg.diou_nms, wk,
                                 out_boxes, out_scores, out_cls, out_index, count, h->stream, h->profiling ? &hook : nullptr);
             delete ctx.cur;
@@ -1727,6 +1750,7 @@ int yn_pack_detections(yn_handle* h, const float* out_boxes, const float* out_sc
     YN_ENTER(h);
     if (B <= 0 || N <= 0 || !out_boxes || !out_scores || !out_cls || !count || !rec_dev || !offsets_dev)
         return fail(h, "yn_pack_detections: bad arguments");
+    if (int rp = range_pending(h, "yn_pack_detections")) return rp;
     launch_pack(out_boxes, out_scores, out_cls, count, B, N, rec_dev, offsets_dev, h->stream);
     HIPCHK(h, hipGetLastError());
     return 0;

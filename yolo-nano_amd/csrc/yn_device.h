@@ -280,6 +280,13 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
     range_report(a.ovf, amax);
 }
 
+// Row stride (halves) of an operand plane [rows][C] in LDS that 16-byte fragment reads walk row by row (lane = row): a
+// ds_read_b128 is served in groups of 16 lanes, conflict-free when their 16-byte pieces tile the 64 banks, i.e. when the stride is an
+// ODD multiple of 16 bytes.  ceil(C/8)*8 + 8 is one only for an even octet count: C = 116 (15 octets) gave 256 bytes - all 16 lanes
+// on the same four banks (SQ_LDS_BANK_CONFLICT = 88 % of the stage-3 chain's LDS cycles, profiles/r04_sq_counters.txt) - and C = 232 a
+// two-way conflict.  The columns [C, stride) stay zero (K tail).
+__host__ __device__ constexpr int plane_stride(int C) { return ((((C + 7) >> 3) + 1) & ~1) * 8 + 8; }
+
 template <int V> struct VecT;
 template <> struct VecT<2> { typedef float2 type; };
 template <> struct VecT<4> { typedef float4 type; };

@@ -13,6 +13,7 @@ typedef _Float16 h16;
 #define YN_HACC_SLOTS 16
 #endif
 constexpr int HACC_SLOTS = YN_HACC_SLOTS;
+static_assert(HACC_SLOTS >= 1 && (HACC_SLOTS & (HACC_SLOTS - 1)) == 0, "YN_HACC_SLOTS must be a power of two: producers pick their copy with blockIdx & (HACC_SLOTS - 1)");
 
 // Column sums of an hgemm output tile, taken in the kernel's epilogue while the tile sits in LDS (one launch and one pass over the
 // tensor less per BatchNorm and direction):

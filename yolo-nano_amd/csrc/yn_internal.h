@@ -161,6 +161,7 @@ struct NmsWork {                                // per-handle scratch, sized for
     int      large_cap;
     const unsigned* ovf;                        // yn_infer: the split-f16 range flag of the network kernels that produced the candidates, or null.
                                                 // Set => compact_kernel reports count[b] = -1 - kept (the results are invalid: yn_range_status)
+    unsigned* ovf_host;                         // with ovf: one word of pinned host memory (device view) that compact_kernel sets to 1 beside the negative counts, or null
 };
 size_t nms_matrix_words_per_image(int N, int C);
 int nms_max_segment();                      // largest per-class segment resolve_segment() can hold (its removed-mask lives in LDS)
@@ -188,6 +189,7 @@ void launch_make_targets(const double* labels, const int32_t* offsets, int B, co
 // GRAD_SLOTS copies of the flat gradient buffer combined once per step by launch_grad_combine.
 constexpr int ACC_SLOTS = 8;
 constexpr int GRAD_SLOTS = 8;
+static_assert((ACC_SLOTS & (ACC_SLOTS - 1)) == 0 && (GRAD_SLOTS & (GRAD_SLOTS - 1)) == 0, "slot copies are chosen with blockIdx & (SLOTS - 1)");
 struct BnApplyArgs {
     const float* y; const double* acc; float eps;           // acc[ACC_SLOTS][2][C]: sum y, sum y*y (launch_bn_stats)
     float* mean; float* invstd;                              // saved for the backward pass
