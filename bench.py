@@ -308,7 +308,7 @@ def _train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
     return line
 
 
-SPLIT_KERNELS = ("head_decode", "head_tail", "down_unit", "dwpw", "head_tower", "unit_chain2")      # besides every symbol with "split" in its name
+SPLIT_KERNELS = ("head_decode", "head_tail", "down_unit", "down2", "dwpw", "head_tower", "unit_chain2", "unit_pipe")      # besides every symbol with "split" in its name
 
 
 def is_split_kernel(kern):

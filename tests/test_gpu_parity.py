@@ -648,6 +648,36 @@ def test_unit_chain_bit_identical_to_three_kernel_path(capi, backbone, C, S, B):
     h.close()
 
 
+@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 32), ("1.0x", 20, 160, 2), ("1.0x", 20, 128, 5), ("1.0x", 80, 608, 8), ("0.5x", 80, 416, 16),
+                                             ("0.5x", 20, 160, 6), ("0.5x", 80, 224, 2), ("1.0x", 20, 352, 4)])
+def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S, B):
+    """Round 5: unit_pipe_kernel - the persistent, software-pipelined form of a stride-1 ShuffleV2 unit (LDS-DMA window and pass-through rows
+    of the next tile in flight under the current tile's GEMMs, register-resident weights, depthwise conv from the LDS image) - against
+    unit_chain2_kernel (YN_CHAIN_PIPE=0) on the same handle: raw heads bit for bit.  Shapes: the BASELINE workload (676 tiles of stage 3 on 512
+    walking workgroups: two and three tiles per workgroup), maps whose last tile is partial (10 x 10 x 2 = 200 rows, 8 x 8 x 5 = 320), tiles that
+    straddle images, the 0.5x widths (24 / 48 / 96: both tile shapes), fewer tiles than workgroups (YN_CHAIN_PIPE=2 lifts the size rule)."""
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
+    h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
+    h.load_state_dict(weights.make_state_dict(backbone, C))
+    h.fold_bn()
+    x = dev(weights.make_input(B, S, seed=S + 3 * B))
+    monkeypatch.setenv("YN_CHAIN_PIPE", "0")
+    ref = [t.clone() for t in h.forward_raw(x)]
+    monkeypatch.setenv("YN_CHAIN_PIPE", "2")
+    for rep in range(3):                                     # (a race between a DMA piece and its reader would not repeat)
+        got = [t.clone() for t in h.forward_raw(x)]
+        for u, v in zip(got, ref):
+            assert torch.equal(u, v), rep
+    h.profile_enable(True)
+    h.forward_raw(x)
+    names = [r[1] for r in h.profile_records()]
+    h.profile_enable(False)
+    if S != 608:                                             # (608 x 608: the 38-wide stage-3 window does not leave room for two workgroups per CU yet - unit_chain2_kernel runs)
+        assert any(n.startswith("unit_pipe_kernel") for n in names), names
+    assert h.range_status() == (False, False)
+    h.close()
+
+
 @pytest.mark.parametrize("backbone,C", [("1.0x", 20), ("0.5x", 80)])
 def test_size_sweep_vs_torch_oracle(capi, backbone, C):
     """Odd map sizes, partial tiles, batch 1..3, both widths: raw heads against the torch-CPU oracle at 1e-4 (the kernels pick

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libyolonano_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_h16.hip", []), ("kernels_chain.hip", []), ("yn_api.hip", [])]
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_h16.hip", []), ("kernels_chain.hip", []), ("kernels_pipe.hip", []), ("yn_api.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
           "-Wno-pass-failed"]
 
@@ -36,7 +36,18 @@ def _compile(item):
     return obj
 
 
+def _clean_stale():
+    """-save-temps leftovers (kernels_*.o.0.hipv4-..., *.host-x86_64-...) are not build products: they only ride along to the GPU box"""
+    for f in os.listdir(CSRC):
+        if ".o." in f or "hipv4" in f or "host-x86_64" in f or f.endswith((".bc", ".s", ".hipi", ".hipfb", ".out")):
+            try:
+                os.remove(os.path.join(CSRC, f))
+            except OSError:
+                pass
+
+
 def build(force=False, verbose=False):
+    _clean_stale()
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in _deps()):
         return OUT
     with ThreadPoolExecutor(max_workers=6) as ex:

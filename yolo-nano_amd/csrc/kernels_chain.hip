@@ -961,6 +961,8 @@ static bool unit_chain_dispatch(const ChainArgs& a, hipStream_t s, bool dry)
     }
     static const int chain_v = getenv("YN_CHAIN_V") ? atoi(getenv("YN_CHAIN_V")) : 2;      // 1: the round-2 kernel (A/B runs); 2: unit_chain2_kernel
     if (a.Ws2h && chain_v >= 2) {
+        // round 5: the persistent, software-pipelined form where it applies (kernels_pipe.hip); coverage is still decided by the tiles below
+        if (!dry && launch_unit_pipe(a, s)) return true;
         if (a.Npad == 64 && !v4) YN_UC2(2, 2, 1, 2, 4)
         if (a.Npad == 64 && v4) YN_UC2(2, 2, 1, 4, 4)
         // small maps (one image): 32-row tiles - twice the workgroups, and a workgroup's serial chain (one depthwise round instead of two,

@@ -1,0 +1,401 @@
+// kernels_pipe.hip — unit_pipe_kernel: a stride-1 ShuffleV2 unit (backbone/shufflenetv2.py:53-63, 70-72, 14-28) as a PERSISTENT,
+// software-pipelined tile walk (round 5).  Same cut and same arithmetic as unit_chain2_kernel (kernels_chain.hip):
+//
+//     depthwise 3x3 of the tile's pixels -> pw2 (split-f16 MFMAs) -> (x1, y) pairs = concat + shuffle -> the NEXT unit's pw1 -> global
+//
+// What unit_chain2_kernel could not do: its 338 workgroups of a 416 x 416 / bs 32 stage-3 unit are all resident at once and run their
+// phases in lock step - a 25 MB read burst with every matrix pipe idle, ~25 k cycles of latency-bound phases with the memory system idle,
+// a store burst (40 k cycles per workgroup, 0.20 of the HBM peak three rounds running).  Here
+//   * a workgroup WALKS 32-row tiles (XCD-contiguous ranges, two workgroups of four wavefronts per CU), and the next tile's depthwise
+//     window and pass-through rows are in flight while the current tile runs its two GEMMs: LDS-DMA (global_load_lds_dwordx4: no
+//     registers, no staging instructions), issued right after the barrier that frees the buffer, waited for with a counted
+//     s_waitcnt before the next tile's first barrier;
+//   * the depthwise conv reads its 3 x 3 windows from that fp32 LDS image (conflict-free 16-byte reads: a pixel's channel quads are
+//     consecutive lanes) - the 18-load global round trip per thread and its address arithmetic are gone;
+//   * both GEMMs' weights are REGISTER-RESIDENT for the whole walk (a wavefront owns 32 columns: 8 k-steps x hi/lo x 16 bytes per
+//     lane = 64 registers per matrix) - no weight traffic and no weight latency per tile (unit_chain2_kernel streamed 118 KB of
+//     weights through L1 for every 64-row tile, three k-steps ahead);
+//   * the pass-through half arrives in LDS too and is read where the accumulator layout needs it (16 ds_read_b32 per lane).
+// Every sum runs in the order of the separate kernels (same fma chain per depthwise output, same 16-deep k-steps per accumulator):
+// bit-identical to unit_chain2_kernel and to the three-kernel path (tests/test_gpu_parity.py::test_unit_chain_bit_identical_...).
+#include "yn_internal.h"
+#include "yn_device.h"
+
+#include <cstdlib>
+
+namespace ynk {
+
+typedef _Float16 ph16;
+typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ph16x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (wave-uniform base + 32-bit lane offset) -> LDS (wave-uniform byte address + lane * 16).
+// Invisible to hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.x "What hipcc does not do"): completion is counted by hand below.
+__device__ __forceinline__ void dma16(const void* gbase, unsigned goff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(goff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+// barriers that do NOT drain the vector-memory counter (a __syncthreads() may: its fence waits for this wavefront's global stores, and the
+// in-order counter then retires the DMA pieces in front of them too)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// BF = branch width, compile-time: with run-time strides (bf, the plane stride, out_ld) every unrolled LDS / global access of the
+// epilogues needs its own address register, and the optimiser hoists ~80 of them out of the tile loop - into the registers the weights
+// live in (first form: 348 registers uncapped, 108 spilled at the 256 two workgroups per CU allow, reloaded - vmcnt(0) - inside both GEMMs).
+// LAST = last unit of its stage (no next pw1: the whole shuffled row goes to global).  Both pointwise convs end in ReLU, the depthwise conv
+// in nothing (every ShuffleNetV2 unit; a launch condition).
+template <int BF, bool LAST>
+__global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tiles, float inv_w, float inv_h)
+{
+    constexpr int WM = BF <= 64 ? 2 : 1, WN = 4 / WM, NT = 1, BM = 32 * WM;
+    constexpr int bf = BF, KQ = (BF + 7) >> 3, PS = plane_stride(BF), S = (KQ + 1) >> 1, SMAX = S;
+    constexpr int CPR = BF >> 2;                                        // 16-byte pieces per row (BF % 4 == 0)
+    constexpr bool RELU = true;
+    static_assert(BF % 4 == 0 && BF <= 128, "channel quads, one 32-column tile per wavefront");
+    extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
+    const int W = a.W, H = a.H, HW = H * W;
+    constexpr bool last = LAST;
+    constexpr int out_ld = LAST ? 2 * BF : BF;
+    const unsigned win_bytes = (unsigned)(BM + 2 * W + 2) * (unsigned)bf * 4u;
+    float* win = reinterpret_cast<float*>(up_smem);                     // fp32 window image: flat pixels [m0 - W - 1, m0 + BM + W + 1) x bf
+    float* x1s = reinterpret_cast<float*>(up_smem + win_bytes);         // pass-through rows [BM][bf]
+    ph16* Ph = reinterpret_cast<ph16*>(up_smem + win_bytes + (unsigned)BM * bf * 4u);   // operand planes [BM][PS]
+    ph16* Pl = Ph + BM * PS;
+    int* mtab = reinterpret_cast<int*>(Pl + BM * PS);                   // [BM] nine tap-valid bits per tile row
+    float* taps = reinterpret_cast<float*>(mtab + BM);                  // depthwise weights [9][bf] + bias [bf] (registers are for the GEMM weights)
+    const unsigned lds_win = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)up_smem;
+    const unsigned lds_x1 = lds_win + win_bytes;
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    // XCD-contiguous walk: XCD x (= blockIdx % 8) owns tiles [x TX, (x+1) TX), its workgroups take them round-robin
+    const int TX = (tiles + 7) >> 3, jstep = (int)(gridDim.x >> 3);
+    const int tend = ((int)(blockIdx.x & 7u) + 1) * TX < tiles ? ((int)(blockIdx.x & 7u) + 1) * TX : tiles;
+    int tile = (int)(blockIdx.x & 7u) * TX + (int)(blockIdx.x >> 3);
+    if (tile >= tend) return;
+
+    // Address arithmetic of the DMA pieces: recomputed per tile from an OPAQUE copy of the thread index - as loop invariants the optimiser
+    // hoists one register per piece (14 of them) out of the tile loop and spills them around the GEMMs, and a scratch reload is a vector-memory
+    // load: its s_waitcnt vmcnt(0) retires the DMA pieces in flight
+    const int t1_last = a.M * bf * 4 - 16;                              // (M * bf * 8 < 2^32 is a launch condition)
+    auto issue_window = [&](int tl) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int gs = (tl * BM - W - 1) * (bf * 4) + tt * 16;          // first byte of the window (negative / past the end at the tensor's ends:
+        const int nch = (int)(win_bytes >> 4);                          //  clamped - those pixels' taps are masked)
+        for (int c0 = 0; c0 < nch; c0 += 256) {
+            int src = gs + c0 * 16;
+            src = src < 0 ? 0 : (src > t1_last ? t1_last : src);
+            if (c0 + tt < nch) dma16(a.t1, (unsigned)src, lds_win + (unsigned)(c0 + wave * 64) * 16u);
+        }
+    };
+    auto issue_x1 = [&](int tl) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int m0 = tl * BM;
+        constexpr int nch = BM * CPR;
+#pragma unroll
+        for (int c0 = 0; c0 < nch; c0 += 256) {
+            const int c = c0 + tt;
+            const int row = c / CPR;
+            const int j = c - row * CPR;
+            const int m = m0 + row < a.M ? m0 + row : a.M - 1;
+            const unsigned src = ((unsigned)m * (unsigned)a.x1_ld + (unsigned)a.x1_off) * 4u + (unsigned)j * 16u;
+            if (c < nch) dma16(a.x1, src, lds_x1 + (unsigned)(c0 + wave * 64) * 16u);
+        }
+    };
+    issue_window(tile);
+    issue_x1(tile);
+
+    // ---- loop invariants: both GEMMs' B fragments of this wavefront's columns, the depthwise taps of this thread's channel quad ----
+    ph16x8 bw2[SMAX][NT][2], bw1[SMAX][NT][2];
+    auto load_w = [&](const void* Wh_, const void* Wl_, ph16x8 (&dst)[SMAX][NT][2]) {
+        const ph16* Wh = reinterpret_cast<const ph16*>(Wh_);
+        const ph16* Wl = reinterpret_cast<const ph16*>(Wl_);
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            const int kq = s * 2 + h;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = wn * NT * 32 + nt * 32 + l31;
+                const bool ok = s < S && kq < KQ && n < a.Npad;
+                const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
+                const unsigned mk = opaque_mask(ok);
+                uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
+                vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
+                dst[s][nt][0] = *reinterpret_cast<ph16x8*>(&vh);
+                dst[s][nt][1] = *reinterpret_cast<ph16x8*>(&vl);
+            }
+        }
+    };
+    load_w(a.Ws2h, a.Ws2l, bw2);
+    if constexpr (!last) load_w(a.Ws1h, a.Ws1l, bw1);
+    float bias2[NT], bias1n[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = wn * NT * 32 + nt * 32 + l31;
+        bias2[nt] = n < bf ? a.b2[n] : 0.0f;
+        bias1n[nt] = (!last && n < bf) ? a.b1n[n] : 0.0f;
+    }
+    constexpr int cgn = CPR;                                            // channel quads x runs of four tile rows: the depthwise phase's threads
+    static_assert(cgn * (BM / 4) <= 256, "one depthwise round per tile");
+    const int cq = t % cgn, pl = t / cgn;
+    const bool worker = pl < BM / 4;
+    for (int i = t; i < 10 * CPR; i += 256) {
+        const int k = i / CPR, c4 = i - k * CPR;
+        *reinterpret_cast<float4*>(taps + 4 * i) = *reinterpret_cast<const float4*>((k < 9 ? a.wdw + k * bf : a.bdw) + 4 * c4);
+    }
+    // K tail of both planes: zero once (nothing below writes columns >= bf)
+    {
+        const int padn = PS - bf;
+        for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (ph16)0.0f; Pl[r * PS + c2] = (ph16)0.0f; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0), as an instruction hipcc's scoreboard sees: no wait for these loads inside the loop
+    float amax = 0.0f;                                                  // range guard (yn_device.h)
+    const int jhi = bf >> 1;
+    f32x16 acc0[NT], acc1[NT];
+
+    // activation of the pointwise convs: one v_max_f32 in the RELU instantiation (apply_act's NaN -> 0 and -0 -> +0 included), the run-time form otherwise
+    auto act1 = [&](float v, int act) { return RELU ? __builtin_fmaxf(v, 0.0f) : apply_act(v, act); };
+    auto gemm = [&](const ph16x8 (&bw)[SMAX][NT][2]) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
+        const ph16* ahp = Ph + (wm * 32 + l31) * PS + h * 8;
+        const ph16* alp = Pl + (wm * 32 + l31) * PS + h * 8;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            if (s < S) {
+                const ph16x8 ah = *reinterpret_cast<const ph16x8*>(ahp + s * 16);
+                const ph16x8 al = *reinterpret_cast<const ph16x8*>(alp + s * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][0], acc0[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][1], acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bw[s][nt][0], acc1[nt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
+    };
+    auto split2 = [&](int r, int c, float v0, float v1) {               // two adjacent channels of row r -> both planes
+        amax = range_track(range_track(amax, v0), v1);
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 hi, lo;
+        hi[0] = (ph16)v0; hi[1] = (ph16)v1;
+        lo[0] = (ph16)((v0 - (float)hi[0]) * 2048.0f); lo[1] = (ph16)((v1 - (float)hi[1]) * 2048.0f);
+        *reinterpret_cast<h2*>(Ph + r * PS + c) = hi;
+        *reinterpret_cast<h2*>(Pl + r * PS + c) = lo;
+    };
+
+    // tap-valid bits of a tile's rows (zero padding of the 3 x 3 window; idle rows: nothing valid) -> mtab; written one tile ahead, behind the
+    // barrier that ends the depthwise phase (the only reader)
+    auto write_mtab = [&](int tl) {
+        if (t < BM) {
+            const int m0 = tl * BM;
+            const int rem0 = m0 % HW;                                   // wave-uniform
+            const int y0 = rem0 / W, x0 = rem0 - y0 * W;
+            const int q = x0 + t;
+            const int dy = (int)(((float)q + 0.5f) * inv_w);            // q / W (exact: q < 2^16)
+            const int x = q - dy * W;
+            const int yy = y0 + dy;
+            const int y = yy - (int)(((float)yy + 0.5f) * inv_h) * H;   // rows past the image's last one continue in the next image
+            const int yb = (y >= 1 ? 1 : 0) | 2 | (y + 1 < H ? 4 : 0), xb = (x >= 1 ? 1 : 0) | 2 | (x + 1 < W ? 4 : 0);
+            int bits = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                if ((yb >> ky) & 1) bits |= xb << (3 * ky);
+            mtab[t] = m0 + t < a.M ? bits : 0;
+        }
+    };
+    write_mtab(tile);
+#ifdef YN_EXP_TIMING
+    long long TS[12]; int tsn = 0, titer = 0;
+#define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
+#else
+#define YN_TS()
+#endif
+    for (;;) {
+#ifdef YN_EXP_TIMING
+        tsn = 0;
+#endif
+        YN_TS();
+        const int m0 = tile * BM;
+        const int nrows = a.M - m0 < BM ? a.M - m0 : BM;
+        const int next = tile + jstep < tend ? tile + jstep : -1;
+        YN_TS();
+        lds_barrier();      // (1) this tile's window and pass-through rows have landed (every wavefront waited for its pieces before it got here), mtab is written
+
+        YN_TS();
+        // ---- depthwise 3x3 from the LDS window -> split planes (the fma chain of dwconv3x3_kernel).  Thread = one channel quad of a RUN of
+        //      four consecutive tile rows: its 3 x 6 window is read row by row (18 sixteen-byte LDS reads for four outputs instead of 36) and the
+        //      four outputs' fma chains are independent - one round per tile instead of four dependent ones ----
+        if (worker) {
+            float4 wd[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(taps + k * bf + 4 * cq);
+            const float4 bd = *reinterpret_cast<const float4*>(taps + 9 * bf + 4 * cq);
+            const int r0 = 4 * pl;
+            const int4 bits4 = *reinterpret_cast<const int4*>(mtab + r0);
+            const int bits[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
+            const float* wp = win + (size_t)r0 * bf + 4 * cq;           // window pixel r0 = the top-left neighbour of tile row r0
+            float4 acc[4] = {bd, bd, bd, bd};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float4 row[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) row[i] = *reinterpret_cast<const float4*>(wp + (ky * W + i) * bf);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool ok = (bits[i] >> (ky * 3 + kx)) & 1;
+                        const float4 v = row[i + kx];
+                        vfma(acc[i], make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f), wd[ky * 3 + kx]);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 o = acc[i];
+                // the fp32 value is the result: without this the optimiser folds the last fma and the conversion below into v_fma_mixlo_f16 - ONE
+                // rounding, straight to f16 - and a value that lies exactly between two f16 neighbours once the fma has been rounded to fp32 gets
+                // the other hi (hi + lo * 2^-11 is the same number either way; bit-identity with the other kernels is not: found on 1 pixel of 200)
+                asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+                amax = range_track(range_track(range_track(range_track(amax, o.x), o.y), o.z), o.w);
+                ph16x4 hi, lo;
+                hi[0] = (ph16)o.x; hi[1] = (ph16)o.y; hi[2] = (ph16)o.z; hi[3] = (ph16)o.w;
+                lo[0] = (ph16)((o.x - (float)hi[0]) * 2048.0f); lo[1] = (ph16)((o.y - (float)hi[1]) * 2048.0f);
+                lo[2] = (ph16)((o.z - (float)hi[2]) * 2048.0f); lo[3] = (ph16)((o.w - (float)hi[3]) * 2048.0f);
+                *reinterpret_cast<ph16x4*>(Ph + (r0 + i) * PS + 4 * cq) = hi;
+                *reinterpret_cast<ph16x4*>(Pl + (r0 + i) * PS + 4 * cq) = lo;
+            }
+        }
+        YN_TS();
+        lds_barrier();      // (2) planes complete; every window read has returned: the window buffer is free
+        YN_TS();
+        if (next >= 0) { issue_window(next); write_mtab(next); }        // in flight under both GEMMs and the first epilogue
+        YN_TS();
+        gemm(bw2);
+        YN_TS();
+        if constexpr (!last) lds_barrier();   // (3) every wavefront is done reading the planes (the epilogue writes x2' into them)
+
+        // ---- y = act(acc + b2) straight to its final place: (x1, y) pairs -> global, or split into the planes as x2'.  Row groups of
+        //      eight are live or idle as a whole (M % 8 == 0 is a launch condition): scalar branches only, one exec region per destination ----
+        {
+            char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * out_ld);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = wn * NT * 32 + nt * 32 + l31;
+                const float bias = bias2[nt];
+                const bool to_global = n < (last ? bf : jhi);
+                const bool to_plane = !last && n >= jhi && n < bf;
+                const float* xr = x1s + (wm * 32 + 4 * h) * bf + (n < bf ? n : 0);
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    if (wm * 32 + 8 * g8 < nrows) {                     // scalar condition
+                        float y[4], xv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[q] = xr[(q + 8 * g8) * bf];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = act1(acc0[nt][4 * g8 + q] + bias, a.act2);
+                        if (to_global) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int row = wm * 32 + q + 8 * g8 + 4 * h;
+                                *reinterpret_cast<float2*>(out_base + (unsigned)(row * out_ld + 2 * n) * 4u) = make_float2(xv[q], y[q]);
+                            }
+                        }
+                        if (to_plane) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) split2(wm * 32 + q + 8 * g8 + 4 * h, 2 * (n - jhi), xv[q], y[q]);
+                        }
+                    }
+                }
+            }
+        }
+        YN_TS();
+        lds_barrier();      // (4) x2' complete; the pass-through buffer is free
+        if (next >= 0) issue_x1(next);
+        YN_TS();
+        if constexpr (!last) {
+            // ---- the next unit's pw1 on x2' -> global ----
+            gemm(bw1);
+            YN_TS();
+            vm_drain();
+            YN_TS();     // the next tile's pieces (and this tile's first stores, long gone) - BEFORE the stores below, which need not be waited for
+            GemmArgs e{};
+            e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = m0 + nrows; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
+            gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, true, lane, bias1n);
+        } else {
+            vm_drain();
+        }
+#ifdef YN_EXP_TIMING
+        YN_TS();
+        if (!last && t == 0 && (blockIdx.x % 61) == 5)
+            printf("pipe bf %d blk %d iter %d: top %lld wait1 %lld dw %lld bar2 %lld issue %lld gemm1 %lld bar3+epi1 %lld bar4+x1 %lld gemm2 %lld drain %lld epi2 %lld total %lld\n", bf, (int)blockIdx.x, titer,
+                   TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2], TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5], TS[7] - TS[6], TS[8] - TS[7], TS[9] - TS[8], TS[10] - TS[9], TS[11] - TS[10], TS[11] - TS[0]);
+        ++titer;
+#endif
+        if (next < 0) break;
+        tile = next;
+    }
+#undef YN_TS
+    range_report(a.ovf, amax);
+}
+
+static size_t unit_pipe_lds(int bf, int W, int BM)
+{
+    return (size_t)(BM + 2 * W + 2) * bf * 4 + (size_t)BM * bf * 4 + (size_t)2 * BM * plane_stride(bf) * 2 + (size_t)BM * 4 + (size_t)10 * bf * 4;
+}
+
+// The persistent form of a stride-1 unit where it applies: split-f16 family, an instantiated branch width, ReLU pointwise / linear depthwise
+// convs, dense depthwise input, whole row groups of eight, a workgroup small enough for two per CU, 32-bit byte offsets, enough tiles to
+// walk.  false = not launched (the caller runs unit_chain2_kernel).
+bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
+{
+    // (read at every launch: the tests compare both forms inside one process)
+    const int mode = getenv("YN_CHAIN_PIPE") ? atoi(getenv("YN_CHAIN_PIPE")) : 1;                // 0: never (A/B), 1: default, 2: also for few tiles
+    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : 256;
+    const int wg_cap = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512;
+    const bool last = a.Wp1n == nullptr;
+    if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;
+    if (a.dw_act != 0 || a.act2 != 1 || (!last && a.act1n != 1)) return false;
+    if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & 3) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
+    if (a.Npad != ((a.bf + 31) & ~31)) return false;
+    if ((double)a.M * a.bf * 8.0 >= 4.0e9 || (double)a.M * a.x1_ld * 4.0 >= 4.0e9) return false;
+#define YN_UP(BFv, LASTv)                                                                                                \
+    {                                                                                                                    \
+        constexpr int BM = BFv <= 64 ? 64 : 32;                                                                          \
+        const size_t lds = unit_pipe_lds(a.bf, a.W, BM);                                                                 \
+        const int tiles = (a.M + BM - 1) / BM;                                                                           \
+        if (lds > 80 * 1024 || (mode < 2 && tiles < min_tiles)) return false;                                            \
+        if (dry) return true;                                                                                            \
+        static unsigned long long attr = 0;                                                                              \
+        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_pipe_kernel<BFv, LASTv>),  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); }                 \
+        unsigned g = xcd_grid((unsigned)tiles);                                                                          \
+        if (g > (unsigned)wg_cap) g = (unsigned)wg_cap;                                                                  \
+        set_last_kernel_name("unit_pipe_kernel<" #BFv "," #LASTv ">");                                                    \
+        hipLaunchKernelGGL((unit_pipe_kernel<BFv, LASTv>), dim3(g), dim3(256), lds, s, a, tiles, 1.0f / (float)a.W, 1.0f / (float)a.H); \
+        return true;                                                                                                     \
+    }
+#define YN_UPB(BFv) if (a.bf == BFv) { if (last) YN_UP(BFv, true) else YN_UP(BFv, false) }
+    YN_UPB(116)          // 1.0x stage 3
+    YN_UPB(96)           // 0.5x stage 4
+    YN_UPB(48)           // 0.5x stage 3
+    YN_UPB(24)           // 0.5x stage 2
+#undef YN_UPB
+#undef YN_UP
+    return false;
+}
+
+}  // namespace ynk

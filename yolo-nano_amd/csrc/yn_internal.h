@@ -46,6 +46,7 @@ struct ChainArgs {
     unsigned* ovf;                              // split-f16 range guard flag or null
 };
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
+bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry = false);   // kernels_pipe.hip: the persistent tile walk; false = not applicable, nothing launched
 
 // The main branch of a stride-2 ShuffleV2 unit as ONE kernel (kernels_chain.hip, down_unit_kernel): pw1 -> depthwise 3x3 stride 2 ->
 // pw2 -> concat + shuffle with the other branch's output.
