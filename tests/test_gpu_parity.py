@@ -672,8 +672,9 @@ def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S,
     h.forward_raw(x)
     names = [r[1] for r in h.profile_records()]
     h.profile_enable(False)
-    if S != 608:                                             # (608 x 608: the 38-wide stage-3 window does not leave room for two workgroups per CU yet - unit_chain2_kernel runs)
-        assert any(n.startswith("unit_pipe_kernel") for n in names), names
+    assert any(n.startswith("unit_pipe_kernel") for n in names), names
+    if S == 608:                                             # the 38-wide stage-3 window: one eight-wavefront workgroup per CU instead of two of four
+        assert any(n.startswith("unit_pipe_kernel<116,false,8>") for n in names), names
     assert h.range_status() == (False, False)
     h.close()
 

@@ -22,6 +22,7 @@
 #include "yn_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ynk {
 
@@ -49,14 +50,20 @@ __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 // live in (first form: 348 registers uncapped, 108 spilled at the 256 two workgroups per CU allow, reloaded - vmcnt(0) - inside both GEMMs).
 // LAST = last unit of its stage (no next pw1: the whole shuffled row goes to global).  Both pointwise convs end in ReLU, the depthwise conv
 // in nothing (every ShuffleNetV2 unit; a launch condition).
-template <int BF, bool LAST>
-__global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tiles, float inv_w, float inv_h)
+// NW = wavefronts per workgroup: 4 (two workgroups per CU) or 8 (one, twice the rows per tile - where a map is so wide that two windows do not
+// fit a CU's LDS: 608 x 608 stage 3) - two wavefronts per SIMD and 256 registers either way.
+template <int BF, bool LAST, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int tiles, float inv_w, float inv_h)
 {
-    constexpr int WM = BF <= 64 ? 2 : 1, WN = 4 / WM, NT = 1, BM = 32 * WM;
+    constexpr int WN = BF <= 64 ? 2 : (BF <= 128 ? 4 : 8), WM = NW / WN, NT = 1, BM = 32 * WM, NTHR = 64 * NW;
+    // STREAM (branches wider than 128: 15 k-steps per GEMM = 120 registers per matrix): ONE register panel.  While a GEMM walks it, every
+    // k-step's fragments are replaced - behind the MFMAs that read them - by the same step of the matrix the NEXT GEMM needs (the next pointwise
+    // conv of this tile, or pw2 of the next tile): a whole GEMM + an epilogue of flight time instead of unit_chain2_kernel's three k-steps
+    constexpr bool STREAM = BF > 128;
     constexpr int bf = BF, KQ = (BF + 7) >> 3, PS = plane_stride(BF), S = (KQ + 1) >> 1, SMAX = S;
     constexpr int CPR = BF >> 2;                                        // 16-byte pieces per row (BF % 4 == 0)
     constexpr bool RELU = true;
-    static_assert(BF % 4 == 0 && BF <= 128, "channel quads, one 32-column tile per wavefront");
+    static_assert(BF % 4 == 0 && BF <= 256 && WM >= 1 && WM * WN == NW, "channel quads, one 32-column tile per wavefront");
     extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
     const int W = a.W, H = a.H, HW = H * W;
     constexpr bool last = LAST;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         asm volatile("" : "+v"(tt));
         const int gs = (tl * BM - W - 1) * (bf * 4) + tt * 16;          // first byte of the window (negative / past the end at the tensor's ends:
         const int nch = (int)(win_bytes >> 4);                          //  clamped - those pixels' taps are masked)
-        for (int c0 = 0; c0 < nch; c0 += 256) {
+        for (int c0 = 0; c0 < nch; c0 += NTHR) {
             int src = gs + c0 * 16;
             src = src < 0 ? 0 : (src > t1_last ? t1_last : src);
             if (c0 + tt < nch) dma16(a.t1, (unsigned)src, lds_win + (unsigned)(c0 + wave * 64) * 16u);
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         const int m0 = tl * BM;
         constexpr int nch = BM * CPR;
 #pragma unroll
-        for (int c0 = 0; c0 < nch; c0 += 256) {
+        for (int c0 = 0; c0 < nch; c0 += NTHR) {
             const int c = c0 + tt;
             const int row = c / CPR;
             const int j = c - row * CPR;
@@ -113,28 +120,29 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
     issue_x1(tile);
 
     // ---- loop invariants: both GEMMs' B fragments of this wavefront's columns, the depthwise taps of this thread's channel quad ----
-    ph16x8 bw2[SMAX][NT][2], bw1[SMAX][NT][2];
-    auto load_w = [&](const void* Wh_, const void* Wl_, ph16x8 (&dst)[SMAX][NT][2]) {
+    ph16x8 bw2[SMAX][NT][2], bw1[STREAM ? 1 : SMAX][NT][2];
+    auto load_step = [&](const void* Wh_, const void* Wl_, int s, ph16x8 (&dst)[NT][2]) {   // the fragments of k-step s
         const ph16* Wh = reinterpret_cast<const ph16*>(Wh_);
         const ph16* Wl = reinterpret_cast<const ph16*>(Wl_);
+        const int kq = s * 2 + h;
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s) {
-            const int kq = s * 2 + h;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = wn * NT * 32 + nt * 32 + l31;
-                const bool ok = s < S && kq < KQ && n < a.Npad;
-                const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
-                const unsigned mk = opaque_mask(ok);
-                uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
-                vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
-                dst[s][nt][0] = *reinterpret_cast<ph16x8*>(&vh);
-                dst[s][nt][1] = *reinterpret_cast<ph16x8*>(&vl);
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = wn * NT * 32 + nt * 32 + l31;
+            const bool ok = s < S && kq < KQ && n < a.Npad;
+            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
+            const unsigned mk = opaque_mask(ok);
+            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
+            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
+            dst[nt][0] = *reinterpret_cast<ph16x8*>(&vh);
+            dst[nt][1] = *reinterpret_cast<ph16x8*>(&vl);
         }
     };
+    auto load_w = [&](const void* Wh, const void* Wl, ph16x8 (&dst)[SMAX][NT][2]) {
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) load_step(Wh, Wl, s, dst[s]);
+    };
     load_w(a.Ws2h, a.Ws2l, bw2);
-    if constexpr (!last) load_w(a.Ws1h, a.Ws1l, bw1);
+    if constexpr (!last && !STREAM) load_w(a.Ws1h, a.Ws1l, bw1);
     float bias2[NT], bias1n[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -143,17 +151,17 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         bias1n[nt] = (!last && n < bf) ? a.b1n[n] : 0.0f;
     }
     constexpr int cgn = CPR;                                            // channel quads x runs of four tile rows: the depthwise phase's threads
-    static_assert(cgn * (BM / 4) <= 256, "one depthwise round per tile");
+    static_assert(cgn * (BM / 4) <= NTHR, "one depthwise round per tile");
     const int cq = t % cgn, pl = t / cgn;
     const bool worker = pl < BM / 4;
-    for (int i = t; i < 10 * CPR; i += 256) {
+    for (int i = t; i < 10 * CPR; i += NTHR) {
         const int k = i / CPR, c4 = i - k * CPR;
         *reinterpret_cast<float4*>(taps + 4 * i) = *reinterpret_cast<const float4*>((k < 9 ? a.wdw + k * bf : a.bdw) + 4 * c4);
     }
     // K tail of both planes: zero once (nothing below writes columns >= bf)
     {
         const int padn = PS - bf;
-        for (int i = t; i < BM * padn; i += 256) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (ph16)0.0f; Pl[r * PS + c2] = (ph16)0.0f; }
+        for (int i = t; i < BM * padn; i += NTHR) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (ph16)0.0f; Pl[r * PS + c2] = (ph16)0.0f; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0), as an instruction hipcc's scoreboard sees: no wait for these loads inside the loop
     float amax = 0.0f;                                                  // range guard (yn_device.h)
@@ -162,7 +170,14 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
 
     // activation of the pointwise convs: one v_max_f32 in the RELU instantiation (apply_act's NaN -> 0 and -0 -> +0 included), the run-time form otherwise
     auto act1 = [&](float v, int act) { return RELU ? __builtin_fmaxf(v, 0.0f) : apply_act(v, act); };
-    auto gemm = [&](const ph16x8 (&bw)[SMAX][NT][2]) {
+    // refill != null (STREAM): k-step s of that matrix replaces the fragments the MFMAs of step s have just read
+    const unsigned lane_w = ((unsigned)h * (WN * 32u) + (unsigned)wn * 32u + (unsigned)l31) * 16u;      // byte offset of this lane's fragment inside a k-step of a pack
+    // which: 0 = no refill, 1 = refill with the next pointwise conv's matrix, 2 = with pw2 (for the next tile); do_refill: wave-uniform
+    auto gemm = [&](ph16x8 (&bw)[SMAX][NT][2], auto which, bool refill) {
+        const char* refill_h = reinterpret_cast<const char*>(decltype(which)::value == 1 ? a.Ws1h : a.Ws2h);
+        const char* refill_l = reinterpret_cast<const char*>(decltype(which)::value == 1 ? a.Ws1l : a.Ws2l);
+        unsigned lw = lane_w;                                           // (opaque per call: as loop invariants the per-step addresses are hoisted out of the tile loop)
+        asm volatile("" : "+v"(lw));
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -171,14 +186,24 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         const ph16* alp = Pl + (wm * 32 + l31) * PS + h * 8;
 #pragma unroll
         for (int s = 0; s < SMAX; ++s) {
-            if (s < S) {
-                const ph16x8 ah = *reinterpret_cast<const ph16x8*>(ahp + s * 16);
-                const ph16x8 al = *reinterpret_cast<const ph16x8*>(alp + s * 16);
+            const ph16x8 ah = *reinterpret_cast<const ph16x8*>(ahp + s * 16);
+            const ph16x8 al = *reinterpret_cast<const ph16x8*>(alp + s * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][0], acc0[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][1], acc1[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bw[s][nt][0], acc1[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][0], acc0[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][nt][1], acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bw[s][nt][0], acc1[nt], 0, 0, 0);
+            }
+            if constexpr (STREAM && decltype(which)::value != 0) {
+                // No mask on this path (a masked load needs a temporary per load in flight: 120 registers), and ONE lane offset for all k-steps
+                // (wave-uniform base + s * 8 KB: per-step 64-bit lane addresses are 60 loop-invariant registers - hoisted, spilled and reloaded
+                // through vmcnt(0) in the first form).  The one octet past the matrix (the last half k-step of an odd octet count) reads the last
+                // valid octet instead: finite weights against the planes' zero K tail.
+                if (refill) {
+                    const unsigned kq = (s * 2 + 1 < KQ) ? (unsigned)(s * 2 + h) : (unsigned)(s * 2 + h < KQ ? s * 2 + h : KQ - 1);
+                    const unsigned off = (s * 2 + 1 < KQ) ? lw + (unsigned)s * (2u * WN * 32u * 16u) : lw - (unsigned)h * (WN * 32u * 16u) + kq * (WN * 32u * 16u);
+                    bw[s][0][0] = *reinterpret_cast<const ph16x8*>(refill_h + off);
+                    bw[s][0][1] = *reinterpret_cast<const ph16x8*>(refill_l + off);
                 }
             }
         }
@@ -284,7 +309,12 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         YN_TS();
         if (next >= 0) { issue_window(next); write_mtab(next); }        // in flight under both GEMMs and the first epilogue
         YN_TS();
-        gemm(bw2);
+        if constexpr (STREAM) {                                         // ... and, behind its k-steps, the matrix of the next GEMM
+            if constexpr (last) gemm(bw2, std::integral_constant<int, 0>{}, false);     // (its own panel: stays)
+            else gemm(bw2, std::integral_constant<int, 1>{}, true);
+        } else {
+            gemm(bw2, std::integral_constant<int, 0>{}, false);
+        }
         YN_TS();
         if constexpr (!last) lds_barrier();   // (3) every wavefront is done reading the planes (the epilogue writes x2' into them)
 
@@ -328,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void unit_pipe_kernel(ChainArgs a, int tile
         YN_TS();
         if constexpr (!last) {
             // ---- the next unit's pw1 on x2' -> global ----
-            gemm(bw1);
+            if constexpr (STREAM) gemm(bw2, std::integral_constant<int, 2>{}, next >= 0);     // bw2 holds pw1n now; pw2 of the next tile follows
+            else gemm(bw1, std::integral_constant<int, 0>{}, false);
             YN_TS();
             vm_drain();
             YN_TS();     // the next tile's pieces (and this tile's first stores, long gone) - BEFORE the stores below, which need not be waited for
@@ -364,36 +395,45 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
 {
     // (read at every launch: the tests compare both forms inside one process)
     const int mode = getenv("YN_CHAIN_PIPE") ? atoi(getenv("YN_CHAIN_PIPE")) : 1;                // 0: never (A/B), 1: default, 2: also for few tiles
-    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : 256;
+    // size rule: the walk pays from about one tile per workgroup slot; the streamed wide form (one tile per workgroup at bs 32) from a third of the chip
+    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : (a.bf > 128 ? 96 : 256);
     const int wg_cap = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512;
     const bool last = a.Wp1n == nullptr;
     if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;
     if (a.dw_act != 0 || a.act2 != 1 || (!last && a.act1n != 1)) return false;
     if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & 3) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
     if (a.Npad != ((a.bf + 31) & ~31)) return false;
+    if (a.bf > 128 && a.Npad != 256) return false;                       // the streamed form indexes its pack with the full eight column tiles
     if ((double)a.M * a.bf * 8.0 >= 4.0e9 || (double)a.M * a.x1_ld * 4.0 >= 4.0e9) return false;
-#define YN_UP(BFv, LASTv)                                                                                                \
+#define YN_UP(BFv, LASTv, NWv)                                                                                           \
     {                                                                                                                    \
-        constexpr int BM = BFv <= 64 ? 64 : 32;                                                                          \
+        constexpr int BM = 32 * (NWv / (BFv <= 64 ? 2 : (BFv <= 128 ? 4 : 8)));                                                             \
         const size_t lds = unit_pipe_lds(a.bf, a.W, BM);                                                                 \
         const int tiles = (a.M + BM - 1) / BM;                                                                           \
-        if (lds > 80 * 1024 || (mode < 2 && tiles < min_tiles)) return false;                                            \
-        if (dry) return true;                                                                                            \
-        static unsigned long long attr = 0;                                                                              \
-        if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_pipe_kernel<BFv, LASTv>),  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); }                 \
-        unsigned g = xcd_grid((unsigned)tiles);                                                                          \
-        if (g > (unsigned)wg_cap) g = (unsigned)wg_cap;                                                                  \
-        set_last_kernel_name("unit_pipe_kernel<" #BFv "," #LASTv ">");                                                    \
-        hipLaunchKernelGGL((unit_pipe_kernel<BFv, LASTv>), dim3(g), dim3(256), lds, s, a, tiles, 1.0f / (float)a.W, 1.0f / (float)a.H); \
-        return true;                                                                                                     \
+        if (lds <= (size_t)(NWv == 4 ? 80 : 160) * 1024) {                                                               \
+            if (mode < 2 && tiles < min_tiles) return false;                                                             \
+            if (dry) return true;                                                                                        \
+            static unsigned long long attr = 0;                                                                          \
+            if (attr_pending(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unit_pipe_kernel<BFv, LASTv, NWv>), \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (NWv == 4 ? 80 : 160) * 1024); }  \
+            unsigned g = xcd_grid((unsigned)tiles);                                                                      \
+            const unsigned cap = (unsigned)(NWv == 4 ? wg_cap : wg_cap / 2);                                             \
+            if (g > cap) g = cap;                                                                                        \
+            set_last_kernel_name("unit_pipe_kernel<" #BFv "," #LASTv "," #NWv ">");                                       \
+            hipLaunchKernelGGL((unit_pipe_kernel<BFv, LASTv, NWv>), dim3(g), dim3(64 * NWv), lds, s, a, tiles, 1.0f / (float)a.W, 1.0f / (float)a.H); \
+            return true;                                                                                                 \
+        }                                                                                                                \
     }
-#define YN_UPB(BFv) if (a.bf == BFv) { if (last) YN_UP(BFv, true) else YN_UP(BFv, false) }
+    // two four-wavefront workgroups per CU where their windows fit, else one of eight
+#define YN_UPB(BFv) if (a.bf == BFv) { if (last) { YN_UP(BFv, true, 4) YN_UP(BFv, true, 8) } else { YN_UP(BFv, false, 4) YN_UP(BFv, false, 8) } return false; }
+#define YN_UPW(BFv) if (a.bf == BFv) { if (last) { YN_UP(BFv, true, 8) } else { YN_UP(BFv, false, 8) } return false; }        // eight column tiles: eight wavefronts
+    YN_UPW(232)          // 1.0x stage 4 (streamed weights)
     YN_UPB(116)          // 1.0x stage 3
     YN_UPB(96)           // 0.5x stage 4
     YN_UPB(48)           // 0.5x stage 3
     YN_UPB(24)           // 0.5x stage 2
 #undef YN_UPB
+#undef YN_UPW
 #undef YN_UP
     return false;
 }
