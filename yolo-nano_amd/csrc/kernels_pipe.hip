@@ -61,22 +61,30 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     // conv of this tile, or pw2 of the next tile): a whole GEMM + an epilogue of flight time instead of unit_chain2_kernel's three k-steps
     constexpr bool STREAM = BF > 128;
     constexpr int bf = BF, KQ = (BF + 7) >> 3, PS = plane_stride(BF), S = (KQ + 1) >> 1, SMAX = S;
-    constexpr int CPR = BF >> 2;                                        // 16-byte pieces per row (BF % 4 == 0)
+    // channel quads where the width allows, else pairs (58, 122: rows are 8-byte aligned only).  The window is a flat byte range either way: its
+    // DMA pieces start at the 16-byte boundary below its first byte (`sh` = 0 or 8 bytes of lead-in per tile); the pass-through rows get 16-byte
+    // padded LDS rows, their last piece reading up to 8 bytes past the row (and, for the tensor's last row, past the tensor: t1 / x1 are arena
+    // buffers - 256-byte granules with slack behind the last one, yn_api.hip arena_take)
+    constexpr int VEC = BF % 4 == 0 ? 4 : 2, CG = BF / VEC, RUN = VEC == 4 ? 4 : 8;      // channel groups; tile rows per depthwise thread
+    constexpr unsigned ROWB = BF * 4u;                                  // bytes per row
+    constexpr int X1C = (int)((ROWB + 15u) / 16u), X1S = X1C * 4;       // 16-byte pieces / floats per pass-through row in LDS
+    typedef typename VecT<VEC>::type vec;
     constexpr bool RELU = true;
-    static_assert(BF % 4 == 0 && BF <= 256 && WM >= 1 && WM * WN == NW, "channel quads, one 32-column tile per wavefront");
+    static_assert(BF % 2 == 0 && BF <= 256 && WM >= 1 && WM * WN == NW && (VEC == 4 || !STREAM), "channel pairs at least, one 32-column tile per wavefront");
     extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
     const int W = a.W, H = a.H, HW = H * W;
     constexpr bool last = LAST;
     constexpr int out_ld = LAST ? 2 * BF : BF;
-    const unsigned win_bytes = (unsigned)(BM + 2 * W + 2) * (unsigned)bf * 4u;
-    float* win = reinterpret_cast<float*>(up_smem);                     // fp32 window image: flat pixels [m0 - W - 1, m0 + BM + W + 1) x bf
-    float* x1s = reinterpret_cast<float*>(up_smem + win_bytes);         // pass-through rows [BM][bf]
-    ph16* Ph = reinterpret_cast<ph16*>(up_smem + win_bytes + (unsigned)BM * bf * 4u);   // operand planes [BM][PS]
+    const unsigned win_bytes = (unsigned)(BM + 2 * W + 2) * ROWB;
+    const unsigned win_lds = (win_bytes + 8u + 15u) & ~15u;             // + the lead-in, in whole pieces
+    unsigned char* win = up_smem;                                       // fp32 window image: flat pixels [m0 - W - 1, m0 + BM + W + 1) x bf, from byte `sh`
+    float* x1s = reinterpret_cast<float*>(up_smem + win_lds);           // pass-through rows [BM][X1S]
+    ph16* Ph = reinterpret_cast<ph16*>(up_smem + win_lds + (unsigned)BM * X1S * 4u);   // operand planes [BM][PS]
     ph16* Pl = Ph + BM * PS;
     int* mtab = reinterpret_cast<int*>(Pl + BM * PS);                   // [BM] nine tap-valid bits per tile row
     float* taps = reinterpret_cast<float*>(mtab + BM);                  // depthwise weights [9][bf] + bias [bf] (registers are for the GEMM weights)
     const unsigned lds_win = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)up_smem;
-    const unsigned lds_x1 = lds_win + win_bytes;
+    const unsigned lds_x1 = lds_win + win_lds;
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
@@ -89,15 +97,18 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     // Address arithmetic of the DMA pieces: recomputed per tile from an OPAQUE copy of the thread index - as loop invariants the optimiser
     // hoists one register per piece (14 of them) out of the tile loop and spills them around the GEMMs, and a scratch reload is a vector-memory
     // load: its s_waitcnt vmcnt(0) retires the DMA pieces in flight
-    const int t1_last = a.M * bf * 4 - 16;                              // (M * bf * 8 < 2^32 is a launch condition)
+    const int t1_lim = ((a.M * (int)ROWB + 15) & ~15) - 16;             // last piece that holds a byte of t1 (M * bf * 8 < 2^32 is a launch condition)
+    auto win_lead = [&](int tl) { return ROWB % 16u == 0 ? 0 : (((tl * BM - W - 1) * (int)ROWB) & 15); };        // 0, or 8 for channel pairs and an odd first pixel
     auto issue_window = [&](int tl) {
         int tt = t;
         asm volatile("" : "+v"(tt));
-        const int gs = (tl * BM - W - 1) * (bf * 4) + tt * 16;          // first byte of the window (negative / past the end at the tensor's ends:
-        const int nch = (int)(win_bytes >> 4);                          //  clamped - those pixels' taps are masked)
+        const int g0 = (tl * BM - W - 1) * (int)ROWB;                   // first byte of the window (negative / past the end at the tensor's ends:
+        const int sh = ROWB % 16u == 0 ? 0 : (g0 & 15);                 //  clamped - those pixels' taps are masked)
+        const int gs = g0 - sh + tt * 16;
+        const int nch = (int)((win_bytes + (unsigned)sh + 15u) >> 4);
         for (int c0 = 0; c0 < nch; c0 += NTHR) {
             int src = gs + c0 * 16;
-            src = src < 0 ? 0 : (src > t1_last ? t1_last : src);
+            src = src < 0 ? 0 : (src > t1_lim ? t1_lim : src);
             if (c0 + tt < nch) dma16(a.t1, (unsigned)src, lds_win + (unsigned)(c0 + wave * 64) * 16u);
         }
     };
@@ -105,12 +116,12 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
         int tt = t;
         asm volatile("" : "+v"(tt));
         const int m0 = tl * BM;
-        constexpr int nch = BM * CPR;
+        constexpr int nch = BM * X1C;
 #pragma unroll
         for (int c0 = 0; c0 < nch; c0 += NTHR) {
             const int c = c0 + tt;
-            const int row = c / CPR;
-            const int j = c - row * CPR;
+            const int row = c / X1C;
+            const int j = c - row * X1C;
             const int m = m0 + row < a.M ? m0 + row : a.M - 1;
             const unsigned src = ((unsigned)m * (unsigned)a.x1_ld + (unsigned)a.x1_off) * 4u + (unsigned)j * 16u;
             if (c < nch) dma16(a.x1, src, lds_x1 + (unsigned)(c0 + wave * 64) * 16u);
@@ -150,13 +161,12 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
         bias2[nt] = n < bf ? a.b2[n] : 0.0f;
         bias1n[nt] = (!last && n < bf) ? a.b1n[n] : 0.0f;
     }
-    constexpr int cgn = CPR;                                            // channel quads x runs of four tile rows: the depthwise phase's threads
-    static_assert(cgn * (BM / 4) <= NTHR, "one depthwise round per tile");
-    const int cq = t % cgn, pl = t / cgn;
-    const bool worker = pl < BM / 4;
-    for (int i = t; i < 10 * CPR; i += NTHR) {
-        const int k = i / CPR, c4 = i - k * CPR;
-        *reinterpret_cast<float4*>(taps + 4 * i) = *reinterpret_cast<const float4*>((k < 9 ? a.wdw + k * bf : a.bdw) + 4 * c4);
+    static_assert(CG * (BM / RUN) <= NTHR, "one depthwise round per tile");     // channel groups x runs of RUN tile rows: the depthwise phase's threads
+    const int cq = t % CG, pl = t / CG;
+    const bool worker = pl < BM / RUN;
+    for (int i = t; i < 10 * (BF / 2); i += NTHR) {
+        const int k = i / (BF / 2), c2 = i - k * (BF / 2);
+        *reinterpret_cast<float2*>(taps + 2 * i) = *reinterpret_cast<const float2*>((k < 9 ? a.wdw + k * bf : a.bdw) + 2 * c2);
     }
     // K tail of both planes: zero once (nothing below writes columns >= bf)
     {
@@ -261,47 +271,61 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
         lds_barrier();      // (1) this tile's window and pass-through rows have landed (every wavefront waited for its pieces before it got here), mtab is written
 
         YN_TS();
-        // ---- depthwise 3x3 from the LDS window -> split planes (the fma chain of dwconv3x3_kernel).  Thread = one channel quad of a RUN of
-        //      four consecutive tile rows: its 3 x 6 window is read row by row (18 sixteen-byte LDS reads for four outputs instead of 36) and the
-        //      four outputs' fma chains are independent - one round per tile instead of four dependent ones ----
+        // ---- depthwise 3x3 from the LDS window -> split planes (the fma chain of dwconv3x3_kernel).  Thread = one channel group (quad, or pair)
+        //      of a RUN of consecutive tile rows (4, or 8): its 3 x (RUN + 2) window is read row by row (18 sixteen-byte LDS reads for four
+        //      outputs instead of 36) and the outputs' fma chains are independent - one round per tile instead of four dependent ones ----
         if (worker) {
-            float4 wd[9];
+            vec wd[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(taps + k * bf + 4 * cq);
-            const float4 bd = *reinterpret_cast<const float4*>(taps + 9 * bf + 4 * cq);
-            const int r0 = 4 * pl;
-            const int4 bits4 = *reinterpret_cast<const int4*>(mtab + r0);
-            const int bits[4] = {bits4.x, bits4.y, bits4.z, bits4.w};
-            const float* wp = win + (size_t)r0 * bf + 4 * cq;           // window pixel r0 = the top-left neighbour of tile row r0
-            float4 acc[4] = {bd, bd, bd, bd};
+            for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const vec*>(taps + k * bf + VEC * cq);
+            const vec bd = *reinterpret_cast<const vec*>(taps + 9 * bf + VEC * cq);
+            const int r0 = RUN * pl;
+            int bits[RUN];
+#pragma unroll
+            for (int q = 0; q < RUN / 4; ++q) {
+                const int4 b4 = *reinterpret_cast<const int4*>(mtab + r0 + 4 * q);
+                bits[4 * q] = b4.x; bits[4 * q + 1] = b4.y; bits[4 * q + 2] = b4.z; bits[4 * q + 3] = b4.w;
+            }
+            // window pixel r0 = the top-left neighbour of tile row r0; the image starts `lead` bytes into the buffer
+            const unsigned char* wp = win + win_lead(tile) + ((unsigned)r0 * bf + VEC * cq) * 4u;
+            vec acc[RUN];
+#pragma unroll
+            for (int i = 0; i < RUN; ++i) acc[i] = bd;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                float4 row[6];
+                vec row[RUN + 2];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) row[i] = *reinterpret_cast<const float4*>(wp + (ky * W + i) * bf);
+                for (int i = 0; i < RUN + 2; ++i) row[i] = *reinterpret_cast<const vec*>(wp + (unsigned)((ky * W + i) * bf) * 4u);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RUN; ++i)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const bool ok = (bits[i] >> (ky * 3 + kx)) & 1;
-                        const float4 v = row[i + kx];
-                        vfma(acc[i], make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f), wd[ky * 3 + kx]);
+                        vec v = row[i + kx];
+                        if constexpr (VEC == 4) v = make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+                        else v = make_float2(ok ? v.x : 0.0f, ok ? v.y : 0.0f);
+                        vfma(acc[i], v, wd[ky * 3 + kx]);
                     }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 o = acc[i];
-                // the fp32 value is the result: without this the optimiser folds the last fma and the conversion below into v_fma_mixlo_f16 - ONE
-                // rounding, straight to f16 - and a value that lies exactly between two f16 neighbours once the fma has been rounded to fp32 gets
-                // the other hi (hi + lo * 2^-11 is the same number either way; bit-identity with the other kernels is not: found on 1 pixel of 200)
-                asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
-                amax = range_track(range_track(range_track(range_track(amax, o.x), o.y), o.z), o.w);
-                ph16x4 hi, lo;
-                hi[0] = (ph16)o.x; hi[1] = (ph16)o.y; hi[2] = (ph16)o.z; hi[3] = (ph16)o.w;
-                lo[0] = (ph16)((o.x - (float)hi[0]) * 2048.0f); lo[1] = (ph16)((o.y - (float)hi[1]) * 2048.0f);
-                lo[2] = (ph16)((o.z - (float)hi[2]) * 2048.0f); lo[3] = (ph16)((o.w - (float)hi[3]) * 2048.0f);
-                *reinterpret_cast<ph16x4*>(Ph + (r0 + i) * PS + 4 * cq) = hi;
-                *reinterpret_cast<ph16x4*>(Pl + (r0 + i) * PS + 4 * cq) = lo;
+            for (int i = 0; i < RUN; ++i) {
+                float o[VEC];
+                if constexpr (VEC == 4) { o[0] = acc[i].x; o[1] = acc[i].y; o[2] = acc[i].z; o[3] = acc[i].w; }
+                else { o[0] = acc[i].x; o[1] = acc[i].y; }
+                typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+                hv hi, lo;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    // the fp32 value is the result: without this the optimiser folds the last fma and the conversion below into v_fma_mixlo_f16 -
+                    // ONE rounding, straight to f16 - and a value that lies exactly between two f16 neighbours once the fma has been rounded to fp32
+                    // gets the other hi (hi + lo * 2^-11 is the same number either way; bit-identity with the other kernels is not: 1 pixel of 200)
+                    asm volatile("" : "+v"(o[j]));
+                    amax = range_track(amax, o[j]);
+                    hi[j] = (ph16)o[j];
+                    lo[j] = (ph16)((o[j] - (float)hi[j]) * 2048.0f);
+                }
+                *reinterpret_cast<hv*>(Ph + (r0 + i) * PS + VEC * cq) = hi;
+                *reinterpret_cast<hv*>(Pl + (r0 + i) * PS + VEC * cq) = lo;
             }
         }
         YN_TS();
@@ -328,13 +352,13 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
                 const float bias = bias2[nt];
                 const bool to_global = n < (last ? bf : jhi);
                 const bool to_plane = !last && n >= jhi && n < bf;
-                const float* xr = x1s + (wm * 32 + 4 * h) * bf + (n < bf ? n : 0);
+                const float* xr = x1s + (wm * 32 + 4 * h) * X1S + (n < bf ? n : 0);
 #pragma unroll
                 for (int g8 = 0; g8 < 4; ++g8) {
                     if (wm * 32 + 8 * g8 < nrows) {                     // scalar condition
                         float y[4], xv[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) xv[q] = xr[(q + 8 * g8) * bf];
+                        for (int q = 0; q < 4; ++q) xv[q] = xr[(q + 8 * g8) * X1S];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) y[q] = act1(acc0[nt][4 * g8 + q] + bias, a.act2);
                         if (to_global) {
@@ -365,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
             YN_TS();     // the next tile's pieces (and this tile's first stores, long gone) - BEFORE the stores below, which need not be waited for
             GemmArgs e{};
             e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = m0 + nrows; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;
-            gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, true, lane, bias1n);
+            gemm_epilogue<NT>(e, acc0, m0 + wm * 32, wn * NT * 32, VEC == 4, lane, bias1n);
         } else {
             vm_drain();
         }
@@ -385,7 +409,8 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
 
 static size_t unit_pipe_lds(int bf, int W, int BM)
 {
-    return (size_t)(BM + 2 * W + 2) * bf * 4 + (size_t)BM * bf * 4 + (size_t)2 * BM * plane_stride(bf) * 2 + (size_t)BM * 4 + (size_t)10 * bf * 4;
+    const size_t win = (((size_t)(BM + 2 * W + 2) * bf * 4 + 8 + 15) & ~(size_t)15), x1row = (((size_t)bf * 4 + 15) / 16) * 16;
+    return win + (size_t)BM * x1row + (size_t)2 * BM * plane_stride(bf) * 2 + (size_t)BM * 4 + (size_t)10 * bf * 4;
 }
 
 // The persistent form of a stride-1 unit where it applies: split-f16 family, an instantiated branch width, ReLU pointwise / linear depthwise
@@ -401,7 +426,7 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
     const bool last = a.Wp1n == nullptr;
     if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;
     if (a.dw_act != 0 || a.act2 != 1 || (!last && a.act1n != 1)) return false;
-    if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & 3) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
+    if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & ((a.bf & 3) ? 1 : 3)) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
     if (a.Npad != ((a.bf + 31) & ~31)) return false;
     if (a.bf > 128 && a.Npad != 256) return false;                       // the streamed form indexes its pack with the full eight column tiles
     if ((double)a.M * a.bf * 8.0 >= 4.0e9 || (double)a.M * a.x1_ld * 4.0 >= 4.0e9) return false;
@@ -429,6 +454,7 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
 #define YN_UPW(BFv) if (a.bf == BFv) { if (last) { YN_UP(BFv, true, 8) } else { YN_UP(BFv, false, 8) } return false; }        // eight column tiles: eight wavefronts
     YN_UPW(232)          // 1.0x stage 4 (streamed weights)
     YN_UPB(116)          // 1.0x stage 3
+    YN_UPB(58)           // 1.0x stage 2 (channel pairs)
     YN_UPB(96)           // 0.5x stage 4
     YN_UPB(48)           // 0.5x stage 3
     YN_UPB(24)           // 0.5x stage 2
