@@ -1,14 +1,29 @@
 #!/usr/bin/env python3
 """What happens when the 4 streams of the default bench share the GPU: joins a rocprofv3 kernel trace of the DEFAULT run (four
 handles / four streams) with one of the ONE-stream run and prints, per kernel symbol, the average duration alone and under
-co-residency (inflation), its per-block resources (LDS, VGPRs, waves) and how much of a CU's residency the launch takes on its own;
-plus the time-weighted number of kernels in flight.  No counters involved (a --pmc pass serialises the dispatches, so it cannot see
-contention; the timestamps of the plain trace can).
+co-residency (inflation), its per-workgroup resources and how many workgroups of it a CU holds; plus the time-weighted number of
+kernels in flight.  No counters involved (a --pmc pass serialises the dispatches, so it cannot see contention; the timestamps of the
+plain trace can).
 
-usage: python tools/concurrency.py <default_kernel_trace.csv> <one_stream_kernel_trace.csv> [steps_to_skip_fraction]"""
+The per-workgroup resources do NOT come from the trace (round 4's table did, and was wrong where it mattered: the trace's LDS_Block_Size
+is the STATIC allocation only - 0 for every kernel that sizes its LDS at launch - and its VGPR_Count leaves the accumulation registers
+out).  They come from
+  * the compiler's own report (hipcc -Rpass-analysis=kernel-resource-usage, parsed by tools/resource_usage.py's reader): VGPRs + AGPRs,
+    static LDS, scratch;
+  * the library's launch log (YN_LOG_LDS=1: "yn_lds <kernel> <dynamic bytes> <threads>", one line per distinct launch shape).
+
+usage: python tools/concurrency.py <default_kernel_trace.csv> <one_stream_kernel_trace.csv> <resource_usage.txt> <dynamic_lds.txt>"""
 import collections
 import csv
+import re
+import subprocess
 import sys
+
+
+def norm(n):
+    n = n.replace("void ynk::", "").replace("ynk::", "").strip().strip("()")
+    n = n[:n.index("(")] if "(" in n else n
+    return re.sub(r"\s+", "", n)
 
 
 def load(path):
@@ -17,12 +32,9 @@ def load(path):
         n = r["Kernel_Name"]
         if "ynk::" not in n:
             continue
-        n = n.replace("void ynk::", "").replace("ynk::", "")
-        n = n[:n.index("(")] if "(" in n else n
         wg = int(r.get("Workgroup_Size_X", 256) or 256) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1)
         grid = int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, int(r.get("LDS_Block_Size", 0) or 0),
-                     int(r.get("VGPR_Count", 0) or 0) + int(r.get("Accum_VGPR_Count", 0) or 0), wg, grid, r.get("Queue_Id", "?")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), norm(n), wg, grid, r.get("Queue_Id", "?")))
     rows.sort()
     return rows
 
@@ -34,16 +46,46 @@ def steady(rows, skip=0.5):
     return [r for r in rows if r[0] >= cut]
 
 
+def compiler_table(path):
+    """kernel -> {VGPRs (incl. AGPRs), LDS (static), scratch} from the -Rpass-analysis=kernel-resource-usage remarks"""
+    out, cur = {}, None
+    names = []
+    for ln in open(path, errors="replace"):
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = m.group(1)
+            names.append(cur)
+            out[cur] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize|LDS Size)[^:]*: (\d+)", ln)
+        if m and cur:
+            out[cur][m.group(1)] = int(m.group(2))
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines() if names else []
+    return {norm(d): out[n] for n, d in zip(names, dem)}
+
+
+def launch_table(path):
+    """kernel -> largest dynamic LDS it was launched with"""
+    out = {}
+    for ln in open(path, errors="replace"):
+        f = ln.split()
+        if len(f) >= 4 and f[0] == "yn_lds":
+            k = norm(" ".join(f[1:-2]))
+            out[k] = max(out.get(k, 0), int(f[-2]))
+    return out
+
+
 def main():
     multi, single = steady(load(sys.argv[1])), steady(load(sys.argv[2]))
+    comp = compiler_table(sys.argv[3]) if len(sys.argv) > 3 else {}
+    dyn = launch_table(sys.argv[4]) if len(sys.argv) > 4 else {}
     solo = collections.defaultdict(list)
     for s, e, n, *_ in single:
         solo[n].append((e - s) / 1e3)
     agg = collections.defaultdict(lambda: {"d": [], "res": None})
-    for s, e, n, lds, vg, wg, grid, q in multi:
+    for s, e, n, wg, grid, q in multi:
         agg[n]["d"].append((e - s) / 1e3)
-        agg[n]["res"] = (lds, vg, wg, grid)
-    # kernels in flight over time (sweep)
+        agg[n]["res"] = (wg, grid)
     ev = []
     for s, e, *_ in multi:
         ev.append((s, 1)); ev.append((e, -1))
@@ -54,26 +96,30 @@ def main():
         cur += d; last = t
     span = sum(hist.values())
     busy = sum((e - s) for s, e, *_ in multi)
-    print("## kernels in flight (default run, steady-state half of the trace; HSA queues used: %s)\n" % sorted({r[7] for r in multi}))
+    print("## kernels in flight (default run, steady-state half of the trace; HSA queues used: %s)\n" % sorted({r[5] for r in multi}))
     print("time-weighted mean %.2f; " % (busy / span) + ", ".join("%d: %.1f %%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
-    print("\n## per kernel symbol\n")
-    print("| kernel | calls | avg us alone (1 stream) | avg us in the 4-stream run | inflation | LDS B/block | VGPRs | blocks | blocks/CU its resources allow | share of the chip's block slots it fills alone |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    print("\n## per kernel symbol (registers / LDS: compiler report + launch log, see the docstring)\n")
+    print("| kernel | calls | avg us alone (1 stream) | avg us in the 4-stream run | inflation | LDS B/workgroup (static + dynamic) | VGPRs + AGPRs | threads | workgroups | workgroups/CU (registers / LDS / wave slots) | share of the chip's workgroup slots it fills alone |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     tot_m = sum(sum(v["d"]) for v in agg.values())
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["d"])):
-        lds, vg, wg, grid = v["res"]
+        wg, grid = v["res"]
+        c = comp.get(n, {})
+        regs = c.get("VGPRs", 0) + c.get("AGPRs", 0)
+        lds = c.get("LDS Size", 0) + dyn.get(n, 0)
         blocks = grid // max(wg, 1)
         waves = max(wg // 64, 1)
-        alloc = ((max(vg, 1) + 7) // 8) * 8
-        by_vgpr = (min(8, 512 // alloc) * 4) // waves if alloc else 8
+        alloc = ((max(regs, 1) + 7) // 8) * 8
+        by_vgpr = (min(8, 512 // alloc) * 4) // waves if regs else 0
         by_lds = (160 * 1024) // lds if lds else 32
         by_waves = 32 // waves
-        per_cu = max(1, min(by_vgpr, by_lds, by_waves, 16))
+        per_cu = max(1, min(by_vgpr or 99, by_lds, by_waves))
         a = sum(v["d"]) / len(v["d"])
         s1 = solo.get(n)
         s_avg = sum(s1) / len(s1) if s1 else float("nan")
-        print("| `%s` | %d | %.1f | %.1f | %.2f | %d | %d | %d | %d | %.2f |" % (n[:48], len(v["d"]), s_avg, a, a / s_avg if s1 else float("nan"), lds, vg, blocks, per_cu,
-                                                                        min(1.0, blocks / (256.0 * per_cu))))
+        print("| `%s` | %d | %.1f | %.1f | %.2f | %d | %s | %d | %d | %d (%s / %d / %d) | %.2f |" % (
+            n[:48], len(v["d"]), s_avg, a, a / s_avg if s1 else float("nan"), lds, regs if regs else "?", wg, blocks, per_cu, by_vgpr if regs else "?", by_lds, by_waves,
+            min(1.0, blocks / (256.0 * per_cu))))
     print("\nsum of kernel durations / wall span = %.2f" % (tot_m * 1e3 / span))
 
 

@@ -28,7 +28,10 @@ case $part in
 stats)
     stats bs32_416 --steps 100 --warmup 20 $B
     stats bs32_416_1stream --steps 400 --warmup 20 --streams 1 --launch eager $B
-    python3 $R/tools/concurrency.py $(find /tmp/yn_prof_bs32_416 -name "*kernel_trace.csv" | head -1) $(find /tmp/yn_prof_bs32_416_1stream -name "*kernel_trace.csv" | head -1) > $O/r05_4stream_concurrency.md 2>$O/concurrency.err
+    # per-workgroup footprints: the compiler's report (committed: tools/resource_table.sh) + the dynamic LDS of every launch shape of the default run
+    YN_LOG_LDS=1 python3 $R/bench.py --steps 4 --warmup 2 $B 2>&1 >/dev/null | grep "^yn_lds" | sort -u > $O/r05_dynamic_lds.txt
+    python3 $R/tools/concurrency.py $(find /tmp/yn_prof_bs32_416 -name "*kernel_trace.csv" | head -1) $(find /tmp/yn_prof_bs32_416_1stream -name "*kernel_trace.csv" | head -1) \
+        $R/profiles/r05_resource_usage.txt $O/r05_dynamic_lds.txt > $O/r05_4stream_concurrency.md 2>$O/concurrency.err
     stats 608_bs32_1stream --size 608 --steps 200 --warmup 20 --streams 1 --launch eager $B
     stats 05x_bs128_1stream --backbone 0.5x --batch 128 --steps 200 --warmup 20 --streams 1 --launch eager $B
     ;;

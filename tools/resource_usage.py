@@ -22,7 +22,7 @@ def parse(path):
 
 def dem(n):
     try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip().replace("ynk::", "")[:70]
+        return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().replace("ynk::", "")[:70]
     except Exception:
         return n
 

@@ -15,11 +15,27 @@
 #include "yn_internal.h"
 #include "yn_device.h"
 
+#include <cstdio>
+#include <mutex>
+#include <set>
+#include <string>
+
 namespace ynk {
 
 static thread_local const char* g_last_kernel = "";
 const char* last_kernel_name() { return g_last_kernel; }
 void set_last_kernel_name(const char* n) { g_last_kernel = n; }
+
+bool g_log_lds = getenv("YN_LOG_LDS") != nullptr && atoi(getenv("YN_LOG_LDS")) != 0;
+void note_launch_lds(const char* kernel, size_t dyn_lds, unsigned threads)
+{
+    static std::mutex mu;
+    static std::set<std::string> seen;
+    char line[512];
+    snprintf(line, sizeof line, "yn_lds %s %zu %u", kernel, dyn_lds, threads);
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen.insert(line).second) fprintf(stderr, "%s\n", line);
+}
 
 // -------------------------------------------------------------------------------------------------
 // GEMM convolution.  Block = 4 waves laid out WM x WN; each wave owns a 32 x (32*NT) output tile and

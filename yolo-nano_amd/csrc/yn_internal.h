@@ -5,6 +5,20 @@
 
 namespace ynk {
 
+// Every launch of the library goes through this form of hipLaunchKernelGGL: with YN_LOG_LDS=1 in the environment each distinct (kernel, dynamic
+// LDS bytes, threads) is written to stderr once ("yn_lds <kernel> <bytes> <threads>").  The rocprofv3 kernel trace reports a kernel's STATIC LDS
+// only; tools/concurrency.py joins these lines (profiles/r05_dynamic_lds.txt) to get the real per-workgroup footprint.
+extern bool g_log_lds;
+void note_launch_lds(const char* kernel, size_t dyn_lds, unsigned threads);
+}  // namespace ynk
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                            \
+    do {                                                                                                                              \
+        if (ynk::g_log_lds) ynk::note_launch_lds(#kernelName, (size_t)(memPerBlock), (unsigned)(dim3(numThreads).x * dim3(numThreads).y)); \
+        hipLaunchKernelGGLInternal((kernelName), numBlocks, numThreads, memPerBlock, streamId, __VA_ARGS__);                         \
+    } while (0)
+namespace ynk {
+
 // ---- GEMM-shaped convolutions (pointwise 1x1 and dense 3x3) on the f32 MFMA ----------------------
 // A operand = activations, NHWC: row m (= pixel) has K contiguous floats at in + m*in_ld + in_off.
 // B operand = folded weights packed k-pair interleaved: Wp[(k/2)][n][k&1], n in [0,Npad), zero padded.
