@@ -88,6 +88,9 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
+#ifdef YN_EXP_TIMING
+    const long long T_start = __builtin_readcyclecounter();
+#endif
     // XCD-contiguous walk: XCD x (= blockIdx % 8) owns tiles [x TX, (x+1) TX), its workgroups take them round-robin
     const int TX = (tiles + 7) >> 3, jstep = (int)(gridDim.x >> 3);
     const int tend = ((int)(blockIdx.x & 7u) + 1) * TX < tiles ? ((int)(blockIdx.x & 7u) + 1) * TX : tiles;
@@ -130,22 +133,34 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     issue_window(tile);
     issue_x1(tile);
 
-    // ---- loop invariants: both GEMMs' B fragments of this wavefront's columns, the depthwise taps of this thread's channel quad ----
+    // Issue order of the prologue = order of need: DMA pieces of the first tile, the depthwise taps (a few loads, bound for LDS), then the 64
+    // weight-fragment loads of a lane.  The vector-memory counter retires in order, so the first wait the compiler places - for the taps, before
+    // their LDS stores - is vmcnt(63): DMA and taps done, the weights still in flight under the first tile's depthwise phase (first form: one
+    // vmcnt(0) in front of the loop - 12-14 k cycles of a workgroup's 25-40 k, 240 KB of fragments per CU through L2 with nothing else going on).
+    constexpr int TAPQ = (10 * (BF / 2) + NTHR - 1) / NTHR;
+    float2 tapv[TAPQ];
+#pragma unroll
+    for (int q = 0; q < TAPQ; ++q) {
+        const int i = t + q * NTHR;
+        const int ic = i < 10 * (BF / 2) ? i : 0;
+        const int k = ic / (BF / 2), c2 = ic - k * (BF / 2);
+        tapv[q] = *reinterpret_cast<const float2*>((k < 9 ? a.wdw + k * bf : a.bdw) + 2 * c2);
+    }
+    // ---- loop invariants: both GEMMs' B fragments of this wavefront's columns ----
     ph16x8 bw2[SMAX][NT][2], bw1[STREAM ? 1 : SMAX][NT][2];
+    // No masks on the fragment loads (a masked load is USED - waited for - where it is issued): the octet past the matrix (the last half k-step
+    // of an odd octet count) and the columns past Npad read the nearest valid ones instead.  Finite weights against the planes' zero K tail add
+    // exact zeros; accumulator columns >= bf are never stored.
     auto load_step = [&](const void* Wh_, const void* Wl_, int s, ph16x8 (&dst)[NT][2]) {   // the fragments of k-step s
-        const ph16* Wh = reinterpret_cast<const ph16*>(Wh_);
-        const ph16* Wl = reinterpret_cast<const ph16*>(Wl_);
-        const int kq = s * 2 + h;
+        const char* Wh = reinterpret_cast<const char*>(Wh_);
+        const char* Wl = reinterpret_cast<const char*>(Wl_);
+        const int kq = s * 2 + h < KQ ? s * 2 + h : KQ - 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = wn * NT * 32 + nt * 32 + l31;
-            const bool ok = s < S && kq < KQ && n < a.Npad;
-            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
-            const unsigned mk = opaque_mask(ok);
-            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
-            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
-            dst[nt][0] = *reinterpret_cast<ph16x8*>(&vh);
-            dst[nt][1] = *reinterpret_cast<ph16x8*>(&vl);
+            const unsigned off = ((unsigned)kq * (unsigned)a.Npad + (unsigned)(n < a.Npad ? n : a.Npad - 1)) * 16u;
+            dst[nt][0] = *reinterpret_cast<const ph16x8*>(Wh + off);
+            dst[nt][1] = *reinterpret_cast<const ph16x8*>(Wl + off);
         }
     };
     auto load_w = [&](const void* Wh, const void* Wl, ph16x8 (&dst)[SMAX][NT][2]) {
@@ -164,16 +179,18 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     static_assert(CG * (BM / RUN) <= NTHR, "one depthwise round per tile");     // channel groups x runs of RUN tile rows: the depthwise phase's threads
     const int cq = t % CG, pl = t / CG;
     const bool worker = pl < BM / RUN;
-    for (int i = t; i < 10 * (BF / 2); i += NTHR) {
-        const int k = i / (BF / 2), c2 = i - k * (BF / 2);
-        *reinterpret_cast<float2*>(taps + 2 * i) = *reinterpret_cast<const float2*>((k < 9 ? a.wdw + k * bf : a.bdw) + 2 * c2);
+    {
+#pragma unroll
+        for (int q = 0; q < TAPQ; ++q) {
+            const int i = t + q * NTHR;
+            if (i < 10 * (BF / 2)) *reinterpret_cast<float2*>(taps + 2 * i) = tapv[q];
+        }
     }
     // K tail of both planes: zero once (nothing below writes columns >= bf)
     {
         const int padn = PS - bf;
         for (int i = t; i < BM * padn; i += NTHR) { const int r = i / padn, c2 = bf + i - r * padn; Ph[r * PS + c2] = (ph16)0.0f; Pl[r * PS + c2] = (ph16)0.0f; }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0), as an instruction hipcc's scoreboard sees: no wait for these loads inside the loop
     float amax = 0.0f;                                                  // range guard (yn_device.h)
     const int jhi = bf >> 1;
     f32x16 acc0[NT], acc1[NT];
@@ -254,19 +271,23 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     };
     write_mtab(tile);
 #ifdef YN_EXP_TIMING
+    const long long T_loop = __builtin_readcyclecounter();
     long long TS[12]; int tsn = 0, titer = 0;
 #define YN_TS() TS[tsn++] = __builtin_readcyclecounter()
 #else
 #define YN_TS()
 #endif
-    for (;;) {
+    // One tile.  Instantiated TWICE: the workgroup's first tile ahead of the loop, the rest in it.  hipcc flushes the vector-memory counter in
+    // front of a loop whose body uses loaded values but holds no loads it counts (the DMA pieces are invisible to it) - with the first tile
+    // inside the loop that flush is a vmcnt(0) on 64 weight-fragment loads per lane before the first depthwise phase may start (12-14 k cycles of
+    // a workgroup's 25-40 k).  Peeled, the waits sit where the first tile USES the fragments: in front of its two GEMMs.
+    auto do_tile = [&](const int tile, const int next) __attribute__((always_inline)) {
 #ifdef YN_EXP_TIMING
         tsn = 0;
 #endif
         YN_TS();
         const int m0 = tile * BM;
         const int nrows = a.M - m0 < BM ? a.M - m0 : BM;
-        const int next = tile + jstep < tend ? tile + jstep : -1;
         YN_TS();
         lds_barrier();      // (1) this tile's window and pass-through rows have landed (every wavefront waited for its pieces before it got here), mtab is written
 
@@ -400,11 +421,22 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
                    TS[1] - TS[0], TS[2] - TS[1], TS[3] - TS[2], TS[4] - TS[3], TS[5] - TS[4], TS[6] - TS[5], TS[7] - TS[6], TS[8] - TS[7], TS[9] - TS[8], TS[10] - TS[9], TS[11] - TS[10], TS[11] - TS[0]);
         ++titer;
 #endif
-        if (next < 0) break;
-        tile = next;
+    };
+    {
+        int next = tile + jstep < tend ? tile + jstep : -1;
+        do_tile(tile, next);
+        while (next >= 0) {
+            tile = next;
+            next = tile + jstep < tend ? tile + jstep : -1;
+            do_tile(tile, next);
+        }
     }
 #undef YN_TS
     range_report(a.ovf, amax);
+#ifdef YN_EXP_TIMING
+    if (t == 0 && (blockIdx.x % 37) == 3)
+        printf("pipewg bf %d last %d blk %d tiles %d prologue %lld total %lld start-stamp %lld\n", bf, (int)last, (int)blockIdx.x, titer, T_loop - T_start, __builtin_readcyclecounter() - T_start, T_start & 0xffffff);
+#endif
 }
 
 static size_t unit_pipe_lds(int bf, int W, int BM)
