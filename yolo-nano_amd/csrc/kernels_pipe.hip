@@ -30,21 +30,6 @@ typedef _Float16 ph16;
 typedef _Float16 ph16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ph16x4 __attribute__((ext_vector_type(4)));
 
-// One LDS-DMA piece: 64 lanes x 16 bytes, global (wave-uniform base + 32-bit lane offset) -> LDS (wave-uniform byte address + lane * 16).
-// Invisible to hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.x "What hipcc does not do"): completion is counted by hand below.
-__device__ __forceinline__ void dma16(const void* gbase, unsigned goff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(goff), "s"(gbase), "s"(lds_dst)
-                 : "memory");
-}
-// barriers that do NOT drain the vector-memory counter (a __syncthreads() may: its fence waits for this wavefront's global stores, and the
-// in-order counter then retires the DMA pieces in front of them too)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // BF = branch width, compile-time: with run-time strides (bf, the plane stride, out_ld) every unrolled LDS / global access of the
 // epilogues needs its own address register, and the optimiser hoists ~80 of them out of the tile loop - into the registers the weights
 // live in (first form: 348 registers uncapped, 108 spilled at the 256 two workgroups per CU allow, reloaded - vmcnt(0) - inside both GEMMs).
@@ -452,8 +437,9 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
 {
     // (read at every launch: the tests compare both forms inside one process)
     const int mode = getenv("YN_CHAIN_PIPE") ? atoi(getenv("YN_CHAIN_PIPE")) : 1;                // 0: never (A/B), 1: default, 2: also for few tiles
-    // size rule: the walk pays from about one tile per workgroup slot; the streamed wide form (one tile per workgroup at bs 32) from a third of the chip
-    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : (a.bf > 128 ? 96 : 256);
+    // size rule: the walk pays from about one tile per workgroup slot; the streamed wide form (a workgroup's whole-panel prefetch instead of three
+    // k-steps of look-ahead) at every size: one 608 x 608 image 0.652 -> 0.639 ms
+    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : (a.bf > 128 ? 1 : 256);
     const int wg_cap = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512;
     const bool last = a.Wp1n == nullptr;
     if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;

@@ -287,6 +287,22 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
 // two-way conflict.  The columns [C, stride) stay zero (K tail).
 __host__ __device__ constexpr int plane_stride(int C) { return ((((C + 7) >> 3) + 1) & ~1) * 8 + 8; }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) and the barriers that go with it (unit_pipe_kernel, head_tail_pipe_group_kernel) -----------------
+// One LDS-DMA piece: 64 lanes x 16 bytes, global (wave-uniform base + 32-bit lane offset) -> LDS (wave-uniform byte address + lane * 16).
+// Invisible to hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.x "What hipcc does not do"): completion is counted by hand below.
+__device__ __forceinline__ void dma16(const void* gbase, unsigned goff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(goff), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+// barriers that do NOT drain the vector-memory counter (a __syncthreads() may: its fence waits for this wavefront's global stores, and the
+// in-order counter then retires the DMA pieces in front of them too)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int V> struct VecT;
 template <> struct VecT<2> { typedef float2 type; };
 template <> struct VecT<4> { typedef float4 type; };
