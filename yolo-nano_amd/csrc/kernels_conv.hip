@@ -722,18 +722,23 @@ __global__ __launch_bounds__(256) void conv3x3_halo_tap_kernel(GemmArgs a)
 // with there, and a second halo phase costs 3 us.  Both forms walk K in the same order — channel half, tap, 16-deep step — so a
 // layer's bits do not depend on which one its size selects (an image's detections are independent of its batch:
 // test_infer_config2_bs32).
-template <int NT, int NH>
+// TPS = taps of weights staged per step (round 5).  A step costs a barrier pair and a weight fetch that was requested one step earlier - ~1.2 us
+// whatever it multiplies - and the small-map forms (NT = 1: 6 KB of weights per tap and channel half) are nothing but 18 of those: smooth_0 (5 408
+// pixels) took as long as smooth_2 (21 632).  TPS = 3 / 9 makes that 6 / 2 steps (18 / 54 KB of LDS); same (half, tap, k-step) order: same bits.
+template <int NT, int NH, int TPS = 1>
 __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
 {
     constexpr int CIN = 96, CH = 48, HC = CIN / NH, KQ = CH / 8, KQT = CIN / 8, BM = 128, BN = 32 * NT, CSH = HC + 8;   // halo row stride (halves): 112 / 208 bytes
     constexpr int WCH = KQ * BN * 8;                                                  // halves per weight plane per (tap, half)
     constexpr int B_PER = (2 * KQ * BN + 255) / 256;                                  // 16-byte granules per thread per (tap, half) (hi and lo planes)
+    constexpr int NSTEP = 18 / TPS;
+    static_assert(9 % TPS == 0, "a step stays inside one channel half");
     extern __shared__ __attribute__((aligned(16))) float c3s_smem[];
     const int W = a.W, H = a.H, HW = H * W;
     const int npix = BM + 2 * W + 2;
     c3h16* Hh = reinterpret_cast<c3h16*>(c3s_smem);                                   // [npix][CSH]
     c3h16* Hl = Hh + (size_t)npix * CSH;
-    c3h16* Bh = Hl + (size_t)npix * CSH;                                              // [KQ][BN][8]
+    c3h16* Bh = Hl + (size_t)npix * CSH;                                              // TPS x { [KQ][BN][8] hi, then lo }
     c3h16* Bl = Bh + WCH;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -752,27 +757,31 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
 #define YN_TS()
 #endif
     YN_TS();
-    c3h16x8 b_reg[B_PER];
-    auto prefetch_b = [&](int step) {                                                 // step = half * 9 + tap
-        const int half = step / 9, tap = step - half * 9;
+    c3h16x8 b_reg[TPS][B_PER];
+    auto prefetch_b = [&](int step) {                                                 // step = (half * 9 + first tap) / TPS
+        const int half = (step * TPS) / 9, tap0 = step * TPS - half * 9;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int g = t + 256 * i;                                                // granule: plane (hi / lo), octet o, column n
-            const int pl = g / (KQ * BN), r = g - pl * (KQ * BN);
-            const int o = r / BN, n = r - o * BN;
-            c3h16x8 v;
+        for (int tt = 0; tt < TPS; ++tt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
-            if (g < 2 * KQ * BN) v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + (((size_t)tap * KQT + half * KQ + o) * a.Npad + n0 + n) * 8);
-            b_reg[i] = v;
-        }
+            for (int i = 0; i < B_PER; ++i) {
+                const int g = t + 256 * i;                                            // granule: plane (hi / lo), octet o, column n
+                const int pl = g / (KQ * BN), r = g - pl * (KQ * BN);
+                const int o = r / BN, n = r - o * BN;
+                c3h16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
+                if (g < 2 * KQ * BN) v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + (((size_t)(tap0 + tt) * KQT + half * KQ + o) * a.Npad + n0 + n) * 8);
+                b_reg[tt][i] = v;
+            }
     };
     auto stage_b = [&]() {
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int g = t + 256 * i;
-            if (g < 2 * KQ * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)g * 8) = b_reg[i];      // Bl follows Bh: plane 1 lands there
-        }
+        for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int g = t + 256 * i;
+                if (g < 2 * KQ * BN) *reinterpret_cast<c3h16x8*>(Bh + (size_t)tt * 2 * WCH + (size_t)g * 8) = b_reg[tt][i];      // Bl follows Bh: plane 1 lands there
+            }
     };
     prefetch_b(0);
 
@@ -846,14 +855,16 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
 
-    for (int step = 0; step < 18; ++step) {                 // (channel half, tap): K = 2 x 9 x 48
-        const int tap = step % 9;
-        if (step + 1 < 18) prefetch_b(step + 1);
+    for (int step = 0; step < NSTEP; ++step) {              // (channel half, TPS taps): K = 2 x 9 x 48
+        if (step + 1 < NSTEP) prefetch_b(step + 1);
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+        const int tap = (step * TPS) % 9 + tt;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const bool ok = (tapmask >> tap) & 1u;
-        const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8 + (NH == 1 ? (step / 9) * CH : 0);
-        const c3h16* Bhb = Bh + (size_t)(h * BN + l31) * 8;
-        const c3h16* Blb = Bl + (size_t)(h * BN + l31) * 8;
+        const size_t arow = (size_t)(W + 1 + r + dy * W + dx) * CSH + h * 8 + (NH == 1 ? ((step * TPS) / 9) * CH : 0);
+        const c3h16* Bhb = Bh + (size_t)tt * 2 * WCH + (size_t)(h * BN + l31) * 8;
+        const c3h16* Blb = Bl + (size_t)tt * 2 * WCH + (size_t)(h * BN + l31) * 8;
 #pragma unroll
         for (int ks = 0; ks < KQ / 2; ++ks) {
             c3h16x8 ah = *reinterpret_cast<const c3h16x8*>(Hh + arow + ks * 16);
@@ -871,9 +882,10 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (step + 1 < 18) {
+        }
+        if (step + 1 < NSTEP) {
             __syncthreads();                                 // everyone is done with this step's weights (and, after tap 8, with the halo planes)
-            if (NH == 2 && tap == 8) load_halo(1);
+            if (NH == 2 && (step * TPS) % 9 + TPS == 9) load_halo(1);
             stage_b();
             __syncthreads();
         }
@@ -916,7 +928,7 @@ __global__ __launch_bounds__(256, NH) void conv3x3_split_kernel(GemmArgs a)
 #endif
 #undef YN_TS
 }
-static size_t conv3x3_split_lds(int W, int NT, int NH) { return ((size_t)2 * (128 + 2 * W + 2) * (96 / NH + 8) + (size_t)2 * 6 * (32 * NT) * 8) * 2; }
+static size_t conv3x3_split_lds(int W, int NT, int NH, int TPS = 1) { return ((size_t)2 * (128 + 2 * W + 2) * (96 / NH + 8) + (size_t)TPS * 2 * 6 * (32 * NT) * 8) * 2; }
 
 static size_t conv3x3_halo_tap_lds(int W, int Cin, int NT, int split = 1)
 {
@@ -1208,19 +1220,27 @@ void launch_conv3x3(const GemmArgs& a, hipStream_t s)
         static unsigned long long attr_s = 0;
         if (attr_pending(attr_s)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const int tiles = (a.M + 127) / 128;
         if (tiles >= 256) {                                // N in one block column; channel halves, two workgroups per CU
             g_last_kernel = "conv3x3_split_kernel<3,2>";
             hipLaunchKernelGGL((conv3x3_split_kernel<3, 2>), dim3(xcd_grid(tiles), 1), dim3(256), conv3x3_split_lds(a.W, 3, 2), s, a);
-        } else if (tiles * 3 >= 256) {                     // N over three block columns (more, shorter workgroups)
-            g_last_kernel = "conv3x3_split_kernel<1,2>";
-            hipLaunchKernelGGL((conv3x3_split_kernel<1, 2>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 2), s, a);
-        } else {                                           // less than one workgroup per CU: latency-bound, all channels staged at once
-            g_last_kernel = "conv3x3_split_kernel<1,1>";
-            hipLaunchKernelGGL((conv3x3_split_kernel<1, 1>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 1), s, a);
+        } else if (tiles * 3 >= 256) {                     // N over three block columns (more, shorter workgroups).  (Three taps per step here: 38-41 us
+            g_last_kernel = "conv3x3_split_kernel<1,2>";    //  against 31 - the 12 KB of weight space cost the third workgroup per CU)
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 2, 1>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 2, 1), s, a);
+        } else if (conv3x3_split_lds(a.W, 1, 1, 9) <= 160 * 1024) {   // less than one workgroup per CU: latency-bound, all channels staged at once, nine taps per step
+            g_last_kernel = "conv3x3_split_kernel<1,1,9>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 1, 9>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 1, 9), s, a);
+        } else if (conv3x3_split_lds(a.W, 1, 1, 3) <= 160 * 1024) {   // (wide maps: the halo leaves room for three taps)
+            g_last_kernel = "conv3x3_split_kernel<1,1,3>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 1, 3>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 1, 3), s, a);
+        } else {
+            g_last_kernel = "conv3x3_split_kernel<1,1,1>";
+            hipLaunchKernelGGL((conv3x3_split_kernel<1, 1, 1>), dim3(xcd_grid(tiles), 3), dim3(256), conv3x3_split_lds(a.W, 1, 1, 1), s, a);
         }
         return;
     }
