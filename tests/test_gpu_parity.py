@@ -679,6 +679,55 @@ def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S,
     h.close()
 
 
+@pytest.mark.parametrize("M,cin,cout,act", [(64, 116, 116, 1), (127, 116, 116, 1), (5408 * 8, 116, 116, 1), (6401, 58, 58, 1), (4096, 96, 96, 2),
+                                           (901, 48, 48, 1), (3333, 24, 24, 1), (2600, 24, 58, 1), (1000, 116, 96, 2)])
+def test_pw_pipe_op_is_bit_identical_to_gemm_split(hvoc, M, cin, cout, act):
+    """Round 5: pw_pipe_kernel (the LAST pointwise configuration index: a persistent tile walk, LDS-DMA input rows, register-resident
+    weights) against gemm_split_kernel's first configuration, bit for bit: whole and partial last tiles, fewer tiles than workgroups, a
+    workgroup walking several tiles (43 264 rows = 1 352 tiles on 1 024 workgroups), odd widths through the two-float pieces (58), N that is
+    not a multiple of four (58: scalar stores)."""
+    rs = np.random.RandomState(M + cin)
+    x = nhwc(rs.standard_normal((1, cin, 1, M)).astype(np.float32))
+    w = dev((rs.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))
+    b = dev(rs.standard_normal((cout,)).astype(np.float32))
+    _, split_fam = hvoc.pw_families()
+    try:
+        hvoc.set_pw_config(split_fam[0])
+        ref = hvoc.op_pwconv(x, w, b, act).clone()
+        hvoc.set_pw_config(split_fam[-1])
+        for rep in range(3):
+            assert torch.equal(hvoc.op_pwconv(x, w, b, act), ref), rep
+    finally:
+        hvoc.set_pw_config(-1)
+
+
+@pytest.mark.parametrize("backbone,S,B", [("1.0x", 416, 8), ("0.5x", 320, 4), ("1.0x", 160, 3)])
+def test_pw_pipe_in_the_network_is_bit_identical(capi, backbone, S, B):
+    """... and inside the network (strided / offset inputs: the right half of a unit's map; lateral and head members), with the kernel seen
+    in the launch records."""
+    h = capi.Handle(S, 20, arch.MULTI_ANCHOR_SIZE, backbone, 0.001, 0.5, max_batch=B)
+    h.load_state_dict(weights.make_state_dict(backbone, 20))
+    h.fold_bn()
+    x = dev(weights.make_input(B, S, seed=S + B))
+    _, split_fam = h.pw_families()
+    try:
+        h.set_pw_config(split_fam[0])
+        ref = [t.clone() for t in h.forward_raw(x)]
+        h.set_pw_config(split_fam[-1])
+        for rep in range(2):
+            for u, v in zip(h.forward_raw(x), ref):
+                assert torch.equal(u, v), rep
+        h.profile_enable(True)
+        h.forward_raw(x)
+        names = [r[1] for r in h.profile_records()]
+        h.profile_enable(False)
+        assert any(n.startswith("pw_pipe_kernel") for n in names), names
+        assert h.range_status() == (False, False)
+    finally:
+        h.set_pw_config(-1)
+        h.close()
+
+
 @pytest.mark.parametrize("backbone,C", [("1.0x", 20), ("0.5x", 80)])
 def test_size_sweep_vs_torch_oracle(capi, backbone, C):
     """Odd map sizes, partial tiles, batch 1..3, both widths: raw heads against the torch-CPU oracle at 1e-4 (the kernels pick

@@ -1044,7 +1044,7 @@ static const char* const g_pws_names[] = {
 constexpr int N_PWS_CFGS = (int)(sizeof(g_pws_cfgs) / sizeof(g_pws_cfgs[0]));
 
 // tile configurations of gemm_conv_kernel, then the register-direct configurations (the f32-MFMA family), then the split-f16 family
-int pw_config_count() { return N_PW_CFGS + N_PWD_CFGS + N_PWS_CFGS; }
+int pw_config_count() { return N_PW_CFGS + N_PWD_CFGS + N_PWS_CFGS + 1; }       // + pw_pipe_kernel (kernels_pipe.hip)
 int pw_f32_config_count() { return N_PW_CFGS + N_PWD_CFGS; }
 
 static bool launch_pw_split(const GemmArgs& a, int idx, hipStream_t s)
@@ -1177,6 +1177,9 @@ static int choose_pw_cfg(int M, int K, int Npad)
 void launch_pw(const GemmArgs& a, hipStream_t s)
 {
     int idx = a.cfg;
+    // the persistent form: only when asked for by index (the autotuner times it beside the gemm_split_kernel configurations); not applicable ->
+    // the heuristic split configuration
+    if (idx == N_PW_CFGS + N_PWD_CFGS + N_PWS_CFGS) { if (launch_pw_pipe(a, s)) return; idx = -1; }
     // layers that carry split packs run on the split-f16 family unless an f32 configuration is requested explicitly
     if (a.Wsh && (idx < 0 || idx >= N_PW_CFGS + N_PWD_CFGS) && launch_pw_split(a, idx < 0 ? -1 : idx - N_PW_CFGS - N_PWD_CFGS, s)) return;
     if (idx >= N_PW_CFGS + N_PWD_CFGS) idx = -1;

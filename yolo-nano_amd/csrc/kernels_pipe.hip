@@ -482,4 +482,158 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
     return false;
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// pw_pipe_kernel: a pointwise conv (utils/modules.py:8-18 folded; backbone/shufflenetv2.py:42-44, 56-58: the first 1x1 conv of a unit's
+// branch 2) as the same persistent walk - unit_pipe_kernel without its depthwise conv and second GEMM.  gemm_split_kernel re-streams the
+// layer's whole weight matrix for every 128-row tile (K = N = 116: 59 KB of fragments against 59 KB of activations read) through a
+// register -> LDS staging pass with a barrier pair per K chunk; here a workgroup walks 32-row (K <= 64: 64-row) tiles with the matrix
+// REGISTER-resident (64 registers), the next tile's fp32 rows arrive by LDS-DMA under the current tile's split pass, GEMM and stores, and
+// 120 registers / 33 KB of LDS leave room for FOUR workgroups per CU.  Same 16-deep k-steps in sequence, same epilogue function:
+// bit-identical to every gemm_split_kernel configuration; the autotuner times it next to them (the last pointwise configuration index).
+// -------------------------------------------------------------------------------------------------
+template <int KK, int NPAD>
+__global__ __launch_bounds__(256, 4) void pw_pipe_kernel(GemmArgs a, int tiles)
+{
+    constexpr int WN = NPAD <= 32 ? 1 : (NPAD <= 64 ? 2 : 4), WM = 4 / WN, BM = 32 * WM, NTHR = 256;
+    constexpr int KQ = (KK + 7) >> 3, PS = plane_stride(KK), S = (KQ + 1) >> 1;
+    constexpr int VEC = KK % 4 == 0 ? 4 : 2, CG = KK / VEC;
+    constexpr unsigned ROWB = KK * 4u;
+    constexpr int X1C = (int)((ROWB + 15u) / 16u), X1S = X1C * 4;       // 16-byte pieces / floats per input row in LDS
+    typedef typename VecT<VEC>::type vec;
+    static_assert(KK % 2 == 0 && S <= 8 && NPAD <= 128, "register-resident B fragments");
+    extern __shared__ __attribute__((aligned(16))) unsigned char pp_smem[];
+    float* raw = reinterpret_cast<float*>(pp_smem);                     // [BM][X1S] fp32 input rows
+    ph16* Ph = reinterpret_cast<ph16*>(pp_smem + (unsigned)BM * X1S * 4u);      // operand planes [BM][PS]
+    ph16* Pl = Ph + BM * PS;
+    const unsigned lds_raw = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pp_smem;
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    const int TX = (tiles + 7) >> 3, jstep = (int)(gridDim.x >> 3);
+    const int tend = ((int)(blockIdx.x & 7u) + 1) * TX < tiles ? ((int)(blockIdx.x & 7u) + 1) * TX : tiles;
+    int tile = (int)(blockIdx.x & 7u) * TX + (int)(blockIdx.x >> 3);
+    if (tile >= tend) return;
+
+    auto issue_rows = [&](int tl) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int m0 = tl * BM;
+        constexpr int nch = BM * X1C;
+#pragma unroll
+        for (int c0 = 0; c0 < nch; c0 += NTHR) {
+            const int c = c0 + tt;
+            const int row = c / X1C;
+            const int j = c - row * X1C;
+            const int m = m0 + row < a.M ? m0 + row : a.M - 1;
+            const unsigned src = ((unsigned)m * (unsigned)a.in_ld + (unsigned)a.in_off) * 4u + (unsigned)j * 16u;
+            if (c < nch) dma16(a.in, src, lds_raw + (unsigned)(c0 + wave * 64) * 16u);
+        }
+    };
+    issue_rows(tile);
+    ph16x8 bw[S][2];
+    {
+        const int n = wn * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int kq = s * 2 + h < KQ ? s * 2 + h : KQ - 1;        // (no masks: unit_pipe_kernel's load_step)
+            const unsigned off = ((unsigned)kq * (unsigned)a.Npad + (unsigned)(n < a.Npad ? n : a.Npad - 1)) * 16u;
+            bw[s][0] = *reinterpret_cast<const ph16x8*>(reinterpret_cast<const char*>(a.Wsh) + off);
+            bw[s][1] = *reinterpret_cast<const ph16x8*>(reinterpret_cast<const char*>(a.Wsl) + off);
+        }
+    }
+    float bias1[1];
+    { const int n = wn * 32 + l31; bias1[0] = n < a.N ? a.bias[n] : 0.0f; }
+    {
+        constexpr int padn = PS - KK;
+        for (int i = t; i < BM * padn; i += NTHR) { const int r = i / padn, c2 = KK + i - r * padn; Ph[r * PS + c2] = (ph16)0.0f; Pl[r * PS + c2] = (ph16)0.0f; }
+    }
+    float amax = 0.0f;
+    const bool vecO = ((a.N | a.out_ld | a.out_off) & 3) == 0;
+
+    auto do_tile = [&](const int tile, const int next) __attribute__((always_inline)) {
+        const int m0 = tile * BM;
+        lds_barrier();      // (1) this tile's rows have landed (every wavefront waited for its pieces), the previous tile's GEMM is done with the planes
+        // ---- split pass: fp32 rows -> hi / lo planes ----
+        {
+            int tt = threadIdx.x;
+            asm volatile("" : "+v"(tt));
+#pragma unroll
+            for (int i0 = 0; i0 < BM * CG; i0 += NTHR) {
+                const int i = i0 + tt;
+                if (i < BM * CG) {
+                    const int r = i / CG, cq = i - r * CG;
+                    const vec v = *reinterpret_cast<const vec*>(raw + r * X1S + VEC * cq);
+                    float o[VEC];
+                    if constexpr (VEC == 4) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; } else { o[0] = v.x; o[1] = v.y; }
+                    typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+                    hv hi, lo;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { amax = range_track(amax, o[j]); hi[j] = (ph16)o[j]; lo[j] = (ph16)((o[j] - (float)hi[j]) * 2048.0f); }
+                    *reinterpret_cast<hv*>(Ph + r * PS + VEC * cq) = hi;
+                    *reinterpret_cast<hv*>(Pl + r * PS + VEC * cq) = lo;
+                }
+            }
+        }
+        lds_barrier();      // (2) planes complete; the row buffer is free
+        if (next >= 0) issue_rows(next);
+        f32x16 acc0[1], acc1[1];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[0][k] = 0.0f; acc1[0][k] = 0.0f; }
+        {
+            int ll = threadIdx.x & 63;
+            asm volatile("" : "+v"(ll));
+            const ph16* ahp = Ph + (wm * 32 + (ll & 31)) * PS + (ll >> 5) * 8;
+            const ph16* alp = Pl + (wm * 32 + (ll & 31)) * PS + (ll >> 5) * 8;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const ph16x8 ah = *reinterpret_cast<const ph16x8*>(ahp + s * 16);
+                const ph16x8 al = *reinterpret_cast<const ph16x8*>(alp + s * 16);
+                acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][0], acc0[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[s][1], acc1[0], 0, 0, 0);
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bw[s][0], acc1[0], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[0][r] = __builtin_fmaf(acc1[0][r], 1.0f / 2048.0f, acc0[0][r]);
+        vm_drain();         // the next tile's pieces - BEFORE this tile's stores, which need not be waited for
+        gemm_epilogue<1>(a, acc0, m0 + wm * 32, wn * 32, vecO, threadIdx.x & 63, bias1);
+    };
+    {
+        int next = tile + jstep < tend ? tile + jstep : -1;
+        vm_drain();         // the first tile's pieces (and the fragments): nothing else in the prologue waits for them
+        do_tile(tile, next);
+        while (next >= 0) {
+            tile = next;
+            next = tile + jstep < tend ? tile + jstep : -1;
+            do_tile(tile, next);
+        }
+    }
+    range_report(a.ovf, amax);
+}
+
+// false = this layer has no instantiated form (the caller takes a gemm_split_kernel configuration)
+bool launch_pw_pipe(const GemmArgs& a, hipStream_t s)
+{
+    if (!a.Wsh || !a.Wsl || a.pass || (a.in_ld & 1) || (a.in_off & 1) || a.Npad != ((a.N + 31) & ~31) || a.M < 64) return false;
+    if ((double)a.M * a.in_ld * 4.0 >= 4.0e9) return false;
+    static const int wg_cap = getenv("YN_PW_PIPE_G") ? atoi(getenv("YN_PW_PIPE_G")) : 1024;
+    static const bool off = getenv("YN_PW_PIPE") && atoi(getenv("YN_PW_PIPE")) == 0;               // A/B runs
+    if (off) return false;
+#define YN_PP(Kv, Nv)                                                                                                    \
+    if (a.K == Kv && a.Npad == Nv) {                                                                                     \
+        constexpr int BM = 32 * (4 / (Nv <= 32 ? 1 : (Nv <= 64 ? 2 : 4)));                                               \
+        const int tiles = (a.M + BM - 1) / BM;                                                                           \
+        const size_t lds = (size_t)BM * (((size_t)Kv * 4 + 15) / 16) * 16 + (size_t)2 * BM * plane_stride(Kv) * 2;        \
+        unsigned g = xcd_grid((unsigned)tiles);                                                                          \
+        if (g > (unsigned)wg_cap) g = (unsigned)wg_cap;                                                                  \
+        set_last_kernel_name("pw_pipe_kernel<" #Kv "," #Nv ">");                                                         \
+        hipLaunchKernelGGL((pw_pipe_kernel<Kv, Nv>), dim3(g), dim3(256), lds, s, a, tiles);                              \
+        return true;                                                                                                     \
+    }
+    YN_PP(116, 128) YN_PP(116, 96) YN_PP(58, 64) YN_PP(96, 96) YN_PP(48, 64) YN_PP(24, 32) YN_PP(24, 64)
+#undef YN_PP
+    return false;
+}
+
 }  // namespace ynk

@@ -113,6 +113,7 @@ void set_last_kernel_name(const char* n);
 int  pw_config_count();                    // f32-MFMA family (tiled, then register-direct) followed by the split-f16 family
 int  pw_f32_config_count();
 void launch_pw(const GemmArgs& a, hipStream_t s);
+bool launch_pw_pipe(const GemmArgs& a, hipStream_t s);      // kernels_pipe.hip: the persistent form (the last pointwise configuration index); false = not applicable
 void launch_conv3x3(const GemmArgs& a, hipStream_t s);
 void launch_dw(const DwArgs& a, hipStream_t s);
 void launch_stem(const float* x_nchw, int B, int H, int W, const float* w /*[27][Cout]*/, const float* bias,
