@@ -680,7 +680,8 @@ def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S,
 
 
 @pytest.mark.parametrize("M,cin,cout,act", [(64, 116, 116, 1), (127, 116, 116, 1), (5408 * 8, 116, 116, 1), (6401, 58, 58, 1), (4096, 96, 96, 2),
-                                           (901, 48, 48, 1), (3333, 24, 24, 1), (2600, 24, 58, 1), (1000, 116, 96, 2)])
+                                           (901, 48, 48, 1), (3333, 24, 24, 1), (2600, 24, 58, 1), (1000, 116, 96, 2), (21632, 232, 232, 1), (1352, 232, 232, 1),
+                                           (5409, 232, 96, 2)])
 def test_pw_pipe_op_is_bit_identical_to_gemm_split(hvoc, M, cin, cout, act):
     """Round 5: pw_pipe_kernel (the LAST pointwise configuration index: a persistent tile walk, LDS-DMA input rows, register-resident
     weights) against gemm_split_kernel's first configuration, bit for bit: whole and partial last tiles, fewer tiles than workgroups, a

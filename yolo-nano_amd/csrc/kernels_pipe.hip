@@ -492,16 +492,18 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
 // 120 registers / 33 KB of LDS leave room for FOUR workgroups per CU.  Same 16-deep k-steps in sequence, same epilogue function:
 // bit-identical to every gemm_split_kernel configuration; the autotuner times it next to them (the last pointwise configuration index).
 // -------------------------------------------------------------------------------------------------
-template <int KK, int NPAD>
-__global__ __launch_bounds__(256, 4) void pw_pipe_kernel(GemmArgs a, int tiles)
+template <int KK, int NPAD, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void pw_pipe_kernel(GemmArgs a, int tiles)
 {
-    constexpr int WN = NPAD <= 32 ? 1 : (NPAD <= 64 ? 2 : 4), WM = 4 / WN, BM = 32 * WM, NTHR = 256;
+    // NW = 4: up to 128 output columns, 128 registers, four workgroups per CU.  NW = 8 (K = 232, the stage-4 width): 256 columns - one 32-column
+    // strip of B per wavefront is 120 registers of fragments - on one workgroup per CU.
+    constexpr int WN = NPAD <= 32 ? 1 : (NPAD <= 64 ? 2 : (NPAD <= 128 ? 4 : 8)), WM = NW / WN, BM = 32 * WM, NTHR = 64 * NW;
     constexpr int KQ = (KK + 7) >> 3, PS = plane_stride(KK), S = (KQ + 1) >> 1;
     constexpr int VEC = KK % 4 == 0 ? 4 : 2, CG = KK / VEC;
     constexpr unsigned ROWB = KK * 4u;
     constexpr int X1C = (int)((ROWB + 15u) / 16u), X1S = X1C * 4;       // 16-byte pieces / floats per input row in LDS
     typedef typename VecT<VEC>::type vec;
-    static_assert(KK % 2 == 0 && S <= 8 && NPAD <= 128, "register-resident B fragments");
+    static_assert(KK % 2 == 0 && S <= (NW * OCC == 16 ? 8 : 15) && NPAD <= 32 * NW && WM >= 1, "register-resident B fragments");
     extern __shared__ __attribute__((aligned(16))) unsigned char pp_smem[];
     float* raw = reinterpret_cast<float*>(pp_smem);                     // [BM][X1S] fp32 input rows
     ph16* Ph = reinterpret_cast<ph16*>(pp_smem + (unsigned)BM * X1S * 4u);      // operand planes [BM][PS]
@@ -620,18 +622,20 @@ bool launch_pw_pipe(const GemmArgs& a, hipStream_t s)
     static const int wg_cap = getenv("YN_PW_PIPE_G") ? atoi(getenv("YN_PW_PIPE_G")) : 1024;
     static const bool off = getenv("YN_PW_PIPE") && atoi(getenv("YN_PW_PIPE")) == 0;               // A/B runs
     if (off) return false;
-#define YN_PP(Kv, Nv)                                                                                                    \
+#define YN_PP(Kv, Nv, NWv, OCCv)                                                                                             \
     if (a.K == Kv && a.Npad == Nv) {                                                                                     \
-        constexpr int BM = 32 * (4 / (Nv <= 32 ? 1 : (Nv <= 64 ? 2 : 4)));                                               \
+        constexpr int BM = 32 * (NWv / (Nv <= 32 ? 1 : (Nv <= 64 ? 2 : (Nv <= 128 ? 4 : 8))));                            \
         const int tiles = (a.M + BM - 1) / BM;                                                                           \
         const size_t lds = (size_t)BM * (((size_t)Kv * 4 + 15) / 16) * 16 + (size_t)2 * BM * plane_stride(Kv) * 2;        \
         unsigned g = xcd_grid((unsigned)tiles);                                                                          \
         if (g > (unsigned)wg_cap) g = (unsigned)wg_cap;                                                                  \
+        if (g > 256u * OCCv) g = 256u * OCCv;                                                                            \
         set_last_kernel_name("pw_pipe_kernel<" #Kv "," #Nv ">");                                                         \
-        hipLaunchKernelGGL((pw_pipe_kernel<Kv, Nv>), dim3(g), dim3(256), lds, s, a, tiles);                              \
+        hipLaunchKernelGGL((pw_pipe_kernel<Kv, Nv, NWv, OCCv>), dim3(g), dim3(64 * NWv), lds, s, a, tiles);                    \
         return true;                                                                                                     \
     }
-    YN_PP(116, 128) YN_PP(116, 96) YN_PP(58, 64) YN_PP(96, 96) YN_PP(48, 64) YN_PP(24, 32) YN_PP(24, 64)
+    YN_PP(116, 128, 4, 4) YN_PP(116, 96, 4, 4) YN_PP(58, 64, 4, 4) YN_PP(96, 96, 4, 4) YN_PP(48, 64, 4, 4) YN_PP(24, 32, 4, 4) YN_PP(24, 64, 4, 4)
+    YN_PP(232, 256, 8, 1) YN_PP(232, 96, 4, 2)
 #undef YN_PP
     return false;
 }
