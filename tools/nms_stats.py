@@ -5,8 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_nano_amd import arch, capi, weights
 
-B, S, C = 32, 416, 80
-h = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE_COCO, "1.0x", 0.001, 0.5, max_batch=B)
+B, S, C = 32, 416, int(os.environ.get("NMS_STATS_C", "80"))
+h = capi.Handle(S, C, arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE, "1.0x", 0.001, 0.5, max_batch=B)
 h.load_state_dict(weights.make_state_dict("1.0x", C))
 h.fold_bn()
 gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
