@@ -870,7 +870,7 @@ __device__ __forceinline__ void key_store(u64* k, int i, u64 v)
 
 template <bool KEYS_IN_LDS>
 __device__ void sort_segment(const float* __restrict__ boxes, const float* __restrict__ scores, int32_t* __restrict__ ids, bool ids_valid,
-                             int n, int P, u64* keys, float4* __restrict__ sbox)
+                             int n, int P, u64* keys, float4* __restrict__ sbox, u64* __restrict__ key_out = nullptr)
 {
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int j = tid; j < P; j += nthr) {
@@ -950,6 +950,10 @@ __device__ void sort_segment(const float* __restrict__ boxes, const float* __res
         }
     }
     }
+    if (key_out) {                                          // a CHUNK of a large segment: its sorted keys, for sort_merge_kernel
+        for (int j = tid; j < n; j += nthr) key_out[j] = key_load<KEYS_IN_LDS>(keys, j);
+        return;
+    }
     for (int j = tid; j < n; j += nthr) {
         const int id = (int)(unsigned)(key_load<KEYS_IN_LDS>(keys, j) & 0xffffffffu);
         ids[j] = id;
@@ -988,6 +992,100 @@ __global__ __launch_bounds__(1024) void sort_kernel(const float* __restrict__ bo
     else
         sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, true, n, P,
                            reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
+}
+
+// ---- large segments without large workgroups (round 5) -------------------------------------------------------------------------------
+// A segment above YN_SORT_SMALL boxes used to get a 1024-thread workgroup with 128 KB of LDS (bitonic network over the whole segment, 26 us
+// for the benchmark's 4 300-box class) - a workgroup that needs a nearly EMPTY CU to start: alone that is a 32-workgroup launch on an idle
+// chip; with other batches in flight (bench.py's four streams) every one of the launch's 352 workgroups, most of which only look at the list and
+// leave, waits for a CU to drain.  Dropping the sort from the four-stream run saved 53 us of a 710 us step - as much as the kernel takes alone.
+// Now: the segment's 1024-box CHUNKS are sorted by the same 256-thread / 8 KB workgroups as the small segments, IN the same launch (extra grid
+// rows: the image's chunk slots, enumerated from bucket_kernel's list), keys out to scratch (the not yet used matrix area); sort_merge_kernel
+// then places every box: its final position = the number of keys above it in every chunk of its segment, eleven-step branch-free binary
+// searches, all chunks of a group in flight together.  Keys are unique ((score, id)), so the order is the one the network produced.
+#define YN_SORT_CHUNK 1024
+#define YN_SORT_CHUNK_LOG 10
+__host__ __device__ inline int nms_chunk_slots(int N, int large_cap) { return N / YN_SORT_CHUNK + large_cap; }     // sum over large segments of ceil(n / 1024) <= N/1024 + their number
+
+// grid (B, C + chunk slots), block 256, LDS 8 KB
+__global__ __launch_bounds__(256) void sort_chunk_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                         int32_t* __restrict__ bucket, float4* __restrict__ sbox, int N, int C,
+                                                         const int32_t* __restrict__ seg_order, const int32_t* __restrict__ large_list, int large_cap,
+                                                         u64* __restrict__ keys_g, size_t keys_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    const int b = blockIdx.x;
+    if ((int)blockIdx.y < C) {                              // a small segment, whole (largest of the image first)
+        const int c = seg_order ? seg_order[(size_t)b * C + blockIdx.y] : (int)blockIdx.y;
+        const int n = seg_count[(size_t)b * C + c];
+        if (n <= 0 || n > YN_SORT_SMALL) return;
+        const int off = seg_off[(size_t)b * C + c];
+        sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, true, n, nms_pow2(n),
+                           reinterpret_cast<u64*>(sort_lds), sbox + (size_t)b * N + off);
+        return;
+    }
+    // chunk slot -> (large segment, chunk): walk the image's list (at most N/1024 entries)
+    int slot = (int)blockIdx.y - C;
+    const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+    const int nl = ll[0];
+    int c = -1, n = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int cl = ll[1 + l];
+        const int nc = seg_count[(size_t)b * C + cl];
+        const int chunks = (nc + YN_SORT_CHUNK - 1) >> YN_SORT_CHUNK_LOG;
+        if (slot < chunks) { c = cl; n = nc; break; }
+        slot -= chunks;
+    }
+    if (c < 0) return;
+    const int j0 = slot << YN_SORT_CHUNK_LOG;
+    const int len = min(YN_SORT_CHUNK, n - j0);
+    const int off = seg_off[(size_t)b * C + c] + j0;
+    sort_segment<true>(boxes + (size_t)b * N * 4, scores + (size_t)b * N, bucket + (size_t)b * N + off, true, len, nms_pow2(len),
+                       reinterpret_cast<u64*>(sort_lds), nullptr, keys_g + (size_t)b * keys_stride + off);
+}
+
+// grid (ceil(N / 256), B), block 256: thread = one position of the image's class-grouped candidate array
+__global__ __launch_bounds__(256) void sort_merge_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ seg_count,
+                                                         const int32_t* __restrict__ seg_off, int32_t* __restrict__ bucket, float4* __restrict__ sbox,
+                                                         int N, int C, const int32_t* __restrict__ large_list, int large_cap,
+                                                         const u64* __restrict__ keys_g, size_t keys_stride)
+{
+    const int b = blockIdx.y;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+    const int nl = ll[0];
+    int off = 0, n = 0;                                     // the large segment this position lies in (segments may lie in any order: scan the list)
+    for (int l = 0; l < nl; ++l) {
+        const int cl = ll[1 + l];
+        const int o = seg_off[(size_t)b * C + cl], nc = seg_count[(size_t)b * C + cl];
+        if (pos >= o && pos < o + nc) { off = o; n = nc; }
+    }
+    if (n == 0) return;
+    const u64* K = keys_g + (size_t)b * keys_stride + off;
+    const u64 key = K[pos - off];
+    const int nch = (n + YN_SORT_CHUNK - 1) >> YN_SORT_CHUNK_LOG;
+    int rank = 0;
+    for (int o0 = 0; o0 < nch; o0 += 8) {                   // eight chunks' searches in flight together
+        int lo[8], len[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { lo[u] = 0; len[u] = o0 + u < nch ? min(YN_SORT_CHUNK, n - ((o0 + u) << YN_SORT_CHUNK_LOG)) : 0; }
+#pragma unroll
+        for (int st = YN_SORT_CHUNK; st >= 1; st >>= 1) {   // largest lo with chunk[lo - 1] > key (descending chunk; the box's own chunk counts its position)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p2 = lo[u] + st;
+                const int idx = ((o0 + u) << YN_SORT_CHUNK_LOG) + (p2 <= len[u] ? p2 - 1 : 0);
+                const u64 kv = K[o0 + u < nch ? idx : 0];
+                if (p2 <= len[u] && kv > key) lo[u] = p2;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += lo[u];
+    }
+    const int id = (int)(unsigned)(key & 0xffffffffu);
+    bucket[(size_t)b * N + off + rank] = id;
+    sbox[(size_t)b * N + off + rank] = *reinterpret_cast<const float4*>(boxes + ((size_t)b * N + id) * 4);
 }
 
 // ---- bucket + sort in ONE launch, for the few-segment case (B * C <= 256: one to three images) ---------------------------------------
@@ -1958,6 +2056,8 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
                        wk.large_list, large_cap, YN_SORT_SMALL, wk.seg_order);
     mark("sort_kernel");
+    static const int chunked_env = getenv("YN_NMS_SORT_CHUNKS") ? atoi(getenv("YN_NMS_SORT_CHUNKS")) : 1;   // A/B: 0 = one 1024-thread workgroup per large segment
+    const bool chunks = !few && chunked_env && wk.large_list && (size_t)N <= wk.matrix_stride;
     if (!(skip & 1)) {
     if (few) {
         // few segments (bs <= 3 at 80 classes): every one gets a 1024-thread / 128 KB-LDS workgroup, all resident at once - one launch
@@ -1965,13 +2065,25 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
         hipLaunchKernelGGL(sort_kernel, dim3(B, C), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, 0, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0, (const int32_t*)wk.seg_order);
     } else {
+    if (chunks) {
+        // small segments whole + the large segments' 1024-box chunks in one launch of 256-thread workgroups, then the merge (keys in the not yet used matrix area)
+        const int slots = N > YN_SORT_SMALL ? nms_chunk_slots(N, large_cap) : 0;
+        hipLaunchKernelGGL(sort_chunk_kernel, dim3(B, C + slots), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                           N, C, (const int32_t*)wk.seg_order, (const int32_t*)wk.large_list, large_cap, M, wk.matrix_stride);
+        if (N > YN_SORT_SMALL) {
+            mark("sort_merge_kernel");
+            hipLaunchKernelGGL(sort_merge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, boxes, wk.seg_count, wk.seg_off, wk.bucket, sbox,
+                               N, C, (const int32_t*)wk.large_list, large_cap, (const u64*)M, wk.matrix_stride);
+        }
+    } else {
     hipLaunchKernelGGL(sort_kernel, dim3(B, C), dim3(256), YN_SORT_SMALL * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                        N, C, 0, YN_SORT_SMALL, (u64*)nullptr, (size_t)0, (const int32_t*)nullptr, 0, (const int32_t*)wk.seg_order);
     if (N > YN_SORT_SMALL)                                  // only the (few) listed large segments get a 128 KB-LDS workgroup
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), YN_SORT_LARGE * 8, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_SMALL, YN_SORT_LARGE, (u64*)nullptr, (size_t)0, (const int32_t*)wk.large_list, large_cap, (const int32_t*)nullptr);
     }
-    if (N > YN_SORT_LARGE)                                  // at most one such segment per image: keys in the (not yet used) matrix area
+    }
+    if (N > YN_SORT_LARGE && !chunks)                       // at most one such segment per image: keys in the (not yet used) matrix area
         hipLaunchKernelGGL(sort_kernel, dim3(large_cap, B), dim3(1024), 0, s, boxes, scores, wk.seg_count, wk.seg_off, wk.bucket, sbox,
                            N, C, YN_SORT_LARGE, 1 << 30, M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, (const int32_t*)nullptr);
     }
