@@ -112,12 +112,13 @@ __device__ __forceinline__ float decode_coord(const GridInfo& g, int s, int gx, 
 // max / sum / arg-max are 4-step reductions inside the 16-lane DPP row.  KMAX*16 >= C.  Returns true when this WAVEFRONT took the general path — then `sc` / `cbest` are the
 // final score and class (needs the objectness) — else the caller finishes with score = 1 / sum * sigmoid(obj_raw), class = cbest.
 // The general path also covers obj_raw < -60: sigmoid below 1e-26, where score = obj / sum (sum <= C) may underflow to equal products.
+// (two halves, so that a caller can run the branch-free first half of SEVERAL candidates back to back - independent dependency chains
+// the scheduler interleaves - before any of the wave-level decisions: head_tail_block's pass A)
 template <bool FULL, int KMAX>
-__device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, int i, int a, int j, float obj_raw,
-                                           float& sum_out, float& sc, int& cbest, float* __restrict__ all_class)
+__device__ __forceinline__ void cand_class_stats(const GridInfo& g, const float* row, int a, int j, float obj_raw,
+                                                 float (&v)[KMAX], float& sum_out, int& first_out, bool& general_out)
 {
     const float* cl = row + g.A + a * g.C;
-    float v[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {                                      // clamped index, -inf through an opaque mask for the slots past C
         const int c = j + 16 * k;
@@ -142,8 +143,15 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) sum += v[k];
-    sum = group16_sum(sum);
-    sum_out = sum;
+    sum_out = group16_sum(sum);
+    first_out = first;
+    general_out = general;
+}
+
+template <bool FULL, int KMAX>
+__device__ __forceinline__ bool cand_class_finish(const GridInfo& g, int i, int j, float obj_raw, const float (&v)[KMAX], float sum, int first, bool general,
+                                                  float& sc, int& cbest, float* __restrict__ all_class)
+{
     if (__any(general)) {
         const float obj = sigmoid_f(obj_raw);
         unsigned long long best = 0;
@@ -165,6 +173,17 @@ __device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, 
     }
     cbest = group16_min_i(first);
     return false;
+}
+
+template <bool FULL, int KMAX>
+__device__ __forceinline__ bool cand_class(const GridInfo& g, const float* row, int i, int a, int j, float obj_raw,
+                                           float& sum_out, float& sc, int& cbest, float* __restrict__ all_class)
+{
+    float v[KMAX];
+    int first;
+    bool general;
+    cand_class_stats<FULL, KMAX>(g, row, a, j, obj_raw, v, sum_out, first, general);
+    return cand_class_finish<FULL, KMAX>(g, i, j, obj_raw, v, sum_out, first, general, sc, cbest, all_class);
 }
 
 // models/yolo_nano.py:253-261 keeps a candidate only when score >= conf_thresh, and score = p_class * sigmoid(obj) with p_class <= 1:
@@ -621,14 +640,46 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
     const int j = t & 15;
     const int ncand = NO * g.A;
     const float skip_logit = conf_skip_logit(conf_thresh);
-    for (int cnd = t >> 4; cnd < ncand; cnd += 16) {
-        const int row = (int)(((unsigned)cnd * magicA) >> 16), an = cnd - row * g.A;
-        float sum, sc;
-        int cbest;
-        const float* rp = raw + row * LD;
-        if (wave_below_conf(rp[an], skip_logit)) { if (j == 0) { st_sum[cnd] = 0.0f; st_cls[cnd] = (int)0x80000000; } continue; }
-        const bool fin = cand_class<false, KMAX>(g, rp, 0, an, j, rp[an], sum, sc, cbest, nullptr);
-        if (j == 0) { st_sum[cnd] = fin ? sc : sum; st_cls[cnd] = fin ? (cbest | (int)0x80000000) : cbest; }
+    // Three candidates per 16-lane group and round (round 5): a candidate is ONE dependency chain - LDS read, max, four row steps, five
+    // exponentials, sum, four row steps, the wave-level decision, four row steps - and at three wavefronts per SIMD a group's six candidates one
+    // after the other were 7.5 k of a workgroup's 27 k cycles.  The branch-free halves of three candidates run back to back; the decisions
+    // follow per candidate, on the same four candidates per wavefront as before (candidate = group + 16 x (3 x round + u)): the same bits.
+    constexpr int CU = 3;
+    for (int c0 = t >> 4; c0 < ncand; c0 += 16 * CU) {     // (ncand = 32 A: whole wavefronts)
+        const float* rp[CU];
+        int an[CU];
+        float obj[CU];
+        bool inr[CU], below[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int cnd = c0 + 16 * u;
+            inr[u] = cnd < ncand;
+            const int cc = inr[u] ? cnd : c0;
+            const int row = (int)(((unsigned)cc * magicA) >> 16);
+            an[u] = cc - row * g.A;
+            rp[u] = raw + row * LD;
+            obj[u] = rp[u][an[u]];
+        }
+        bool all_below = true;
+#pragma unroll
+        for (int u = 0; u < CU; ++u) { below[u] = inr[u] && wave_below_conf(obj[u], skip_logit); all_below = all_below && (below[u] || !inr[u]); }
+        float v[CU][KMAX], sum[CU];
+        int first[CU];
+        bool general[CU];
+        if (!all_below) {
+#pragma unroll
+            for (int u = 0; u < CU; ++u) cand_class_stats<false, KMAX>(g, rp[u], an[u], j, obj[u], v[u], sum[u], first[u], general[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int cnd = c0 + 16 * u;
+            if (!inr[u]) continue;
+            if (below[u]) { if (j == 0) { st_sum[cnd] = 0.0f; st_cls[cnd] = (int)0x80000000; } continue; }
+            float sc;
+            int cbest;
+            const bool fin = cand_class_finish<false, KMAX>(g, 0, j, obj[u], v[u], sum[u], first[u], general[u], sc, cbest, nullptr);
+            if (j == 0) { st_sum[cnd] = fin ? sc : sum[u]; st_cls[cnd] = fin ? (cbest | (int)0x80000000) : cbest; }
+        }
     }
     __syncthreads();
     YN_TS();
