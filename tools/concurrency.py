@@ -98,6 +98,11 @@ def main():
     busy = sum((e - s) for s, e, *_ in multi)
     print("## kernels in flight (default run, steady-state half of the trace; HSA queues used: %s)\n" % sorted({r[5] for r in multi}))
     print("time-weighted mean %.2f; " % (busy / span) + ", ".join("%d: %.1f %%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
+    # per HSA queue (= bench.py stream): how much of the span it has a kernel executing.  A queue that is busy well under 100 % is waiting for
+    # its launches, not for the GPU: rocprofv3's tracing multiplies the cost of a launch, so THIS run is bound by the launching thread and
+    # holds fewer kernels in flight than the unprofiled run (tools/probe/enqueue_time.py: 120 us to enqueue a batch that takes 1 050 us;
+    # tools/probe/queue_probe.hip: four streams do run four kernels at once on this GPU)
+    print("\nper queue: " + ", ".join("%s busy %.0f %%" % (q, 100.0 * sum(e - s for s, e, *r in multi if r[-1] == q) / span) for q in sorted({r[5] for r in multi})))
     print("\n## per kernel symbol (registers / LDS: compiler report + launch log, see the docstring)\n")
     print("| kernel | calls | avg us alone (1 stream) | avg us in the 4-stream run | inflation | LDS B/workgroup (static + dynamic) | VGPRs + AGPRs | threads | workgroups | workgroups/CU (registers / LDS / wave slots) | share of the chip's workgroup slots it fills alone |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")

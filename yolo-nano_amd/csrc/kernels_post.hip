@@ -2106,9 +2106,9 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     mark("bucket_kernel");
     hipLaunchKernelGGL(bucket_kernel, dim3(B), dim3(1024), 2 * C * sizeof(int32_t), s, cls, N, C, wk.seg_count, wk.seg_off, wk.tile_off, wk.bucket, wk.keep,
                        wk.large_list, large_cap, YN_SORT_SMALL, wk.seg_order);
-    mark("sort_kernel");
     static const int chunked_env = getenv("YN_NMS_SORT_CHUNKS") ? atoi(getenv("YN_NMS_SORT_CHUNKS")) : 1;   // A/B: 0 = one 1024-thread workgroup per large segment
     const bool chunks = !few && chunked_env && wk.large_list && (size_t)N <= wk.matrix_stride;
+    mark(chunks ? "sort_chunk_kernel" : "sort_kernel");
     if (!(skip & 1)) {
     if (few) {
         // few segments (bs <= 3 at 80 classes): every one gets a 1024-thread / 128 KB-LDS workgroup, all resident at once - one launch
