@@ -45,7 +45,7 @@ def calls_of(path, layers, reps):
 def family(name):
     name = name.replace("void ", "").replace("ynk::", "")
     name = name.split("<")[0].split("(")[0].strip()
-    return "pointwise_gemm" if name in ("gemm_conv_kernel", "gemm_direct_kernel", "gemm_split_kernel") else name   # autotuned per process
+    return "pointwise_gemm" if name in ("gemm_conv_kernel", "gemm_direct_kernel", "gemm_split_kernel", "pw_pipe_kernel") else name   # autotuned per process
 
 
 def main():

@@ -442,6 +442,7 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
     const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : (a.bf > 128 ? 1 : 256);
     const int wg_cap = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512;
     const bool last = a.Wp1n == nullptr;
+    const bool force8 = getenv("YN_CHAIN_PIPE_NW") && atoi(getenv("YN_CHAIN_PIPE_NW")) == 8;      // A/B: the eight-wavefront form also where two windows fit
     if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;
     if (a.dw_act != 0 || a.act2 != 1 || (!last && a.act1n != 1)) return false;
     if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & ((a.bf & 3) ? 1 : 3)) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
@@ -453,7 +454,7 @@ bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
         constexpr int BM = 32 * (NWv / (BFv <= 64 ? 2 : (BFv <= 128 ? 4 : 8)));                                                             \
         const size_t lds = unit_pipe_lds(a.bf, a.W, BM);                                                                 \
         const int tiles = (a.M + BM - 1) / BM;                                                                           \
-        if (lds <= (size_t)(NWv == 4 ? 80 : 160) * 1024) {                                                               \
+        if (lds <= (size_t)(NWv == 4 ? 80 : 160) * 1024 && !(NWv == 4 && force8)) {                                      \
             if (mode < 2 && tiles < min_tiles) return false;                                                             \
             if (dry) return true;                                                                                        \
             static unsigned long long attr = 0;                                                                          \
