@@ -897,6 +897,37 @@ def test_postprocess_very_large_classes(hvoc, prefilter):
         hvoc.nms_prefilter(1)
 
 
+def test_postprocess_large_classes_many_segments(hvoc):
+    """The same class sizes in a batch of MORE than 256 (image, class) segments - the regime of the benchmark: there the segments above
+    1 024 boxes are sorted as 1 024-box chunks by the small segments' workgroups (sort_chunk_kernel) and placed by sort_merge_kernel
+    (round 5; up to nine chunks here, a last chunk of 356 / 204 / 808 boxes, a class of exactly 2 048): every copy of an image must give
+    the oracle's kept set, bit for bit."""
+    rs = np.random.RandomState(23)
+    N, C = 14000, 20
+    def image(sizes):
+        cls = np.concatenate([np.full(k, c) for c, k in sizes.items()] + [rs.randint(10, C, N - sum(sizes.values()))]).astype(np.int64)
+        rs.shuffle(cls)
+        ctr = rs.uniform(0.05, 0.95, (N, 2)); wh = rs.uniform(0.02, 0.09, (N, 2))
+        boxes = np.clip(np.concatenate([ctr - wh / 2, ctr + wh / 2], 1), 0, 1).astype(np.float32)
+        conf = np.zeros((N, C), np.float32)
+        conf[np.arange(N), cls] = rs.uniform(0.01, 1.0, N).astype(np.float32)
+        return boxes, conf
+    imgs = [image({0: 6500, 1: 4300, 2: 900}), image({3: 9000, 4: 64, 5: 2048}), image({6: 1025, 7: 1024, 8: 3000})]
+    B = 15                                                  # 300 segments
+    boxes = np.stack([imgs[i % 3][0] for i in range(B)])
+    conf = np.stack([imgs[i % 3][1] for i in range(B)])
+    hvoc.set_thresholds(0.001, 0.5)
+    out = hvoc.postprocess(dev(boxes), dev(conf))
+    counts = out[4].cpu().tolist()
+    refs = [orc.postprocess(bb, cc, 0.001, 0.5) for bb, cc in imgs]
+    for bi in range(B):
+        rb, rs_, rc = refs[bi % 3]
+        k = counts[bi]
+        assert k == len(rs_), (bi, k, len(rs_))
+        assert np.array_equal(out[0][bi, :k].cpu().numpy(), rb) and np.array_equal(out[1][bi, :k].cpu().numpy(), rs_)
+        assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
+
+
 def test_pack_detections(hcoco):
     """yn_pack_detections: the whole batch's kept rows as one record list + offsets == the per-image outputs."""
     hcoco.set_grid(416)
