@@ -669,17 +669,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
     auto load_b = [&](const void* Wh_, const void* Wl_, int s, uch16x8 (&dst)[NT][2]) {
         const uch16* Wh = reinterpret_cast<const uch16*>(Wh_);
         const uch16* Wl = reinterpret_cast<const uch16*>(Wl_);
-        const int kq = s * 2 + h;
+        // NO masks (round 5): a masked load is USED where it is issued - eight v_and per fragment - and hipcc then waits for it there: every k-step
+        // of the walk drained the vector-memory counter (vmcnt(3) ... vmcnt(0) in front of its MFMAs) and cost a full L2 round trip, D deep or
+        // not.  Clamped addresses instead: an octet past K (kq = KQ, odd octet counts) meets the planes' zero K tail, a column past Npad is
+        // never stored, a step past the walk reads its A fragment from the zero tail (a_col below).  Finite weights x 0: exact zeros, as before.
+        const int kq = min(s * 2 + h, KQ - 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = wn * NT * 32 + nt * 32 + l31;
-            const bool ok = s < S && kq < KQ && n < a.Npad;
-            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
-            const unsigned mk = opaque_mask(ok);
-            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
-            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
-            dst[nt][0] = *reinterpret_cast<uch16x8*>(&vh);
-            dst[nt][1] = *reinterpret_cast<uch16x8*>(&vl);
+            const int n = min(wn * NT * 32 + nt * 32 + l31, a.Npad - 1);
+            const size_t off = ((size_t)kq * a.Npad + n) * 8;
+            dst[nt][0] = *reinterpret_cast<const uch16x8*>(Wh + off);
+            dst[nt][1] = *reinterpret_cast<const uch16x8*>(Wl + off);
         }
     };
     auto prime_b = [&](const void* Wh, const void* Wl) {
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
 
     f32x16 acc0[NT], acc1[NT];
     // entry state: the fragments of steps 0 .. D-1 of this matrix are in flight (prime_b).  Steps past the last one (at most D - 1 of them)
-    // multiply a valid A fragment by zero weights: exact zeros, no branch around the loads
+    // multiply the zero K tail of the A rows by whatever fragment the clamped load brought: exact zeros, no branch around the loads
     auto gemm = [&](const void* Wh, const void* Wl) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -807,9 +807,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const int s = s0 + j;
-                const int ks = s < S ? s : S - 1;
-                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ph + (wm * 32 + l31) * PS + ks * 16 + h * 8);
-                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Pl + (wm * 32 + l31) * PS + ks * 16 + h * 8);
+                const int a_col = s < S ? s * 16 + h * 8 : PS - 8;      // past the walk: the last 16 bytes of the row's zero K tail (plane_stride)
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(Ph + (wm * 32 + l31) * PS + a_col);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(Pl + (wm * 32 + l31) * PS + a_col);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
@@ -1764,17 +1764,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
         // (without a next unit the steps >= S are masked loads at a clamped address: the base must still be a real pointer)
         const uch16* Wh = reinterpret_cast<const uch16*>((third && chain) ? a.W1nh : ((second && !third) ? a.W3h : a.W2h));
         const uch16* Wl = reinterpret_cast<const uch16*>((third && chain) ? a.W1nl : ((second && !third) ? a.W3l : a.W2l));
-        const int kq = ks * 2 + h;
+        // no masks (unit_chain2_kernel's load_b: a masked load is waited for where it is issued - the walk then paid a memory round trip per
+        // k-step): clamped octet / column, and the steps past the walk take their A fragment from the planes' zero K tail
+        const int kq = min(ks * 2 + h, KQ - 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = (wave * NT + nt) * 32 + l31;
-            const bool ok = (s < S || (chain && s < S + S2)) && kq < KQ && n < a.Npad;
-            const size_t off = ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n : 0)) * 8;
-            const unsigned mk = opaque_mask(ok);
-            uint4 vh = *reinterpret_cast<const uint4*>(Wh + off), vl = *reinterpret_cast<const uint4*>(Wl + off);
-            vh.x &= mk; vh.y &= mk; vh.z &= mk; vh.w &= mk; vl.x &= mk; vl.y &= mk; vl.z &= mk; vl.w &= mk;
-            dst[nt][0] = *reinterpret_cast<uch16x8*>(&vh);
-            dst[nt][1] = *reinterpret_cast<uch16x8*>(&vl);
+            const int n = min((wave * NT + nt) * 32 + l31, a.Npad - 1);
+            const size_t off = ((size_t)kq * a.Npad + n) * 8;
+            dst[nt][0] = *reinterpret_cast<const uch16x8*>(Wh + off);
+            dst[nt][1] = *reinterpret_cast<const uch16x8*>(Wl + off);
         }
     };
 #pragma unroll
@@ -1914,12 +1912,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f; }
             }
-            // steps beyond the walk (s >= Stot, at most D - 1 of them) multiply a valid A fragment by zero weights: exact zeros, no branch
+            // steps beyond the walk (s >= Stot, at most D - 1 of them) multiply the zero K tail of a row by some weights: exact zeros, no branch
             const int sc = s < Stot ? s : Stot - 1;
             const bool second = sc >= S2 && sc < S;
             const int ks = sc >= S ? sc - S : (second ? sc - S2 : sc), PS = second ? PS1 : PS2;
-            const uch16x8 ah = *reinterpret_cast<const uch16x8*>((second ? A1h : A2h) + l31 * PS + ks * 16 + h * 8);
-            const uch16x8 al = *reinterpret_cast<const uch16x8*>((second ? A1l : A2l) + l31 * PS + ks * 16 + h * 8);
+            const int a_col = s < Stot ? ks * 16 + h * 8 : PS - 8;
+            const uch16x8 ah = *reinterpret_cast<const uch16x8*>((second ? A1h : A2h) + l31 * PS + a_col);
+            const uch16x8 al = *reinterpret_cast<const uch16x8*>((second ? A1l : A2l) + l31 * PS + a_col);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
