@@ -1757,10 +1757,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
     // ITS columns straight from L2 into registers, D k-steps ahead, with no barrier between the steps of the two pointwise convs (the first
     // form staged K chunks through LDS: eight barrier rounds of ~3.7 k cycles, each waiting for a load issued one round earlier behind the
     // other workgroups' window traffic - 30 k of the workgroup's 60 k cycles).  Step s of the walk: pw2's steps, then branch 1's.
+    // The walk is laid out in PADDED steps: every GEMM starts at a multiple of D (G2 = S2 rounded up, G1 likewise), so that the unrolled
+    // D-step body holds nothing but loads, two LDS reads and MFMAs, and what happens between the GEMMs stands once, between the loops (it
+    // stood inside every unrolled step, D copies of the store epilogue: a 50-100 KB loop body the instruction cache could not hold - a k-step
+    // cost ~900 cycles for 192 cycles of MFMAs even with six workgroups on an idle chip).  A padded step multiplies the zero K tail: exact zeros.
+    const int G2 = (S2 + D - 1) / D * D, G1 = (S1 + D - 1) / D * D;
     uch16x8 bq[D][NT][2];
-    auto load_b = [&](int s, uch16x8 (&dst)[NT][2]) {
-        const bool second = s >= S2, third = s >= S;
-        const int ks = third ? s - S : (second ? s - S2 : s), KQ = (second && !third) ? KQ1 : KQ2;
+    auto load_b = [&](int s, uch16x8 (&dst)[NT][2]) {          // s: padded step
+        const bool second = s >= G2, third = s >= G2 + G1;
+        const int ks = third ? s - (G2 + G1) : (second ? s - G2 : s), KQ = (second && !third) ? KQ1 : KQ2;
         // (without a next unit the steps >= S are masked loads at a clamped address: the base must still be a real pointer)
         const uch16* Wh = reinterpret_cast<const uch16*>((third && chain) ? a.W1nh : ((second && !third) ? a.W3h : a.W2h));
         const uch16* Wl = reinterpret_cast<const uch16*>((third && chain) ? a.W1nl : ((second && !third) ? a.W3l : a.W2l));
@@ -1861,7 +1866,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) { acc0[i][k] = 0.0f; acc1[i][k] = 0.0f; }
-    const int jhi = bf >> 1, Stot = chain ? S + S2 : S;
+    const int jhi = bf >> 1;
     char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * (2 * bf));
     // concat + shuffle store: out[row][2n] = branch 1, out[row][2n + 1] = branch 2; with a next unit behind it, the pairs of the columns
     // n >= bf/2 - channels [bf, 2bf) of the output: that unit's x2 - are ALSO split into the (then free) planes of branch 2
@@ -1889,44 +1894,45 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 1) void down2_kernel(Down2Args a
             }
         }
     };
-    for (int s0 = 0; s0 < Stot; s0 += D) {
+    auto run_gemm = [&](const uch16* Ah_, const uch16* Al_, int PS, int Sn, int p0, int p1) {     // padded steps [p0, p1) of one GEMM (Sn real k-steps)
+        const uch16* ahp = Ah_ + l31 * PS + h * 8;
+        const uch16* alp = Al_ + l31 * PS + h * 8;
+        for (int s0 = p0; s0 < p1; s0 += D) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const int s = s0 + j;
-            if (s == S2) {                                              // (wave-uniform) pw2 is complete: its tile waits in registers for its partner
+            for (int j = 0; j < D; ++j) {
+                const int ks = s0 + j - p0;
+                const int a_col = ks < Sn ? ks * 16 : PS - 8 - h * 8;  // padded step: the last 16 bytes of the row's zero K tail
+                const uch16x8 ah = *reinterpret_cast<const uch16x8*>(ahp + a_col);
+                const uch16x8 al = *reinterpret_cast<const uch16x8*>(alp + a_col);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        y3[nt][r] = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias2[nt], a.act2);
-                        acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f;
-                    }
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][1], acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[j][nt][0], acc1[nt], 0, 0, 0);
+                }
+                load_b(s0 + j + D, bq[j]);                              // (clamped beyond the walk)
             }
-            if (chain && s == S) {                                      // (wave-uniform) the unit's output is complete: store it, x2' -> planes
-                __syncthreads();                                        // every wavefront is past its last read of the planes
-                store_pairs();
-                __syncthreads();                                        // x2' is complete (its K tail [bf, PS2) is still zero)
-                range_report(a.ovf, amax);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f; }
-            }
-            // steps beyond the walk (s >= Stot, at most D - 1 of them) multiply the zero K tail of a row by some weights: exact zeros, no branch
-            const int sc = s < Stot ? s : Stot - 1;
-            const bool second = sc >= S2 && sc < S;
-            const int ks = sc >= S ? sc - S : (second ? sc - S2 : sc), PS = second ? PS1 : PS2;
-            const int a_col = s < Stot ? ks * 16 + h * 8 : PS - 8;
-            const uch16x8 ah = *reinterpret_cast<const uch16x8*>((second ? A1h : A2h) + l31 * PS + a_col);
-            const uch16x8 al = *reinterpret_cast<const uch16x8*>((second ? A1l : A2l) + l31 * PS + a_col);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc0[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][0], acc0[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][1], acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[j][nt][0], acc1[nt], 0, 0, 0);
-            }
-            load_b(s + D, bq[j]);                                       // (masked to zeros beyond the walk)
         }
+    };
+    run_gemm(A2h, A2l, PS2, S2, 0, G2);                                 // pw2: its tile then waits in registers for its partner
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            y3[nt][r] = apply_act(__builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]) + bias2[nt], a.act2);
+            acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f;
+        }
+    run_gemm(A1h, A1l, PS1, S1, G2, G2 + G1);                           // branch 1's pointwise conv
+    if (chain) {                                                        // the unit's output is complete: store it, x2' -> planes, the next unit's pw1
+        __syncthreads();                                                // every wavefront is past its last read of the planes
+        store_pairs();
+        __syncthreads();                                                // x2' is complete (its K tail [bf, PS2) is still zero)
+        range_report(a.ovf, amax);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[nt][r] = 0.0f; acc1[nt][r] = 0.0f; }
+        run_gemm(A2h, A2l, PS2, S2, G2 + G1, G2 + G1 + G2);
     }
     YN_TS();
     if (!chain) {
