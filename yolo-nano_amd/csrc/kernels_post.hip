@@ -496,13 +496,9 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
             const int gi = t + 256 * i;
             const int pl = gi / (4 * BN2), r = gi - pl * (4 * BN2);
             const int o = r / BN2, n = r - o * BN2;
-            const bool ok = n < a.Npad;
-            c3h16x8 v = *reinterpret_cast<const c3h16x8*>(reinterpret_cast<const c3h16*>(pl ? a.Wfl : a.Wfh) + ((size_t)(chunk * 4 + o) * a.Npad + (ok ? n : 0)) * 8);
-            if (!ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
-            }
-            b2_reg[i] = v;
+            // (no select on the loaded value: it would be a USE where the load is issued, and hipcc then waits for every load of the prefetch
+            // in turn, inside the MFMA section it is meant to hide under.  A column past Npad reads column Npad - 1: never decoded.)
+            b2_reg[i] = *reinterpret_cast<const c3h16x8*>(reinterpret_cast<const c3h16*>(pl ? a.Wfl : a.Wfh) + ((size_t)(chunk * 4 + o) * a.Npad + (n < a.Npad ? n : a.Npad - 1)) * 8);
         }
     };
     auto stage_b2 = [&]() {
