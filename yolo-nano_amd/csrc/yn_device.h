@@ -182,25 +182,26 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
     float4 a_reg[A_PER][2];
     c3h16x8 b_reg[B_PER];
     float amax = 0.0f;                                      // range guard: largest |activation| this thread has split
+    // prefetch(): NOTHING but loads (round 5).  The round-2 form masked every loaded value where it was loaded (vmask on A, a select on B): a
+    // use at the point of issue, so hipcc waited for each load in turn - vmcnt(3) ... vmcnt(0) behind every group of four - BEFORE the MFMAs
+    // of the current chunk the prefetch was meant to hide under; the K loop ran load -> wait -> MFMA -> barrier, strictly in sequence.  Now the
+    // addresses are clamped (row M - 1, column Npad - 1, octet KQ - 1, the row start for k >= K) and the only thing that must be zero - the A
+    // values past K, which meet the clamped octets - is zeroed in stage(), after the MFMAs, where the values are needed anyway.  Rows past M and
+    // columns past Npad compute on duplicates and are never stored.  Same values in the planes: the same bits.
     auto prefetch = [&](int c) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int g = t + 256 * i;
             const int row = g / OQ, k = c * KC + (g % OQ) * 8;
             const int m = m0 + row;
-            const bool rok = g < BM * OQ && m < a.M;
             const float* p = a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off;
             if (vecA) {
-                const bool k0 = k < a.K, k1 = k + 4 < a.K;
-                a_reg[i][0] = vmask(*reinterpret_cast<const float4*>(p + (k0 ? k : 0)), opaque_mask(rok && k0));
-                a_reg[i][1] = vmask(*reinterpret_cast<const float4*>(p + (k1 ? k + 4 : 0)), opaque_mask(rok && k1));
+                a_reg[i][0] = *reinterpret_cast<const float4*>(p + (k < a.K ? k : 0));
+                a_reg[i][1] = *reinterpret_cast<const float4*>(p + (k + 4 < a.K ? k + 4 : 0));
             } else {
                 float2 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool kj = k + 2 * j < a.K;
-                    v[j] = vmask(*reinterpret_cast<const float2*>(p + (kj ? k + 2 * j : 0)), opaque_mask(rok && kj));
-                }
+                for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float2*>(p + (k + 2 * j < a.K ? k + 2 * j : 0));
                 a_reg[i][0] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
                 a_reg[i][1] = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
             }
@@ -210,22 +211,19 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
             const int g = t + 256 * i;                      // plane, octet, column
             const int pl = g / (OQ * BN), r = g - pl * (OQ * BN);
             const int o = r / BN, n = r - o * BN;
-            const int kq = c * (KC / 8) + o;
-            const bool ok = g < 2 * OQ * BN && kq < KQ && n0 + n < a.Npad;
-            c3h16x8 v = *reinterpret_cast<const c3h16x8*>((pl ? Wsl : Wsh) + ((size_t)(ok ? kq : 0) * a.Npad + (ok ? n0 + n : 0)) * 8);
-            if (!ok) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
-            }
-            b_reg[i] = v;
+            const int kq = min(c * (KC / 8) + o, KQ - 1), nn = min(n0 + n, a.Npad - 1);
+            b_reg[i] = *reinterpret_cast<const c3h16x8*>(((pl & 1) ? Wsl : Wsh) + ((size_t)kq * a.Npad + nn) * 8);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int c) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int g = t + 256 * i;
             if (g < BM * OQ) {
-                const float x8[8] = {a_reg[i][0].x, a_reg[i][0].y, a_reg[i][0].z, a_reg[i][0].w, a_reg[i][1].x, a_reg[i][1].y, a_reg[i][1].z, a_reg[i][1].w};
+                const int k = c * KC + (g % OQ) * 8;        // valid values of this granule: K - k of them (vecA: whole quads, else pairs)
+                float x8[8] = {a_reg[i][0].x, a_reg[i][0].y, a_reg[i][0].z, a_reg[i][0].w, a_reg[i][1].x, a_reg[i][1].y, a_reg[i][1].z, a_reg[i][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x8[j] = (k + (vecA ? (j & 4) : (j & 6)) < a.K) ? x8[j] : 0.0f;
                 c3h16x8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { amax = range_track(amax, x8[j]); hi[j] = (c3h16)x8[j]; lo[j] = (c3h16)((x8[j] - (float)hi[j]) * 2048.0f); }
@@ -246,7 +244,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
         for (int r = 0; r < 16; ++r) { acc0[i][r] = 0.0f; acc1[i][r] = 0.0f; }
 
     prefetch(0);
-    stage();
+    stage(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) prefetch(c + 1);
@@ -269,7 +267,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmArgs& a, c3h16* smem, 
         }
         if (c + 1 < nchunks) {
             __syncthreads();
-            stage();
+            stage(c + 1);
             __syncthreads();
         }
     }
