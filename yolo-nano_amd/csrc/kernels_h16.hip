@@ -126,8 +126,12 @@ __global__ __launch_bounds__(256, NT >= 3 ? 3 : 4) void hgemm_kernel(HGemmArgs a
         if (TAPS == 9 && m < a.M) { const int rem = m % (a.H * a.W); a_y[i] = rem / a.W; a_x[i] = rem - a_y[i] * a.W; }
     }
     constexpr int B_PER = (4 * BN + 255) / 256;                       // B chunk = 4 octets x BN columns = 4*BN 16-byte granules / 256 threads
+    // prefetch(): loads only - the zeroing of what a clamped address brought (keep8) happens in stage(), with the flags kept from here.  A mask
+    // applied where the value is loaded is a use at the point of issue: hipcc then waits for every load in turn BEFORE the MFMAs of the current
+    // chunk, and the K loop runs load -> wait -> MFMA -> barrier in sequence (round 5; the inference GEMMs had the same: yn_device.h).
     h16x8 a_reg[2];
     h16x8 b_reg[B_PER];
+    bool a_ok[2], b_ok[B_PER];
     auto prefetch = [&](int c) {
         const int tap = TAPS == 9 ? c / cpt : 0;
         const int kq = (c - tap * cpt) * (KC / 8) + a_oct;             // octet inside the tap
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(256, NT >= 3 ? 3 : 4) void hgemm_kernel(HGemmArgs a
                 ok = ok && in;
                 src = in ? src + dy * a.W + dx : src;                  // clamped to the centre pixel when the tap is outside
             }
-            a_reg[i] = keep8(ldh8(a.in + (size_t)src * a.in_ld + a.in_off + (kq < KQ ? kq : 0) * 8), ok);
+            a_reg[i] = ldh8(a.in + (size_t)src * a.in_ld + a.in_off + (kq < KQ ? kq : 0) * 8);
+            a_ok[i] = ok;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
@@ -150,16 +155,17 @@ __global__ __launch_bounds__(256, NT >= 3 ? 3 : 4) void hgemm_kernel(HGemmArgs a
             const int o = g / BN, n = g - o * BN;
             const int kqb = (c - tap * cpt) * (KC / 8) + o;
             const bool ok = g < 4 * BN && kqb < KQ;
-            b_reg[i] = keep8(ldh8(a.Wp + (((size_t)tap * KQ + (ok ? kqb : 0)) * a.Npad + n0 + (g < 4 * BN ? n : 0)) * 8), ok);
+            b_reg[i] = ldh8(a.Wp + (((size_t)tap * KQ + (ok ? kqb : 0)) * a.Npad + n0 + (g < 4 * BN ? n : 0)) * 8);
+            b_ok[i] = ok;
         }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sth8(As + a_row[i] * AST + a_oct * 8, a_reg[i]);
+        for (int i = 0; i < 2; ++i) sth8(As + a_row[i] * AST + a_oct * 8, keep8(a_reg[i], a_ok[i]));
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int g = t + 256 * i;
-            if (g < 4 * BN) sth8(Bs + (size_t)g * 8, b_reg[i]);
+            if (g < 4 * BN) sth8(Bs + (size_t)g * 8, keep8(b_reg[i], b_ok[i]));
         }
     };
     f32x16 acc[NT];
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a)
     // staging: thread -> (row = t/8 + 32*i, octet = t%8), i = 0..1, for both tiles
     const int s_oct = t & 7;
     h16x8 dreg[2], xreg[2];
+    bool dok[2], xok[2];                                                // (masks applied in stage(): hgemm_kernel's prefetch)
     auto prefetch = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -360,7 +367,8 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a)
             const bool mok = m < m_end;
             const int mc = mok ? m : m_begin;
             const int nn = n0 + s_oct * 8, kk = k0 + s_oct * 8;
-            dreg[i] = keep8(ldh8(a.dy + (size_t)mc * a.dy_ld + (nn < a.Np ? nn : 0)), mok && nn < a.Np);
+            dreg[i] = ldh8(a.dy + (size_t)mc * a.dy_ld + (nn < a.Np ? nn : 0));
+            dok[i] = mok && nn < a.Np;
             bool ok = mok && kk < a.Kp;
             int src = mc;
             if (TAPS == 9) {
@@ -370,12 +378,14 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(HWgradArgs a)
                 ok = ok && in;
                 src = in ? mc + dyy * a.W + dxx : mc;
             }
-            xreg[i] = keep8(ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0)), ok);
+            xreg[i] = ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0));
+            xok[i] = ok;
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            dreg[i] = keep8(dreg[i], dok[i]); xreg[i] = keep8(xreg[i], xok[i]);
             const int row = (t >> 3) + 32 * i;
             // ST is not a multiple of 8 halves: store as four 4-byte pieces
             h16x2* d = reinterpret_cast<h16x2*>(Ds + row * ST + s_oct * 8);
@@ -496,13 +506,15 @@ __global__ __launch_bounds__(256) void hwgrad2_kernel(HWgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     h16x8 dreg[DPER], xreg[XPER];
+    bool dok[DPER], xok[XPER];                                          // (masks applied in stage(): hgemm_kernel's prefetch)
     auto prefetch = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < DPER; ++i) {
             const int g = t + 256 * i;
             const int m = mt + g / DOCT, nn = n0 + (g % DOCT) * 8;
             const bool ok = m < m_end && nn < a.Np;
-            dreg[i] = keep8(ldh8(a.dy + (size_t)(m < m_end ? m : m_begin) * a.dy_ld + (nn < a.Np ? nn : 0)), ok);
+            dreg[i] = ldh8(a.dy + (size_t)(m < m_end ? m : m_begin) * a.dy_ld + (nn < a.Np ? nn : 0));
+            dok[i] = ok;
         }
 #pragma unroll
         for (int i = 0; i < XPER; ++i) {
@@ -518,10 +530,15 @@ __global__ __launch_bounds__(256) void hwgrad2_kernel(HWgradArgs a)
                 ok = ok && in;
                 src = in ? mc + dyy * a.W + dxx : mc;
             }
-            xreg[i] = keep8(ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0)), ok);
+            xreg[i] = ldh8(a.x + (size_t)src * a.x_ld + a.x_off + (kk < a.Kp ? kk : 0));
+            xok[i] = ok;
         }
     };
     auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < DPER; ++i) dreg[i] = keep8(dreg[i], dok[i]);
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) xreg[i] = keep8(xreg[i], xok[i]);
 #pragma unroll
         for (int i = 0; i < DPER; ++i) {
             const int g = t + 256 * i;
