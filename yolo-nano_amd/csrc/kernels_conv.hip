@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 
     float2 a_reg[A_PER];
     float4 b_reg[B_PER];
+    // masks of what the clamped addresses brought, applied in stage() (round 5): a mask applied where the value is loaded is a use at the point
+    // of issue, and hipcc then waits for every load of the prefetch in turn before the MFMAs it is meant to hide under (yn_device.h)
+    unsigned a_mk[A_PER], b_mk[B_PER];
     // 16-byte global accesses whenever the layer's channel counts / offsets are multiples of 4 floats (wave-uniform) and the
     // thread owns an even number of k-pairs
     const bool vecA = (MODE == 0) && (A_PER % 2 == 0) && ((a.K | a.in_ld | a.in_off) & 3) == 0;
@@ -114,9 +117,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
             for (int i = 0; i < A_PER / 2; ++i) {
                 const int m = m0 + t / (KP / 2) + (512 / KP) * i;
                 const bool ok = kv && m < a.M;
-                const float4 v = vmask(*reinterpret_cast<const float4*>(a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0)), opaque_mask(ok));
+                const float4 v = *reinterpret_cast<const float4*>(a.in + (size_t)(m < a.M ? m : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0));
                 a_reg[2 * i] = make_float2(v.x, v.y);
                 a_reg[2 * i + 1] = make_float2(v.z, v.w);
+                a_mk[2 * i] = a_mk[2 * i + 1] = opaque_mask(ok);
             }
         } else if (MODE == 0) {
             const int k = k0 + 2 * a_kp;
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const bool ok = kv && a_m[i] >= 0;
-                a_reg[i] = vmask(*reinterpret_cast<const float2*>(a.in + (size_t)(a_m[i] >= 0 ? a_m[i] : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0)), opaque_mask(ok));
+                a_reg[i] = *reinterpret_cast<const float2*>(a.in + (size_t)(a_m[i] >= 0 ? a_m[i] : a.M - 1) * a.in_ld + a.in_off + (kv ? k : 0));
+                a_mk[i] = opaque_mask(ok);
             }
         } else {
             const int kk = k0 + 2 * a_kp;                   // global k = tap*Cin + ci
@@ -139,8 +144,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
                 const unsigned mk = opaque_mask(ok);
                 const int src = ok ? mc + dy * a.W + dx : mc;          // clamped to the centre pixel when the tap is outside
                 const int cic = tap < 9 ? ci : 0;
-                float2 v = vmask(*reinterpret_cast<const float2*>(a.in + (size_t)src * a.in_ld + a.in_off + cic), mk);
-                if (a.resample) {
+                float2 v = *reinterpret_cast<const float2*>(a.in + (size_t)src * a.in_ld + a.in_off + cic);
+                a_mk[i] = mk;
+                if (a.resample) {                           // (the fused add needs both values: this form masks where it loads)
+                    v = vmask(v, mk);
                     const int yc = ok ? y : 0, xc = ok ? x : 0;
                     const int b = mc / (a.H * a.W);
                     size_t p2;
@@ -159,7 +166,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
             const int kpg = (k0 >> 1) + kp;
             const int n = n0 + c4 * 2;
             const bool ok = kpg < kp_total && n < a.Npad;
-            b_reg[i] = vmask(*reinterpret_cast<const float4*>(a.Wp + ((size_t)(ok ? kpg : 0) * a.Npad + (ok ? n : 0)) * 2), opaque_mask(ok));
+            b_reg[i] = *reinterpret_cast<const float4*>(a.Wp + ((size_t)(ok ? kpg : 0) * a.Npad + (ok ? n : 0)) * 2);
+            b_mk[i] = opaque_mask(ok);
         }
     };
     auto stage = [&](int buf) {
@@ -168,21 +176,21 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs a)
 #pragma unroll
             for (int i = 0; i < A_PER / 2; ++i) {
                 const int r = t / (KP / 2) + (512 / KP) * i;
-                *reinterpret_cast<float2*>(As + buf * KP * AS + kp * AS + r * 2) = a_reg[2 * i];
-                *reinterpret_cast<float2*>(As + buf * KP * AS + (kp + 1) * AS + r * 2) = a_reg[2 * i + 1];
+                *reinterpret_cast<float2*>(As + buf * KP * AS + kp * AS + r * 2) = vmask(a_reg[2 * i], a_mk[2 * i]);
+                *reinterpret_cast<float2*>(As + buf * KP * AS + (kp + 1) * AS + r * 2) = vmask(a_reg[2 * i + 1], a_mk[2 * i + 1]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int r = t / KP + RPP * i;
-                *reinterpret_cast<float2*>(As + buf * KP * AS + a_kp * AS + r * 2) = a_reg[i];
+                *reinterpret_cast<float2*>(As + buf * KP * AS + a_kp * AS + r * 2) = vmask(a_reg[i], a_mk[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int idx = t + 256 * i;
             const int kp = idx / (BN / 2), c4 = idx - kp * (BN / 2);
-            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = b_reg[i];
+            *reinterpret_cast<float4*>(Bs + buf * KP * BS + kp * BS + c4 * 4) = vmask(b_reg[i], b_mk[i]);
         }
     };
 
