@@ -452,12 +452,27 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
 #endif
     YN_TS();
     // ---- 1. loads -----------------------------------------------------------------------------------------------------------------
+    // the 96 x 96 split weights go straight into LDS: 2 304 sixteen-byte LDS-DMA pieces, nine per thread, no registers (round 5; they were nine
+    // 16-byte register loads per thread, staged by hand after the depthwise phase: 36 registers live across it, and with the windows and the
+    // taps the kernel's budget was exceeded - hipcc issued the batch in three instalments, each a memory round trip)
+    {
+        constexpr int NP1 = 2 * KQ * BN1;                   // pieces: plane (hi / lo), octet, column
+        static_assert(NP1 % 256 == 0 && (KQ * BN1) % 64 == 0, "whole wavefronts per plane");
+        const unsigned lds_bs = (unsigned)(size_t)(__attribute__((address_space(3))) c3h16*)Bs;
+#pragma unroll
+        for (int i = 0; i < NP1 / 256; ++i) {
+            const int g0 = 256 * i + 64 * wave;             // this wavefront's first piece (wave-uniform)
+            const int pl = g0 / (KQ * BN1);
+            dma16(pl ? a.Wl : a.Wh, (unsigned)(g0 - pl * (KQ * BN1) + lane) * 16u, lds_bs + (unsigned)g0 * 16u);
+        }
+    }
     const int cq = t % (C / 4), run = t / (C / 4);          // 24 channel quads x 8 runs of 4 pixels = 192 workers
     const bool worker = run < 8;
     const int c = cq * 4, ry = run >> 1, rx = (run & 1) * R;
     float4 win[3][R + 2], wd[9], bd = make_float4(0.f, 0.f, 0.f, 0.f);
     if (worker) {
         const int oy = oy0 + ry;
+        unsigned wok = 0;                                   // which window values are inside the image: the masks are applied AFTER the whole batch
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy - 1 + ky;
@@ -467,25 +482,18 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
             for (int j = 0; j < R + 2; ++j) {
                 const int ix = ox0 + rx - 1 + j;
                 const bool ok = yok && ix >= 0 && ix < a.W;
-                win[ky][j] = vmask(*reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C), opaque_mask(ok));
+                win[ky][j] = *reinterpret_cast<const float4*>(rowp + (size_t)(ok ? ix : 0) * C);
+                wok |= (ok ? 1u : 0u) << (ky * (R + 2) + j);
             }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) wd[k] = *reinterpret_cast<const float4*>(a.wdw + k * C + c);
         bd = *reinterpret_cast<const float4*>(a.bdw + c);
-    }
-    constexpr int B1_PER = (2 * KQ * BN1 + 255) / 256;      // 9 granules of 16 bytes per thread
-    c3h16x8 b1_reg[B1_PER];
+        __builtin_amdgcn_sched_barrier(0);                  // all 28 loads are issued before the first is used (one memory round trip, not three)
 #pragma unroll
-    for (int i = 0; i < B1_PER; ++i) {
-        const int gi = t + 256 * i;                         // plane, octet, column
-        const int pl = gi / (KQ * BN1), r = gi - pl * (KQ * BN1);
-        const int o = r / BN1, n = r - o * BN1;
-        c3h16x8 v;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (c3h16)0.0f;
-        if (gi < 2 * KQ * BN1) v = *reinterpret_cast<const c3h16x8*>(reinterpret_cast<const c3h16*>(pl ? a.Wl : a.Wh) + ((size_t)o * BN1 + n) * 8);
-        b1_reg[i] = v;
+            for (int j = 0; j < R + 2; ++j) win[ky][j] = vmask(win[ky][j], 0u - ((wok >> (ky * (R + 2) + j)) & 1u));
     }
     const float gbias = (wave < 3) ? a.bias[wave * 32 + l31] : 0.0f;
     constexpr int B2_PER = 2 * 4 * BN2 / 256;               // 8 granules per thread and chunk
@@ -529,11 +537,7 @@ __device__ __forceinline__ void head_tail_block(const HeadTailArgs& a, const Gri
             *reinterpret_cast<c3h16x4*>(Al + op * AST + c) = lo;
         }
     }
-#pragma unroll
-    for (int i = 0; i < B1_PER; ++i) {
-        const int gi = t + 256 * i;
-        if (gi < 2 * KQ * BN1) *reinterpret_cast<c3h16x8*>(Bs + (size_t)gi * 8) = b1_reg[i];
-    }
+    vm_drain();                                             // the weight pieces (issued a depthwise phase ago)
     prefetch_b2(0);
     __syncthreads();
     YN_TS();
@@ -710,7 +714,8 @@ constexpr int HEAD_TAIL_HALVES = 2 * 32 * 104 + 2 * 12 * 96 * 8;        // plane
 static_assert(2 * 12 * 96 * 8 >= 2 * 4 * 256 * 8 && 2 * 12 * 96 * 8 >= 32 * 260 * 2 + 32 * 8 * 4 + 32 * 4 * 2, "weight space holds a chunk and the raw tile");
 
 template <int KMAX>
-__global__ __launch_bounds__(256, 3) void head_tail_group_kernel(Group<HeadTailArgs> q, GridInfo g, float conf_thresh,
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(3, 3)))     // exactly three wavefronts per SIMD: LDS holds three workgroups; aiming at four costs the load batch its registers
+void head_tail_group_kernel(Group<HeadTailArgs> q, GridInfo g, float conf_thresh,
                                                                   float* __restrict__ boxes, float* __restrict__ scores, int32_t* __restrict__ cls)
 {
     extern __shared__ __attribute__((aligned(16))) float head_tail_smem[];
