@@ -816,8 +816,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN != 4 ? 1 : ((NT == 1 && V ==
                     acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[j][nt][1], acc1[nt], 0, 0, 0);
                     acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[j][nt][0], acc1[nt], 0, 0, 0);
                 }
-                load_b(Wh, Wl, s + D, bq[j]);                   // (masked to zeros beyond the last step)
-            }
+                load_b(Wh, Wl, s + D, bq[j]);                   // (clamped beyond the last step)
+                __builtin_amdgcn_sched_barrier(0);              // HERE, behind the MFMAs that freed the slot: hipcc sank all D steps' loads to the end of
+            }                                                   // the unrolled group, where the next group needs them at once (a round trip per group)
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
