@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const float* __restrict
     const u64 key = K[pos - off];
     const int nch = (n + YN_SORT_CHUNK - 1) >> YN_SORT_CHUNK_LOG;
     int rank = 0;
-    for (int o0 = 0; o0 < nch; o0 += 8) {                   // eight chunks' searches in flight together
+    for (int o0 = 0; o0 < nch; o0 += 8) {                   // eight chunks' searches in flight together (sixteen: slower - the absent chunks' loads are issued too)
         int lo[8], len[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { lo[u] = 0; len[u] = o0 + u < nch ? min(YN_SORT_CHUNK, n - ((o0 + u) << YN_SORT_CHUNK_LOG)) : 0; }
@@ -2094,7 +2094,11 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     float4* sbox = reinterpret_cast<float4*>(wk.sbox);
     u64* M = reinterpret_cast<u64*>(wk.matrix);
     static const int fuse_bs = getenv("YN_NMS_FUSE_BUCKET") ? atoi(getenv("YN_NMS_FUSE_BUCKET")) : 1;       // A/B: 0 = bucket_kernel + sort_kernel also for few segments
-    const bool few = (long)B * C <= 256;
+    // "few segments" (one to three images at 80 classes): everything of an image's NMS on big workgroups that are all resident at once.  Not for
+    // maps with more than 16 K candidates per image (608 x 608: one class of the benchmark's images holds ~10 000 boxes): there the 16 384-key
+    // bitonic network of the one-workgroup sort is 60 us of a 0.57 ms call, and the chunked sort + merge (three launches) is shorter
+    static const int few_n = getenv("YN_NMS_FEW_N") ? atoi(getenv("YN_NMS_FEW_N")) : 16384;
+    const bool few = (long)B * C <= 256 && N <= few_n;
     const int32_t* seg_order = wk.seg_order;                // bucket_kernel's size ranking; the fused kernel does not produce one (few segments: nothing to order)
     if (few && fuse_bs && wk.ctr && !(skip & 1)) {
         seg_order = nullptr;
