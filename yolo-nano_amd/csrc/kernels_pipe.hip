@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void pw_pipe_kernel(GemmArgs a, int t
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[0][r] = __builtin_fmaf(acc1[0][r], 1.0f / 2048.0f, acc0[0][r]);
         vm_drain();         // the next tile's pieces - BEFORE this tile's stores, which need not be waited for
-        gemm_epilogue<1>(a, acc0, m0 + wm * 32, wn * 32, vecO, threadIdx.x & 63, bias1);
+        gemm_epilogue_impl<1, false>(a, acc0, m0 + wm * 32, wn * 32, vecO, threadIdx.x & 63, bias1);     // (no pass-through form: its loads would make hipcc drain the memory counter - stores included - at the top of every tile)
     };
     {
         int next = tile + jstep < tend ? tile + jstep : -1;
