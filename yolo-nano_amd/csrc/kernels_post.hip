@@ -1356,19 +1356,38 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
     const int b = blockIdx.y;
     const int32_t* toff = tile_off + (size_t)b * (C + 1);
     const int total = toff[C];
-    for (int t = blockIdx.x * 4 + wave; t < total; t += gridDim.x * 4) {
-        int lo = 0, hi = C;                                 // largest c with toff[c] <= t
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
-        const int c = lo;
-        const int n = seg_count[(size_t)b * C + c];
-        const int T = (n + 63) >> 6;
-        int rem = t - toff[c], ri = 0;
-        while (rem >= T - ri) { rem -= T - ri; ++ri; }
-        const int ci = ri + rem;
-        if (nms_colmajor(n)) matrix_tile<DIOU, true>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
-                                                     M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
-        else matrix_tile<DIOU>(sbox + (size_t)b * N + seg_off[(size_t)b * C + c], n, T, ri, ci, thresh,
-                               M + (size_t)b * m_stride + (size_t)toff[c] * 64, cbox, carea);
+    // A wavefront walks a CONTIGUOUS range of the image's tiles (round 5; it took tiles 4g + w, + 4G, ...): locating a tile - a binary search over
+    // the classes' tile offsets, the (row chunk, column chunk) of the triangle by subtraction, the segment's count and offset: a dozen dependent
+    // scalar loads, ~2.5 k cycles beside the tile's ~5 k - is paid once per range; the next tile is one step along the row (or the start of
+    // the next row / segment).  Same tiles, same words.
+    const int waves = (int)gridDim.x * 4, wid = (int)blockIdx.x * 4 + wave;
+    const int per = (total + waves - 1) / waves;
+    int t = wid * per;
+    const int t_end = min(total, t + per);
+    if (t >= t_end) return;
+    int lo = 0, hi = C;                                     // largest c with toff[c] <= t
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
+    int c = lo;
+    int n = seg_count[(size_t)b * C + c];
+    int T = (n + 63) >> 6;
+    int rem = t - toff[c], ri = 0;
+    while (rem >= T - ri) { rem -= T - ri; ++ri; }
+    int ci = ri + rem;
+    for (;;) {
+        const float4* sb = sbox + (size_t)b * N + seg_off[(size_t)b * C + c];
+        u64* Ms = M + (size_t)b * m_stride + (size_t)toff[c] * 64;
+        if (nms_colmajor(n)) matrix_tile<DIOU, true>(sb, n, T, ri, ci, thresh, Ms, cbox, carea);
+        else matrix_tile<DIOU>(sb, n, T, ri, ci, thresh, Ms, cbox, carea);
+        if (++t >= t_end) break;
+        if (++ci == T) {
+            if (++ri == T) {                                // the segment's last tile: on to the next class that has any
+                do { ++c; } while (toff[c + 1] <= t);
+                n = seg_count[(size_t)b * C + c];
+                T = (n + 63) >> 6;
+                ri = 0;
+            }
+            ci = ri;
+        }
     }
 }
 
