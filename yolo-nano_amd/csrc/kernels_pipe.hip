@@ -620,6 +620,7 @@ bool launch_pw_pipe(const GemmArgs& a, hipStream_t s)
 {
     if (!a.Wsh || !a.Wsl || a.pass || (a.in_ld & 1) || (a.in_off & 1) || a.Npad != ((a.N + 31) & ~31) || a.M < 64) return false;
     if ((double)a.M * a.in_ld * 4.0 >= 4.0e9) return false;
+    if ((a.K & 3) && a.in_slack < 8) return false;          // the last 16-byte piece of a row overruns it by 8 bytes: only where the caller vouches for the tensor's end
     static const int wg_cap = getenv("YN_PW_PIPE_G") ? atoi(getenv("YN_PW_PIPE_G")) : 1024;
     static const bool off = getenv("YN_PW_PIPE") && atoi(getenv("YN_PW_PIPE")) == 0;               // A/B runs
     if (off) return false;

@@ -289,7 +289,7 @@ size_t network_arena_bytes(yn_handle* h, int B, int S)
     const size_t p3 = (size_t)B * (S / 8) * (S / 8), p4 = p3 / 4, p5 = p4 / 4;
     fl += (p3 + p4 + p5) * NECK * 2 + p4 * NECK;      // laterals, smoothed (p4 twice)
     fl += (p3 + p4 + p5) * NECK * 3;                   // head scratch, one set per (concurrent) head
-    return fl * sizeof(float) + 64 * 256;
+    return fl * sizeof(float) + 192 * 256;           // (rounding + 16 bytes of slack per buffer: arena_take)
 }
 
 // every cached hipGraphExec_t refers to the buffers it was captured with: destroy them whenever those go away
@@ -321,7 +321,9 @@ int ensure_arena(yn_handle* h, int B, int S)
 
 float* arena_take(yn_handle* h, size_t floats)
 {
-    size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
+    // 16 bytes of slack behind every tensor: the LDS-DMA kernels fetch whole 16-byte pieces, and the last piece of a tensor's last row may run
+    // up to 8 bytes past it (rows of 58 or 24 floats behind an 8-byte-aligned start) - never used, but it must be readable
+    size_t bytes = (floats * sizeof(float) + 16 + 255) & ~(size_t)255;
     if (h->arena_used + bytes > h->arena_bytes) return nullptr;
     float* p = (float*)(h->arena + h->arena_used);
     h->arena_used += bytes;
@@ -527,6 +529,7 @@ GemmArgs pw_args(yn_handle* h, const Layer& l, const float* in, int in_ld, int i
     a.out = out; a.out_ld = out_ld; a.out_off = out_off;
     a.pass = pass; a.pass_ld = pass_ld; a.pass_off = pass_off;
     a.M = (int)M; a.K = l.cin; a.N = l.cout; a.Npad = l.Npad; a.act = l.act;
+    a.in_slack = (h->arena && (const char*)in >= h->arena && (const char*)in < h->arena + h->arena_bytes) ? 16 : 0;
     if (n_store > l.cout && n_store <= l.Npad) a.N = n_store;     // padded output row: the extra (zero-weight) columns are stored too
     if (!exact(h)) { a.Wsh = l.ws_hi; a.Wsl = l.ws_lo; }          // split-f16 MFMA family (fp32-class); exact_f32 / range fallback: the f32-MFMA kernels
     a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;

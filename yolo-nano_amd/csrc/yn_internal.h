@@ -36,6 +36,8 @@ struct GemmArgs {
     int dw_stride;                              // dwpw_tile_kernel: stride of the depthwise conv (H, W = its INPUT extent, M = output pixels)
     const void* Wsh; const void* Wsl;           // split-f16 packs of the same weights (hi, lo * 2^11): [taps][ceil(Cin/8)][Npad][8] halves, or null
     unsigned* ovf;                              // split-f16 range guard (yn_device.h, range_report): set to 1 when an activation >= 65504 was split; or null
+    int in_slack;                               // bytes that may be READ past the last element of `in` (arena tensors: 16; caller's tensors: 0) - pw_pipe_kernel's
+                                                // 16-byte DMA pieces run 8 bytes past a row whose K is not a multiple of 4
 };
 
 struct DwArgs {
