@@ -167,3 +167,16 @@ def test_checkpoint_round_trip():
     ra, rb = a(x), b(x)
     for u, v in zip(ra, rb):
         np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_four_streams_are_deterministic_under_contention():
+    """Round 5: the persistent kernels stage their next tile with LDS-DMA pieces the compiler's wait-count bookkeeping does not see; a piece racing
+    its reader would change results only under load.  Four handles / four streams, 60 rounds with all four in flight: every checked call equals
+    the handle's own first (solo) call bit for bit (tools/soak_streams.py; 300+ rounds by hand)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("soak_streams", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_streams.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(calls=60, S=416, B=8) == 0
