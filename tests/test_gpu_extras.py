@@ -179,4 +179,4 @@ def test_four_streams_are_deterministic_under_contention():
     spec = importlib.util.spec_from_file_location("soak_streams", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_streams.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.main(calls=60, S=416, B=8) == 0
+    assert mod.main(calls=60, S=416, B=16) == 0              # (16 images: every stage runs its persistent form)
