@@ -133,6 +133,16 @@ int  yn_pw_f32_config_count(void);
  * (default): on the stages whose map is large enough for that to pay; 0: three kernels per unit everywhere; 2: one kernel per
  * unit everywhere.  All three give bit-identical results (A/B measurements, tests). */
 int  yn_unit_chain(yn_handle* h, int mode);
+/* The form of that one-kernel-per-unit launch (backbone/shufflenetv2.py:53-63, 70-72): unit_pipe_kernel, the persistent software-pipelined
+ * tile walk - mode 1 (default): by its size rule; 0: never (unit_chain2_kernel everywhere); 2: also for few tiles.  Bit-identical. */
+int  yn_chain_pipe(yn_handle* h, int mode);
+/* All but the last stride-1 unit of a backbone stage (backbone/shufflenetv2.py:118-125: the `for i in range(numrepeat)` loop) as ONE
+ * persistent launch (stage_pipe_kernel: (unit, tile) work items by ticket, tile-level ready flags between the units).  mode 1 (default):
+ * from 256 tiles; 0: one launch per unit; 2: at every size.  publish_early 1 (default): a tile raises its ready flag right behind its
+ * stores; 0: under the next tile's depthwise phase.  Bit-identical to the per-unit launches. */
+int  yn_stage_fuse(yn_handle* h, int mode, int publish_early);
+/* pw_pipe_kernel (the persistent form of a pointwise conv, utils/modules.py:8-18 folded) among the autotuner's candidates: 1 (default) / 0. */
+int  yn_pw_pipe(yn_handle* h, int enable);
 
 /* ---- weights ------------------------------------------------------------------------------- */
 /* nn.Module.load_state_dict (eval.py:127, benchmark.py:132): one call per state-dict entry, using

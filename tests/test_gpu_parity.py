@@ -650,20 +650,23 @@ def test_unit_chain_bit_identical_to_three_kernel_path(capi, backbone, C, S, B):
 
 @pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 32), ("1.0x", 20, 160, 2), ("1.0x", 20, 128, 5), ("1.0x", 80, 608, 8), ("0.5x", 80, 416, 16),
                                              ("0.5x", 20, 160, 6), ("0.5x", 80, 224, 2), ("1.0x", 20, 352, 4)])
-def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S, B):
+def test_unit_pipe_is_bit_identical_to_chain2(capi, backbone, C, S, B):
     """Round 5: unit_pipe_kernel - the persistent, software-pipelined form of a stride-1 ShuffleV2 unit (LDS-DMA window and pass-through rows
     of the next tile in flight under the current tile's GEMMs, register-resident weights, depthwise conv from the LDS image) - against
-    unit_chain2_kernel (YN_CHAIN_PIPE=0) on the same handle: raw heads bit for bit.  Shapes: the BASELINE workload (676 tiles of stage 3 on 512
+    unit_chain2_kernel (yn_chain_pipe(h, 0)) on the same handle: raw heads bit for bit.  Shapes: the BASELINE workload (676 tiles of stage 3 on 512
     walking workgroups: two and three tiles per workgroup), maps whose last tile is partial (10 x 10 x 2 = 200 rows, 8 x 8 x 5 = 320), tiles that
-    straddle images, the 0.5x widths (24 / 48 / 96: both tile shapes), fewer tiles than workgroups (YN_CHAIN_PIPE=2 lifts the size rule)."""
+    straddle images, the 0.5x widths (24 / 48 / 96: both tile shapes), fewer tiles than workgroups (yn_chain_pipe(h, 2) lifts the size rule).
+    Round 6: the forms are chosen through the C ABI (handle setters), not through the process environment; the one-launch-per-stage form
+    (stage_pipe_kernel) is off here - it has its own test below."""
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
     h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
     h.load_state_dict(weights.make_state_dict(backbone, C))
     h.fold_bn()
     x = dev(weights.make_input(B, S, seed=S + 3 * B))
-    monkeypatch.setenv("YN_CHAIN_PIPE", "0")
+    h.stage_fuse(0)
+    h.chain_pipe(0)
     ref = [t.clone() for t in h.forward_raw(x)]
-    monkeypatch.setenv("YN_CHAIN_PIPE", "2")
+    h.chain_pipe(2)
     for rep in range(3):                                     # (a race between a DMA piece and its reader would not repeat)
         got = [t.clone() for t in h.forward_raw(x)]
         for u, v in zip(got, ref):
@@ -675,6 +678,42 @@ def test_unit_pipe_is_bit_identical_to_chain2(capi, monkeypatch, backbone, C, S,
     assert any(n.startswith("unit_pipe_kernel") for n in names), names
     if S == 608:                                             # the 38-wide stage-3 window: one eight-wavefront workgroup per CU instead of two of four
         assert any(n.startswith("unit_pipe_kernel<116,false,8>") for n in names), names
+    assert h.range_status() == (False, False)
+    h.close()
+
+
+@pytest.mark.parametrize("backbone,C,S,B", [("1.0x", 80, 416, 32), ("1.0x", 20, 160, 2), ("1.0x", 20, 128, 5), ("1.0x", 80, 608, 8), ("0.5x", 80, 416, 16),
+                                             ("0.5x", 20, 160, 6), ("0.5x", 80, 224, 2), ("1.0x", 20, 352, 4), ("1.0x", 80, 320, 24)])
+@pytest.mark.parametrize("publish_early", [True, False])
+def test_stage_pipe_is_bit_identical(capi, backbone, C, S, B, publish_early):
+    """Round 6: stage_pipe_kernel - all but the last stride-1 unit of a stage as ONE persistent launch ((unit, tile) work items by ticket, tile-level
+    ready flags, write-through hand-off between workgroups, the next item's weights streamed behind the MFMAs) - against one unit_chain2_kernel
+    launch per unit on the same handle: raw heads bit for bit, five repetitions (a hand-off that reads a row before its producer's store has landed
+    would not repeat; the sync words must come back to zero after every launch or the second call already fails).  Shapes: the BASELINE workload
+    (6 x 676 items of stage 3 on 512 workgroups), partial last tiles, tiles that straddle images, the 0.5x widths (64-row tiles), far fewer items than
+    workgroups (mode 2 lifts the size rule), a 608 x 608 map whose window does not fit two workgroups per CU (falls back to per-unit launches)."""
+    anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
+    h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
+    h.load_state_dict(weights.make_state_dict(backbone, C))
+    h.fold_bn()
+    x = dev(weights.make_input(B, S, seed=S + 3 * B))
+    h.stage_fuse(0)
+    h.chain_pipe(0)
+    ref = [t.clone() for t in h.forward_raw(x)]
+    h.chain_pipe(1)
+    h.stage_fuse(2, publish_early)
+    for rep in range(5):
+        got = [t.clone() for t in h.forward_raw(x)]
+        for u, v in zip(got, ref):
+            assert torch.equal(u, v), rep
+    h.profile_enable(True)
+    h.forward_raw(x)
+    names = [r[1] for r in h.profile_records()]
+    h.profile_enable(False)
+    if S != 608:
+        assert any(n.startswith("stage_pipe_kernel") for n in names), names
+    if backbone == "1.0x" and S != 608:
+        assert any(n.startswith("stage_pipe_kernel<116,4,%s>" % ("true" if publish_early else "false")) for n in names), names
     assert h.range_status() == (False, False)
     h.close()
 

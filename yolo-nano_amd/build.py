@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libyolonano_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_h16.hip", []), ("kernels_chain.hip", []), ("kernels_pipe.hip", []), ("yn_api.hip", [])]
+SOURCES = [("kernels_conv.hip", []), ("kernels_post.hip", ["-ffp-contract=off"]), ("kernels_train.hip", []), ("kernels_bwd.hip", []), ("kernels_h16.hip", []), ("kernels_chain.hip", []), ("kernels_pipe.hip", []), ("kernels_stage.hip", []), ("yn_api.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
           "-Wno-pass-failed"]
 
@@ -37,9 +37,10 @@ def _compile(item):
 
 
 def _clean_stale():
-    """-save-temps leftovers (kernels_*.o.0.hipv4-..., *.host-x86_64-...) are not build products: they only ride along to the GPU box"""
+    """-save-temps leftovers of THIS recipe (kernels_*.o.0.hipv4-..., *.host-x86_64-...): not build products, they would only ride along to the
+    GPU box.  Called on the rebuild path only (never on a plain import: another process's compile may be using its own), exact patterns."""
     for f in os.listdir(CSRC):
-        if ".o." in f or "hipv4" in f or "host-x86_64" in f or f.endswith((".bc", ".s", ".hipi", ".hipfb", ".out")):
+        if f.startswith(("kernels_", "yn_api")) and (".o." in f or "hipv4-amdgcn" in f or "host-x86_64" in f):
             try:
                 os.remove(os.path.join(CSRC, f))
             except OSError:
@@ -47,9 +48,9 @@ def _clean_stale():
 
 
 def build(force=False, verbose=False):
-    _clean_stale()
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(p) for p in _deps()):
         return OUT
+    _clean_stale()
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

@@ -49,6 +49,9 @@ SIGNATURES = {
     "yn_pw_config_count": (_i32, []),
     "yn_pw_f32_config_count": (_i32, []),
     "yn_unit_chain": (_i32, [_vp, _i32]),
+    "yn_chain_pipe": (_i32, [_vp, _i32]),
+    "yn_stage_fuse": (_i32, [_vp, _i32, _i32]),
+    "yn_pw_pipe": (_i32, [_vp, _i32]),
     "yn_multi_stream": (_i32, [_vp, _i32]),
     "yn_exact_f32": (_i32, [_vp, _i32]),
     "yn_range_status": (_i32, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
@@ -265,6 +268,19 @@ class Handle:
         """One kernel per stride-1 ShuffleV2 unit: 1 = where the map is large enough (default), 0 = never, 2 = always (True = 2);
         bit-identical results either way."""
         self._ck(self.lib.yn_unit_chain(self.h, 2 if mode is True else int(mode)), "yn_unit_chain")
+
+    def chain_pipe(self, mode=1):
+        """unit_pipe_kernel (the persistent per-unit tile walk): 1 = by its size rule (default), 0 = never, 2 = also for few tiles; bit-identical."""
+        self._ck(self.lib.yn_chain_pipe(self.h, 2 if mode is True else int(mode)), "yn_chain_pipe")
+
+    def stage_fuse(self, mode=1, publish_early=True):
+        """stage_pipe_kernel (all but the last stride-1 unit of a stage as ONE persistent launch): 1 = from 256 tiles (default), 0 = never,
+        2 = at every size; bit-identical to the per-unit launches."""
+        self._ck(self.lib.yn_stage_fuse(self.h, 2 if mode is True else int(mode), int(bool(publish_early))), "yn_stage_fuse")
+
+    def pw_pipe(self, on=True):
+        """pw_pipe_kernel among the pointwise autotune candidates (default on)."""
+        self._ck(self.lib.yn_pw_pipe(self.h, int(bool(on))), "yn_pw_pipe")
 
     def multi_stream(self, on=True):
         """Fork independent kernel chains of one forward onto the handle's side streams (default on).  Turn off when several

@@ -152,8 +152,15 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
 #pragma unroll
         for (int s = 0; s < SMAX; ++s) load_step(Wh, Wl, s, dst[s]);
     };
+    // The first tile's DMA pieces and the tap loads are OLDER than the fragment loads between the two asm statements (side-effecting asm: hipcc
+    // schedules no load across either), so the counted wait behind them retires exactly the pieces and the taps - in EVERY wavefront, taken or
+    // not taken branches notwithstanding - and leaves the fragments in flight under the first depthwise phase.  (Round 5 relied on the wait hipcc
+    // places for the tap stores: in the BF = 24 / 48 / 58 forms that one sits in a branch wavefronts 2-3 skip - ADVICE r5.)  The number of loads
+    // between the markers is checked against the wait's count in the ISA by tests/test_capi_cpu.py.
+    asm volatile("; YN_PIPE_FRAG_BEGIN" ::: "memory");
     load_w(a.Ws2h, a.Ws2l, bw2);
     if constexpr (!last && !STREAM) load_w(a.Ws1h, a.Ws1l, bw1);
+    asm volatile("; YN_PIPE_FRAG_END\n\ts_waitcnt vmcnt(%0)" ::"i"(SMAX * NT * 2 * ((!last && !STREAM) ? 2 : 1)) : "memory");
     float bias2[NT], bias1n[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -435,14 +442,18 @@ static size_t unit_pipe_lds(int bf, int W, int BM)
 // walk.  false = not launched (the caller runs unit_chain2_kernel).
 bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry)
 {
-    // (read at every launch: the tests compare both forms inside one process)
-    const int mode = getenv("YN_CHAIN_PIPE") ? atoi(getenv("YN_CHAIN_PIPE")) : 1;                // 0: never (A/B), 1: default, 2: also for few tiles
+    // the form is the handle's choice (yn_chain_pipe -> ChainArgs::pipe_mode: 0 by the size rule, 1 never, 2 also for few tiles); the A/B knobs
+    // below are read once per process
+    const int mode = a.pipe_mode == 1 ? 0 : (a.pipe_mode == 2 ? 2 : 1);
     // size rule: the walk pays from about one tile per workgroup slot; the streamed wide form (a workgroup's whole-panel prefetch instead of three
     // k-steps of look-ahead) at every size: one 608 x 608 image 0.652 -> 0.639 ms
-    const int min_tiles = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : (a.bf > 128 ? 1 : 256);
-    const int wg_cap = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512;
+    static const int min_tiles_env = getenv("YN_CHAIN_PIPE_MIN") ? atoi(getenv("YN_CHAIN_PIPE_MIN")) : -1;
+    const int min_tiles = min_tiles_env >= 0 ? min_tiles_env : (a.bf > 128 ? 1 : 256);
+    // walking workgroups: a multiple of 8 (XCD-contiguous ranges: jstep = grid / 8 tiles per step - a cap below 8 would never advance), at least 16 so
+    // that the eight-wavefront forms' half is one too
+    static const int wg_cap = [] { int c = getenv("YN_CHAIN_PIPE_G") ? atoi(getenv("YN_CHAIN_PIPE_G")) : 512; c &= ~15; return c < 16 ? 16 : c; }();
     const bool last = a.Wp1n == nullptr;
-    const bool force8 = getenv("YN_CHAIN_PIPE_NW") && atoi(getenv("YN_CHAIN_PIPE_NW")) == 8;      // A/B: the eight-wavefront form also where two windows fit
+    static const bool force8 = getenv("YN_CHAIN_PIPE_NW") && atoi(getenv("YN_CHAIN_PIPE_NW")) == 8;      // A/B: the eight-wavefront form also where two windows fit
     if (!mode || !a.Ws2h || (!last && !a.Ws1h)) return false;
     if (a.dw_act != 0 || a.act2 != 1 || (!last && a.act1n != 1)) return false;
     if ((a.M & 7) || a.t1_ld != a.bf || a.t1_off != 0 || ((a.x1_ld | a.x1_off) & ((a.bf & 3) ? 1 : 3)) || a.out_ld != (last ? 2 * a.bf : a.bf)) return false;
@@ -621,9 +632,7 @@ bool launch_pw_pipe(const GemmArgs& a, hipStream_t s)
     if (!a.Wsh || !a.Wsl || a.pass || (a.in_ld & 1) || (a.in_off & 1) || a.Npad != ((a.N + 31) & ~31) || a.M < 64) return false;
     if ((double)a.M * a.in_ld * 4.0 >= 4.0e9) return false;
     if ((a.K & 3) && a.in_slack < 8) return false;          // the last 16-byte piece of a row overruns it by 8 bytes: only where the caller vouches for the tensor's end
-    static const int wg_cap = getenv("YN_PW_PIPE_G") ? atoi(getenv("YN_PW_PIPE_G")) : 1024;
-    static const bool off = getenv("YN_PW_PIPE") && atoi(getenv("YN_PW_PIPE")) == 0;               // A/B runs
-    if (off) return false;
+    static const int wg_cap = [] { int c = getenv("YN_PW_PIPE_G") ? atoi(getenv("YN_PW_PIPE_G")) : 1024; c &= ~7; return c < 8 ? 8 : c; }();    // a multiple of 8, at least 8 (jstep = grid / 8)
 #define YN_PP(Kv, Nv, NWv, OCCv)                                                                                             \
     if (a.K == Kv && a.Npad == Nv) {                                                                                     \
         constexpr int BM = 32 * (NWv / (Nv <= 32 ? 1 : (Nv <= 64 ? 2 : (Nv <= 128 ? 4 : 8))));                            \

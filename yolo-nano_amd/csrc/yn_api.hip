@@ -145,6 +145,12 @@ struct yn_handle {
     bool autotune = true;
     int force_pw_cfg = -1;                         // yn_set_pw_config (testing aid)
     int unit_chain = 1;                            // stride-1 ShuffleV2 units as one kernel each: 0 off, 1 where the map is large enough, 2 always (yn_unit_chain / YN_UNIT_CHAIN)
+    bool pw_pipe = true;                           // pw_pipe_kernel among the pointwise candidates (yn_pw_pipe / YN_PW_PIPE=0)
+    int chain_pipe = 1;                            // unit_pipe_kernel (the persistent per-unit walk): 0 never, 1 by the size rule, 2 always (yn_chain_pipe / YN_CHAIN_PIPE)
+    int stage_fuse = 1;                            // all but the last stride-1 unit of a stage as ONE persistent launch (stage_pipe_kernel): 0 off, 1 from 256 tiles, 2 always (yn_stage_fuse / YN_STAGE_FUSE)
+    int stage_pub_early = 1;                       // its tiles raise their ready flag right behind their stores (1) or under the next tile's depthwise phase (0) (YN_STAGE_PUB)
+    unsigned* stage_sync = nullptr;                // its queue heads / ready flags / exit count: behind the activation arena, zero between launches
+    size_t stage_sync_bytes = 0;
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     std::vector<GraphEntry> graphs;
     bool profiling = false;
@@ -313,8 +319,14 @@ int ensure_arena(yn_handle* h, int B, int S)
     const size_t need = network_arena_bytes(h, B, S);
     if (need <= h->arena_bytes) return 0;
     if (h->arena) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
-    HIPCHK(h, hipMalloc((void**)&h->arena, need));
+    // behind the activations: the sync words of stage_pipe_kernel (kernels_stage.hip) for the largest stage (stage 2: B (S/8)^2 rows, 32-row tiles,
+    // up to YN_STAGE_MAX units).  Zeroed HERE, once, on the handle's stream; every launch leaves them zero.
+    const size_t sync_bytes = (stage_sync_words((int)((size_t)B * (S / 8) * (S / 8) / 32 + 1), YN_STAGE_MAX) * sizeof(unsigned) + 255) & ~(size_t)255;
+    HIPCHK(h, hipMalloc((void**)&h->arena, need + sync_bytes));
     h->arena_bytes = need;
+    h->stage_sync = reinterpret_cast<unsigned*>(h->arena + need);
+    h->stage_sync_bytes = sync_bytes;
+    HIPCHK(h, hipMemsetAsync(h->stage_sync, 0, sync_bytes, h->stream));
     drop_graphs(h);
     return 0;
 }
@@ -447,9 +459,9 @@ int tune_pw(yn_handle* h, GemmArgs a)
     if (h->force_pw_cfg >= 0) return h->force_pw_cfg;
     if (!h->autotune) return -1;
     // the candidates: the split-f16 family for a layer that carries split packs, else the f32-MFMA family (each bit-identical inside)
-    const int c_lo = a.Wsh ? pw_f32_config_count() : 0, c_hi = a.Wsh ? pw_config_count() : pw_f32_config_count();
+    const int c_lo = a.Wsh ? pw_f32_config_count() : 0, c_hi = a.Wsh ? pw_config_count() - (h->pw_pipe ? 0 : 1) : pw_f32_config_count();   // (pw_pipe_kernel is the last index)
     // one table per process, shared by every handle (bench.py runs four per GPU: the layer shapes are timed once, not four times)
-    const std::vector<int> key = {h->cfg.device, a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0, a.Wsh ? 1 : 0};
+    const std::vector<int> key = {h->cfg.device, a.M, a.K, a.N, a.Npad, a.act, a.in_ld, a.in_off, a.out_ld, a.out_off, a.pass ? 1 : 0, a.Wsh ? 1 : 0, h->pw_pipe ? 1 : 0};
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = g_pw_tuned.find(key);
@@ -619,6 +631,7 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
     const float* x1 = oA;
     int x1_ld = C;
     float* final_out = R > 2 ? oA : oB;
+    std::vector<ChainArgs> ua;
     for (int bi = 1; bi < R; ++bi) {
         const std::string P = name(bi);
         const bool last = bi == R - 1;
@@ -639,17 +652,57 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
             a.out = final_out; a.out_ld = C;
         }
         a.B = B; a.H = H; a.W = W; a.bf = bf; a.Npad = pw2.Npad; a.M = (int)M;
+        a.pipe_mode = h->chain_pipe == 1 ? 0 : (h->chain_pipe == 0 ? 1 : 2);
         a.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
+        ua.push_back(a);
+        x1 = a.out; x1_ld = bf;
+        float* tmp = tA; tA = tB; tB = tmp;
+    }
+    // All but the last unit as ONE persistent launch (stage_pipe_kernel, kernels_stage.hip) where a form exists: the conditions of
+    // unit_pipe_kernel (split-f16 family, ReLU pointwise / linear depthwise convs, dense inputs) + channel quads + enough tiles to walk
+    int staged = 0;
+    if (h->stage_fuse && !exact(h) && R - 2 >= 2 && R - 2 <= YN_STAGE_MAX && h->stage_sync) {
+        StageArgs sa{};
+        bool ok = true;
+        double fl = 0, by = 0;
+        for (int i = 0; i < R - 2 && ok; ++i) {
+            const ChainArgs& q = ua[i];
+            ok = q.Ws2h && q.Ws1h && q.dw_act == 0 && q.act2 == 1 && q.act1n == 1 && q.t1_ld == bf && q.t1_off == 0 && q.x1_off == 0 && (q.x1_ld & 3) == 0 &&
+                 q.out_ld == bf && q.Npad == ((bf + 31) & ~31);
+            StageUnit& u = sa.u[i];
+            u.t1 = q.t1; u.x1 = q.x1; u.x1_ld = q.x1_ld; u.wdw = q.wdw; u.bdw = q.bdw; u.b2 = q.b2; u.b1n = q.b1n;
+            u.Ws2h = q.Ws2h; u.Ws2l = q.Ws2l; u.Ws1h = q.Ws1h; u.Ws1l = q.Ws1l; u.out = q.out; u.t1n = q.t1n;
+            fl += 2.0 * M * bf * (9.0 + 2.0 * bf);
+            by += 4.0 * (4.0 * M * bf + 2.0 * bf * bf + 10.0 * bf);
+        }
+        const int BMt = bf <= 64 ? 64 : 32;
+        sa.nunits = R - 2; sa.M = (int)M; sa.H = H; sa.W = W; sa.tiles = (int)((M + BMt - 1) / BMt);
+        sa.inv_w = 1.0f / (float)W; sa.inv_h = 1.0f / (float)H;
+        sa.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
+        sa.sync = h->stage_sync;
+        ok = ok && (h->stage_fuse == 2 || sa.tiles >= 256) && stage_sync_words(sa.tiles, sa.nunits) * sizeof(unsigned) <= h->stage_sync_bytes;
+        if (ok && launch_stage_pipe(sa, bf, h->stage_pub_early, h->cur, true)) {
+            snprintf(nm, sizeof nm, "backbone.stage%d.1-%d.dw+pw2+pw1n", stage, R - 2);
+            const std::string sname = nm;
+            if (!dbg_skip(h, sname) && !dbg_skip(h, name(1) + ".chain")) {
+                Bracket br(h, sname, fl, by);
+                (void)launch_stage_pipe(sa, bf, h->stage_pub_early, h->cur);
+            }
+            staged = R - 2;
+        }
+    }
+    for (int bi = 1 + staged; bi < R; ++bi) {
+        const std::string P = name(bi);
+        const bool last = bi == R - 1;
+        const ChainArgs& a = ua[bi - 1];
         Bracket br(h, P + (last ? ".dw+pw2" : ".dw+pw2+pw1n"), 2.0 * M * bf * (9.0 + bf + (last ? 0.0 : (double)bf)),
                    4.0 * (4.0 * M * bf + (last ? 1.0 : 2.0) * bf * bf + 10.0 * bf));
-        if (dbg_skip(h, P + ".chain")) { br.cancel(); x1 = a.out; x1_ld = bf; float* tq = tA; tA = tB; tB = tq; continue; }
+        if (dbg_skip(h, P + ".chain")) { br.cancel(); continue; }
         if (!launch_unit_chain(a, h->cur)) {                 // cannot happen after the coverage check above
             br.cancel();
             fail(h, "unit chain: no tile for stage %d unit %d after the coverage check", stage, bi);
             return -1;                                         // never fall back here: the chain has consumed its input buffers
         }
-        x1 = a.out; x1_ld = bf;
-        float* tmp = tA; tA = tB; tB = tmp;
     }
     *result = final_out;
     return 1;
@@ -1200,6 +1253,10 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     if (const char* e12 = getenv("YN_TAIL_FUSE")) h->tail_fuse = atoi(e12) != 0;
     if (const char* e8 = getenv("YN_FUSE_DECODE")) { h->fuse_decode = atoi(e8) != 0; h->fuse_decode_mode = atoi(e8); }
     if (const char* e6 = getenv("YN_MULTI_STREAM")) h->multi_stream = atoi(e6) != 0;  // A/B switch: fork independent chains onto side streams
+    if (const char* e = getenv("YN_CHAIN_PIPE")) h->chain_pipe = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    if (const char* e = getenv("YN_STAGE_FUSE")) h->stage_fuse = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    if (const char* e = getenv("YN_STAGE_PUB")) h->stage_pub_early = atoi(e) != 0;
+    if (const char* e = getenv("YN_PW_PIPE")) h->pw_pipe = atoi(e) != 0;
     if (const char* e4 = getenv("YN_UNIT_CHAIN")) h->unit_chain = atoi(e4) < 0 ? 0 : (atoi(e4) > 2 ? 2 : atoi(e4));    // A/B switch for the one-kernel-per-unit chain
     build_layers(h);
     if (set_grid_info(h, cfg->input_size)) { g_create_error = h->err; delete h; return 1; }
@@ -1408,6 +1465,30 @@ int yn_exact_f32(yn_handle* h, int enable)
 }
 int yn_multi_stream(yn_handle* h, int enable) { if (!h) return 1; h->multi_stream = enable != 0; return 0; }
 int yn_unit_chain(yn_handle* h, int mode) { if (!h) return 1; h->unit_chain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return 0; }
+int yn_chain_pipe(yn_handle* h, int mode)
+{
+    if (!h) return 1;
+    const int m = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    if (m != h->chain_pipe) drop_graphs(h);
+    h->chain_pipe = m;
+    return 0;
+}
+int yn_stage_fuse(yn_handle* h, int mode, int publish_early)
+{
+    if (!h) return 1;
+    const int m = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    if (m != h->stage_fuse || (publish_early != 0) != (h->stage_pub_early != 0)) drop_graphs(h);
+    h->stage_fuse = m;
+    h->stage_pub_early = publish_early != 0;
+    return 0;
+}
+int yn_pw_pipe(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != h->pw_pipe) drop_graphs(h);
+    h->pw_pipe = enable != 0;
+    return 0;
+}
 
 int yn_synchronize(yn_handle* h) { YN_ENTER(h); HIPCHK(h, hipStreamSynchronize(h->stream)); return 0; }
 

@@ -60,7 +60,29 @@ struct ChainArgs {
     float* t1n;                                 // next unit's depthwise input [M][bf]
     int B, H, W, bf, Npad, M;
     unsigned* ovf;                              // split-f16 range guard flag or null
+    int pipe_mode;                              // unit_pipe_kernel: 0 by the size rule, 1 never, 2 also for few tiles (yn_chain_pipe)
 };
+// The stride-1 units of a stage (all but the last) as ONE persistent launch (kernels_stage.hip, stage_pipe_kernel): work items = (unit, tile)
+// handed out by ticket, tile-level ready flags between the units.
+struct StageUnit {
+    const float* t1;                            // depthwise input = this unit's pw1 output, [M][bf]
+    const float* x1; int x1_ld; int pad_;       // pass-through half of the unit's input (offset 0)
+    const float* wdw; const float* bdw;         // depthwise [9][bf], [bf]
+    const float* b2; const float* b1n;          // biases of pw2 and of the next unit's pw1
+    const void *Ws2h, *Ws2l, *Ws1h, *Ws1l;      // split-f16 packs of pw2 / the next unit's pw1
+    float* out;                                 // first half of the shuffled output [M][bf] (the next unit's pass-through half)
+    float* t1n;                                 // the next unit's depthwise input [M][bf]
+};
+constexpr int YN_STAGE_MAX = 7;
+struct StageArgs {
+    StageUnit u[YN_STAGE_MAX];
+    int nunits, M, H, W, tiles;
+    float inv_w, inv_h;
+    unsigned* ovf;                              // split-f16 range guard flag or null
+    unsigned* sync;                             // stage_sync_words() words, zero between launches (the kernel leaves them zero)
+};
+size_t stage_sync_words(int tiles, int nunits);
+bool launch_stage_pipe(const StageArgs& a, int bf, int pub_early, hipStream_t s, bool dry = false);   // false = no form for this shape, nothing launched
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
 bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry = false);   // kernels_pipe.hip: the persistent tile walk; false = not applicable, nothing launched
 
