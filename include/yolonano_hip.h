@@ -84,7 +84,11 @@ int  yn_exact_f32(yn_handle* h, int enable);
  *     NEGATIVE (-1 - K_b), and yn_pack_detections carries the mark on as offsets_dev[B] = -1 - total.  The flag is sticky until
  *     yn_range_status clears it.  The same fact OUT OF BAND, for callers that loop `i < count[b]` without looking at the sign: the kernel
  *     that writes the negative counts also sets one word of pinned host memory, and from then on every yn_infer / yn_pack_detections
- *     on the handle returns YN_STATUS_RANGE (checked on the host, no synchronisation) until yn_range_status has been called.
+ *     on the handle returns YN_STATUS_RANGE (checked on the host, no synchronisation) until yn_range_status has been called - or
+ *     yn_exact_f32(h, 1) is in force (the f32-MFMA family cannot leave the range: running again under it is the recovery).  The out-of-band
+ *     check is BEST EFFORT for pipelined calls: a yn_infer enqueued before the marking kernel has run is not refused; the negative counts
+ *     always travel with the results themselves.
+ *     yn_range_status also reports (return 1 + yn_last_error) an expired bounded wait of stage_pipe_kernel (yn_stage_fuse).
  * Tiny values need no guard: below the f16 normal range lo = (x - hi) * 2^11 still carries x. */
 int  yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overflow);
 /* yn_infer only: the last pointwise conv of each detection head (models/yolo_nano.py:299-301) and the decode of that scale's

@@ -741,6 +741,31 @@ def test_pw_pipe_op_is_bit_identical_to_gemm_split(hvoc, M, cin, cout, act):
         hvoc.set_pw_config(-1)
 
 
+@pytest.mark.parametrize("M,cin,cout", [(333, 58, 58), (4100, 116, 96), (97, 24, 58), (1000, 232, 116)])
+def test_pw_k_tail_never_reads_a_neighbours_nan(hvoc, M, cin, cout):
+    """The unmasked prefetches of the split-f16 GEMMs (round 5) make the K tail exact only as 'zero A tail x finite B': the activations'
+    neighbourhood must never leak in.  K % 16 != 0 inputs inside a NaN-filled buffer (what lies behind the tensor, and behind every clamped
+    row, is NaN): every split configuration must give the finite, bit-identical result of the first one (advisor, round 5)."""
+    rs = np.random.RandomState(M + cin)
+    buf = torch.full((M * cin + 4096,), float("nan"), dtype=torch.float32, device="cuda")
+    x = buf[2048:2048 + M * cin].view(1, 1, M, cin)
+    x.copy_(dev(rs.standard_normal((1, 1, M, cin)).astype(np.float32)))
+    w = dev((rs.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))
+    b = dev(rs.standard_normal((cout,)).astype(np.float32))
+    _, split_fam = hvoc.pw_families()
+    try:
+        hvoc.set_pw_config(split_fam[0])
+        ref = hvoc.op_pwconv(x, w, b, 1).clone()
+        assert bool(torch.isfinite(ref).all())
+        xc = x.clone()                                               # the same values in an ordinary allocation
+        assert torch.equal(hvoc.op_pwconv(xc, w, b, 1), ref)
+        for cfg in split_fam[1:]:
+            hvoc.set_pw_config(cfg)
+            assert torch.equal(hvoc.op_pwconv(x, w, b, 1), ref), cfg
+    finally:
+        hvoc.set_pw_config(-1)
+
+
 @pytest.mark.parametrize("backbone,S,B", [("1.0x", 416, 8), ("0.5x", 320, 4), ("1.0x", 160, 3)])
 def test_pw_pipe_in_the_network_is_bit_identical(capi, backbone, S, B):
     """... and inside the network (strided / offset inputs: the right half of a unit's map; lateral and head members), with the kernel seen

@@ -231,6 +231,17 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[nt][r] = __builtin_fmaf(acc1[nt][r], 1.0f / 2048.0f, acc0[nt][r]);
     };
+    // STREAM: hipcc is TOLD where the streamed panel has landed (an empty asm that reads and writes its 30 fragment registers: its own wait for the
+    // refill loads goes HERE - behind the hand-placed drain - instead of in front of the next tile's first GEMM's
+    // MFMAs with the count of the loads it knows of, vmcnt(0) at the last k-step, which retires the DMA pieces issued just before that GEMM)
+    auto panel_landed = [&]() {
+        if constexpr (STREAM) {
+            static_assert(!STREAM || (SMAX == 15 && NT == 1), "30 asm operands");
+#define YN_P2(s) "+v"(bw2[s][0][0]), "+v"(bw2[s][0][1])
+            asm volatile("" : YN_P2(0), YN_P2(1), YN_P2(2), YN_P2(3), YN_P2(4), YN_P2(5), YN_P2(6), YN_P2(7), YN_P2(8), YN_P2(9), YN_P2(10), YN_P2(11), YN_P2(12), YN_P2(13), YN_P2(SMAX - 1));
+#undef YN_P2
+        }
+    };
     auto split2 = [&](int r, int c, float v0, float v1) {               // two adjacent channels of row r -> both planes
         amax = range_track(range_track(amax, v0), v1);
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -244,7 +255,10 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
     // tap-valid bits of a tile's rows (zero padding of the 3 x 3 window; idle rows: nothing valid) -> mtab; written one tile ahead, behind the
     // barrier that ends the depthwise phase (the only reader)
     auto write_mtab = [&](int tl) {
-        if (t < BM) {
+        int tq = threadIdx.x;                                           // (opaque: as a loop invariant the mtab address is one more register held across the GEMMs -
+        asm volatile("" : "+v"(tq));                                    //  the eight-wavefront form of width 116 spilled it, and a scratch reload's vmcnt(0) retires the DMA pieces in flight)
+        if (tq < BM) {
+            const int t = tq;
             const int m0 = tl * BM;
             const int rem0 = m0 % HW;                                   // wave-uniform
             const int y0 = rem0 / W, x0 = rem0 - y0 * W;
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
         // ---- y = act(acc + b2) straight to its final place: (x1, y) pairs -> global, or split into the planes as x2'.  Row groups of
         //      eight are live or idle as a whole (M % 8 == 0 is a launch condition): scalar branches only, one exec region per destination ----
         {
-            char* out_base = reinterpret_cast<char*>(a.out + (size_t)m0 * out_ld);
+            const __amdgpu_buffer_rsrc_t out_rs = buf_rsrc(a.out + (size_t)m0 * out_ld);       // (one lane offset + immediates instead of a 64-bit lane address per row)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = wn * NT * 32 + nt * 32 + l31;
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int row = wm * 32 + q + 8 * g8 + 4 * h;
-                                *reinterpret_cast<float2*>(out_base + (unsigned)(row * out_ld + 2 * n) * 4u) = make_float2(xv[q], y[q]);
+                                buf_store_b64<0>(out_rs, (unsigned)(row * out_ld + 2 * n) * 4u, make_float2(xv[q], y[q]));
                             }
                         }
                         if (to_plane) {
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void unit_pipe_kernel(ChainArgs a, int 
             else gemm(bw1, std::integral_constant<int, 0>{}, false);
             YN_TS();
             vm_drain();
+            panel_landed();
             YN_TS();     // the next tile's pieces (and this tile's first stores, long gone) - BEFORE the stores below, which need not be waited for
             GemmArgs e{};
             e.out = a.t1n; e.out_ld = bf; e.out_off = 0; e.M = m0 + nrows; e.N = bf; e.Npad = a.Npad; e.bias = a.b1n; e.act = a.act1n; e.pass = nullptr;

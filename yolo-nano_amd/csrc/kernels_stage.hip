@@ -45,26 +45,6 @@ __device__ __forceinline__ void dma16_sc1(const void* gbase, unsigned goff, unsi
                  : "v"(goff), "s"(gbase), "s"(lds_dst)
                  : "memory");
 }
-// write-through stores (sc1): compiler-visible (counted, hazards padded)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* p) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000); }
-__device__ __forceinline__ void st_wt_b128(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
-{
-    sf32x4 d = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, d), r, (int)off, 0, 16);
-}
-__device__ __forceinline__ void st_wt_b64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v)
-{
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 d = {v.x, v.y};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, d), r, (int)off, 0, 16);
-}
-
-// sync words of one launch (per handle, zero between launches)
-constexpr int STAGE_HEAD_STRIDE = 64;          // one queue head per 256 bytes
-constexpr int STAGE_EXIT = 8 * STAGE_HEAD_STRIDE;
-constexpr int STAGE_TIMEOUT = STAGE_EXIT + 1;
-constexpr int STAGE_FLAGS = 1024;
-
 template <int BF, int NW, bool PUB_EARLY>
 __global__ __launch_bounds__(64 * NW, 2) void stage_pipe_kernel(StageArgs a)
 {
@@ -415,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stage_pipe_kernel(StageArgs a)
 
         // ---- y = relu(acc + b2): (x1, y) pairs -> global (write-through: the next unit's pass-through half), or split into the planes as x2' ----
         {
-            const __amdgpu_buffer_rsrc_t ro = wt_rsrc(U.out);
+            const __amdgpu_buffer_rsrc_t ro = buf_rsrc(U.out);
             const int n = ncol;
             const float bias = n < BF ? biasl[(2 * par) * BF + n] : 0.0f;
             const bool to_global = n < jhi;
@@ -433,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stage_pipe_kernel(StageArgs a)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int row = m0 + wm * 32 + q + 8 * g8 + 4 * h;
-                            st_wt_b64(ro, (unsigned)(row * BF + 2 * n) * 4u, make_float2(xv[q], y[q]));
+                            buf_store_b64<16>(ro, (unsigned)(row * BF + 2 * n) * 4u, make_float2(xv[q], y[q]));
                         }
                     }
                     if (to_plane) {
@@ -478,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stage_pipe_kernel(StageArgs a)
         }
         YN_TS(10);
         {
-            const __amdgpu_buffer_rsrc_t rt = wt_rsrc(U.t1n);
+            const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.t1n);
             const float bias = ncol < BF ? biasl[(2 * par + 1) * BF + ncol] : 0.0f;
             // gemm_epilogue_impl's 16-byte form: an accumulator quad transposed inside its four lanes, lane j stores row j x 4 columns
             const int j = lane & 3;
@@ -498,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, 2) void stage_pipe_kernel(StageArgs a)
                     if (j & 2) { v0 = r0; v1 = r1; } else { v2 = r0; v3 = r1; }
                 }
                 const int m = m0 + wm * 32 + 8 * g + 4 * h + j;
-                if (m < m0 + nrows && nq < BF) st_wt_b128(rt, (unsigned)(m * BF + nq) * 4u, make_float4(v0, v1, v2, v3));
+                if (m < m0 + nrows && nq < BF) buf_store_b128<16>(rt, (unsigned)(m * BF + nq) * 4u, make_float4(v0, v1, v2, v3));
             }
         }
         YN_TS(11);

@@ -1266,7 +1266,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
         hipMemsetAsync(h->range_flags, 0, 3 * sizeof(unsigned), h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         g_create_error = "yn_create: out of device memory"; delete h; return 1;
     }
-    if (hipHostMalloc((void**)&h->range_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&h->range_host, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||      // coherent: the kernel's system-scope store is visible when it is made, not at kernel end (HIP_HOST_COHERENT=0)
         hipHostGetDevicePointer((void**)&h->range_host_dev, h->range_host, 0) != hipSuccess) {
         g_create_error = "yn_create: no pinned host memory for the range flag"; delete h; return 1;
     }
@@ -1622,7 +1622,8 @@ int yn_fold_bn(yn_handle* h)
 // yn_range_status yet.  No synchronisation: the word is host memory.
 static int range_pending(yn_handle* h, const char* who)
 {
-    if (h->range_host && __atomic_load_n(h->range_host, __ATOMIC_RELAXED)) {
+    // (not under yn_exact_f32: the f32-MFMA family cannot raise the flag, and running again under it IS the documented recovery - ADVICE r5)
+    if (!exact(h) && h->range_host && __atomic_load_n(h->range_host, __ATOMIC_RELAXED)) {
         fail(h, "%s: an earlier yn_infer split an activation >= 65504 (split-f16 range): its results are invalid - call yn_range_status to acknowledge, "
                 "then yn_exact_f32(h, 1) and run again", who);
         return YN_STATUS_RANGE;
@@ -1638,6 +1639,15 @@ int yn_range_status(yn_handle* h, int* weights_exceed_f16, int* activation_overf
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (f) HIPCHK(h, hipMemsetAsync(h->range_flags + 1, 0, sizeof(unsigned), h->stream));
     if (h->range_host) __atomic_store_n(h->range_host, 0u, __ATOMIC_RELAXED);      // acknowledged (the stream is idle: no compact_kernel can still set it)
+    if (h->stage_sync) {                                                            // stage_pipe_kernel's bounded waits (kernels_stage.hip): an expired one marks the launch
+        unsigned tmo = 0;
+        HIPCHK(h, hipMemcpyAsync(&tmo, h->stage_sync + STAGE_TIMEOUT, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (tmo) {
+            HIPCHK(h, hipMemsetAsync(h->stage_sync + STAGE_TIMEOUT, 0, sizeof(unsigned), h->stream));
+            return fail(h, "stage_pipe_kernel: a bounded wait for a tile's ready flag expired (2 s): the results of that call are invalid; yn_stage_fuse(h, 0, 1) runs the units one launch each");
+        }
+    }
     if (weights_exceed_f16) *weights_exceed_f16 = h->range_fallback ? 1 : 0;
     if (activation_overflow) *activation_overflow = f ? 1 : 0;
     return 0;

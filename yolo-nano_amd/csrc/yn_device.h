@@ -301,6 +301,28 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned goff, unsigned
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Raw-buffer stores: SGPR descriptor + ONE 32-bit lane offset + a 12-bit immediate - the four rows of an accumulator group share an offset register
+// where `global_store` held a 64-bit lane address per row as a loop invariant (unit_pipe_kernel<116,false,8> spilled them: 16 bytes of scratch whose
+// reload - s_waitcnt vmcnt(0) - retired the DMA pieces in flight).  AUX = 0: plain; 16: sc1 = write-through (hand-off to another workgroup inside a
+// launch, kernels_stage.hip).  Offsets are unsigned 32-bit (the descriptor spans 4 GB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(void* p) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, -1, 0x00020000); }
+template <int AUX>
+__device__ __forceinline__ void buf_store_b128(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+    const f4 d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), r, (int)off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store_b64(__amdgpu_buffer_rsrc_t r, unsigned off, float2 v)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((__vector_size__(2 * sizeof(unsigned))));
+    const f2 d = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, d), r, (int)off, 0, AUX);
+}
+
 template <int V> struct VecT;
 template <> struct VecT<2> { typedef float2 type; };
 template <> struct VecT<4> { typedef float4 type; };

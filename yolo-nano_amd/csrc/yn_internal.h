@@ -34,7 +34,11 @@ struct GemmArgs {
     const float* dw_w; const float* dw_b;       // fused depthwise prologue (dwpw kernel): [9][K], [K]
     int dw_act;                                 // activation between the depthwise and the pointwise conv
     int dw_stride;                              // dwpw_tile_kernel: stride of the depthwise conv (H, W = its INPUT extent, M = output pixels)
-    const void* Wsh; const void* Wsl;           // split-f16 packs of the same weights (hi, lo * 2^11): [taps][ceil(Cin/8)][Npad][8] halves, or null
+    const void* Wsh; const void* Wsl;           // split-f16 packs of the same weights (hi, lo * 2^11): [taps][ceil(Cin/8)][Npad][8] halves, or null.
+                                                // INVARIANT the kernels rely on (their prefetches carry no masks): every value of every octet
+                                                // < ceil(Cin/8) and every column < Npad is FINITE (fold_pack_kernel checks what it packs and zero-fills the
+                                                // padding) - the A operand's zero K tail times a clamped / padded B octet must be an exact zero; and
+                                                // accumulator rows >= M hold duplicates of row M - 1: an epilogue must never reduce over rows
     unsigned* ovf;                              // split-f16 range guard (yn_device.h, range_report): set to 1 when an activation >= 65504 was split; or null
     int in_slack;                               // bytes that may be READ past the last element of `in` (arena tensors: 16; caller's tensors: 0) - pw_pipe_kernel's
                                                 // 16-byte DMA pieces run 8 bytes past a row whose K is not a multiple of 4
@@ -81,6 +85,12 @@ struct StageArgs {
     unsigned* ovf;                              // split-f16 range guard flag or null
     unsigned* sync;                             // stage_sync_words() words, zero between launches (the kernel leaves them zero)
 };
+// layout of the sync words: eight queue heads (one per 256 bytes), the exit count, the timeout mark (set when a bounded wait expired: the results of
+// that launch are not to be trusted - yn_range_status reports and clears it), then one ready flag per (unit, tile)
+constexpr int STAGE_HEAD_STRIDE = 64;
+constexpr int STAGE_EXIT = 8 * STAGE_HEAD_STRIDE;
+constexpr int STAGE_TIMEOUT = STAGE_EXIT + 1;
+constexpr int STAGE_FLAGS = 1024;
 size_t stage_sync_words(int tiles, int nunits);
 bool launch_stage_pipe(const StageArgs& a, int bf, int pub_early, hipStream_t s, bool dry = false);   // false = no form for this shape, nothing launched
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
