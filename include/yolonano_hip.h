@@ -142,8 +142,9 @@ int  yn_unit_chain(yn_handle* h, int mode);
 int  yn_chain_pipe(yn_handle* h, int mode);
 /* All but the last stride-1 unit of a backbone stage (backbone/shufflenetv2.py:118-125: the `for i in range(numrepeat)` loop) as ONE
  * persistent launch (stage_pipe_kernel: (unit, tile) work items by ticket, tile-level ready flags between the units).  mode 1 (default):
- * from 256 tiles; 0: one launch per unit; 2: at every size.  publish_early 1 (default): a tile raises its ready flag right behind its
- * stores; 0: under the next tile's depthwise phase.  Bit-identical to the per-unit launches. */
+ * from 256 tiles; 0: one launch per unit; 2: at every size.  publish_early 0 (default): a tile raises its ready flag under the next tile's
+ * depthwise phase (at once when the workgroup has to wait for its next item's inputs); 1: right behind its stores.  Bit-identical to the
+ * per-unit launches. */
 int  yn_stage_fuse(yn_handle* h, int mode, int publish_early);
 /* pw_pipe_kernel (the persistent form of a pointwise conv, utils/modules.py:8-18 folded) among the autotuner's candidates: 1 (default) / 0. */
 int  yn_pw_pipe(yn_handle* h, int enable);

@@ -691,7 +691,7 @@ def test_stage_pipe_is_bit_identical(capi, backbone, C, S, B, publish_early):
     launch per unit on the same handle: raw heads bit for bit, five repetitions (a hand-off that reads a row before its producer's store has landed
     would not repeat; the sync words must come back to zero after every launch or the second call already fails).  Shapes: the BASELINE workload
     (6 x 676 items of stage 3 on 512 workgroups), partial last tiles, tiles that straddle images, the 0.5x widths (64-row tiles), far fewer items than
-    workgroups (mode 2 lifts the size rule), a 608 x 608 map whose window does not fit two workgroups per CU (falls back to per-unit launches)."""
+    workgroups (mode 2 lifts the size rule), a 608 x 608 map whose window does not fit two workgroups per CU (the eight-wavefront form)."""
     anchors = arch.MULTI_ANCHOR_SIZE_COCO if C == 80 else arch.MULTI_ANCHOR_SIZE
     h = capi.Handle(S, C, anchors, backbone, 0.001, 0.5, max_batch=B)
     h.load_state_dict(weights.make_state_dict(backbone, C))
@@ -710,10 +710,9 @@ def test_stage_pipe_is_bit_identical(capi, backbone, C, S, B, publish_early):
     h.forward_raw(x)
     names = [r[1] for r in h.profile_records()]
     h.profile_enable(False)
-    if S != 608:
-        assert any(n.startswith("stage_pipe_kernel") for n in names), names
-    if backbone == "1.0x" and S != 608:
-        assert any(n.startswith("stage_pipe_kernel<116,4,%s>" % ("true" if publish_early else "false")) for n in names), names
+    assert any(n.startswith("stage_pipe_kernel") for n in names), names
+    if backbone == "1.0x":                                   # 608 x 608: the 38-wide stage-3 window - one eight-wavefront workgroup per CU, 64-row tiles
+        assert any(n.startswith("stage_pipe_kernel<116,%d,%s>" % (8 if S == 608 else 4, "true" if publish_early else "false")) for n in names), names
     assert h.range_status() == (False, False)
     h.close()
 

@@ -147,7 +147,7 @@ def test_first_tile_wait_counts_the_fragment_loads(kernels_asm):
                 assert m and int(m.group(1)) == expect, "%s: %d fragment loads between the markers, the wait behind them says %s" % (name, expect, ln.strip())
                 expect = None
                 checked += 1
-    assert checked >= 22 + 8, "unit_pipe_kernel has 22 instantiations, stage_pipe_kernel 8: only %d marker pairs seen" % checked
+    assert checked >= 22 + 16, "unit_pipe_kernel has 22 instantiations, stage_pipe_kernel 16: only %d marker pairs seen" % checked
 
 
 def test_no_compiler_drain_under_the_dma_in_the_tile_loops(kernels_asm):

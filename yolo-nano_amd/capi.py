@@ -273,7 +273,7 @@ class Handle:
         """unit_pipe_kernel (the persistent per-unit tile walk): 1 = by its size rule (default), 0 = never, 2 = also for few tiles; bit-identical."""
         self._ck(self.lib.yn_chain_pipe(self.h, 2 if mode is True else int(mode)), "yn_chain_pipe")
 
-    def stage_fuse(self, mode=1, publish_early=True):
+    def stage_fuse(self, mode=1, publish_early=False):
         """stage_pipe_kernel (all but the last stride-1 unit of a stage as ONE persistent launch): 1 = from 256 tiles (default), 0 = never,
         2 = at every size; bit-identical to the per-unit launches."""
         self._ck(self.lib.yn_stage_fuse(self.h, 2 if mode is True else int(mode), int(bool(publish_early))), "yn_stage_fuse")

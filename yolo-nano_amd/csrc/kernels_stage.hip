@@ -544,41 +544,47 @@ static size_t stage_pipe_lds(int bf, int W, int BM)
 
 size_t stage_sync_words(int tiles, int nunits) { return (size_t)STAGE_FLAGS + (size_t)tiles * nunits; }
 
-// true = launched.  false = no form for this shape (the caller launches the units one by one).
-bool launch_stage_pipe(const StageArgs& a, int bf, int pub_early, hipStream_t s, bool dry)
+// true = launched (or, dry: would be).  false = no form for this shape or fewer than min_tiles tiles (the caller launches the units one by one).
+// The tile count of the form taken goes into the arguments here (a.tiles is ignored on entry).
+bool launch_stage_pipe(StageArgs a, int bf, int pub_early, int min_tiles, size_t sync_bytes, hipStream_t s, bool dry)
 {
-    if (a.nunits < 2 || a.nunits > YN_STAGE_MAX || (a.M & 7) || a.tiles >= (1 << 20)) return false;
-    if ((double)a.M * bf * 8.0 >= 2.0e9) return false;                    // 31-bit buffer offsets
+    if (a.nunits < 2 || a.nunits > YN_STAGE_MAX || (a.M & 7)) return false;
+    if ((double)a.M * bf * 8.0 >= 4.0e9) return false;                    // 32-bit byte offsets (DMA pieces, raw-buffer stores)
     // workgroups: tickets in hand (~1.65 per workgroup) against the tiles of one unit decide how often an item finds its inputs unfinished
     static const int wg_env = getenv("YN_STAGE_G") ? atoi(getenv("YN_STAGE_G")) : 0;
     // 416 x 416 / bs 32, stage 3: 384 / 448 / 512 workgroups all run 96-98 us (fewer stalls against fewer slots); the narrow branches (<= 48
     // channels: 52 KB of LDS, 168 registers) fit three workgroups per CU: 0.5x bs 128 stage 2 149 -> 130 us with 768
-    const int wg = wg_env > 0 ? wg_env : (bf <= 48 ? 768 : 512);
+    const int wg4 = wg_env > 0 ? wg_env : (bf <= 48 ? 768 : 512);
+    // two four-wavefront workgroups per CU where their windows fit (80 KB each), else one of eight (twice the rows per tile; 608 x 608 stage 3: W = 38)
 #define YN_SP(BFv, NWv)                                                                                                  \
     if (bf == BFv) {                                                                                                     \
         constexpr int BM = 32 * (NWv / (BFv <= 64 ? 2 : 4));                                                             \
+        constexpr size_t LDS_MAX = (size_t)(NWv == 4 ? 80 : 160) * 1024;                                                 \
         const size_t lds = stage_pipe_lds(bf, a.W, BM);                                                                  \
-        if (lds > (size_t)80 * 1024 || a.tiles != (a.M + BM - 1) / BM) return false;                                     \
-        if (dry) return true;                                                                                            \
-        unsigned g = (unsigned)wg;                                                                                       \
-        if (g > (unsigned)(a.tiles * a.nunits)) g = (unsigned)(a.tiles * a.nunits);                                      \
-        if (pub_early) {                                                                                                 \
-            static unsigned long long attr = 0;                                                                          \
-            if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_pipe_kernel<BFv, NWv, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            set_last_kernel_name("stage_pipe_kernel<" #BFv "," #NWv ",true>");                                           \
-            hipLaunchKernelGGL((stage_pipe_kernel<BFv, NWv, true>), dim3(g), dim3(64 * NWv), lds, s, a);                 \
-        } else {                                                                                                         \
-            static unsigned long long attr = 0;                                                                          \
-            if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_pipe_kernel<BFv, NWv, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            set_last_kernel_name("stage_pipe_kernel<" #BFv "," #NWv ",false>");                                          \
-            hipLaunchKernelGGL((stage_pipe_kernel<BFv, NWv, false>), dim3(g), dim3(64 * NWv), lds, s, a);                \
+        a.tiles = (a.M + BM - 1) / BM;                                                                                   \
+        if (lds <= LDS_MAX) {                                                                                            \
+            if (a.tiles < min_tiles || a.tiles >= (1 << 20) || stage_sync_words(a.tiles, a.nunits) * sizeof(unsigned) > sync_bytes) return false; \
+            if (dry) return true;                                                                                        \
+            unsigned g = (unsigned)(NWv == 4 ? wg4 : 256);                                                               \
+            if (g > (unsigned)(a.tiles * a.nunits)) g = (unsigned)(a.tiles * a.nunits);                                  \
+            if (pub_early) {                                                                                             \
+                static unsigned long long attr = 0;                                                                      \
+                if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_pipe_kernel<BFv, NWv, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
+                set_last_kernel_name("stage_pipe_kernel<" #BFv "," #NWv ",true>");                                       \
+                hipLaunchKernelGGL((stage_pipe_kernel<BFv, NWv, true>), dim3(g), dim3(64 * NWv), lds, s, a);             \
+            } else {                                                                                                     \
+                static unsigned long long attr = 0;                                                                      \
+                if (attr_pending(attr)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_pipe_kernel<BFv, NWv, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX); \
+                set_last_kernel_name("stage_pipe_kernel<" #BFv "," #NWv ",false>");                                      \
+                hipLaunchKernelGGL((stage_pipe_kernel<BFv, NWv, false>), dim3(g), dim3(64 * NWv), lds, s, a);            \
+            }                                                                                                            \
+            return true;                                                                                                 \
         }                                                                                                                \
-        return true;                                                                                                     \
     }
-    YN_SP(116, 4)
-    YN_SP(96, 4)
-    YN_SP(48, 4)
-    YN_SP(24, 4)
+    YN_SP(116, 4) YN_SP(116, 8)
+    YN_SP(96, 4) YN_SP(96, 8)
+    YN_SP(48, 4) YN_SP(48, 8)
+    YN_SP(24, 4) YN_SP(24, 8)
 #undef YN_SP
     return false;
 }

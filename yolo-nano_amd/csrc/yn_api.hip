@@ -148,7 +148,7 @@ struct yn_handle {
     bool pw_pipe = true;                           // pw_pipe_kernel among the pointwise candidates (yn_pw_pipe / YN_PW_PIPE=0)
     int chain_pipe = 1;                            // unit_pipe_kernel (the persistent per-unit walk): 0 never, 1 by the size rule, 2 always (yn_chain_pipe / YN_CHAIN_PIPE)
     int stage_fuse = 1;                            // all but the last stride-1 unit of a stage as ONE persistent launch (stage_pipe_kernel): 0 off, 1 from 256 tiles, 2 always (yn_stage_fuse / YN_STAGE_FUSE)
-    int stage_pub_early = 1;                       // its tiles raise their ready flag right behind their stores (1) or under the next tile's depthwise phase (0) (YN_STAGE_PUB)
+    int stage_pub_early = 0;                       // its tiles raise their ready flag right behind their stores (1) or under the next tile's depthwise phase (0, default: 608 x 608 stage 3 144 vs 150 us, 0.5x bs 128 101 vs 105, 416 bs 32 equal) (YN_STAGE_PUB)
     unsigned* stage_sync = nullptr;                // its queue heads / ready flags / exit count: behind the activation arena, zero between launches
     size_t stage_sync_bytes = 0;
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
@@ -675,18 +675,17 @@ int run_unit_chain(yn_handle* h, int stage, int R, float* oA, int B, int H, int 
             fl += 2.0 * M * bf * (9.0 + 2.0 * bf);
             by += 4.0 * (4.0 * M * bf + 2.0 * bf * bf + 10.0 * bf);
         }
-        const int BMt = bf <= 64 ? 64 : 32;
-        sa.nunits = R - 2; sa.M = (int)M; sa.H = H; sa.W = W; sa.tiles = (int)((M + BMt - 1) / BMt);
+        sa.nunits = R - 2; sa.M = (int)M; sa.H = H; sa.W = W;
         sa.inv_w = 1.0f / (float)W; sa.inv_h = 1.0f / (float)H;
         sa.ovf = h->range_flags ? h->range_flags + 1 : nullptr;
         sa.sync = h->stage_sync;
-        ok = ok && (h->stage_fuse == 2 || sa.tiles >= 256) && stage_sync_words(sa.tiles, sa.nunits) * sizeof(unsigned) <= h->stage_sync_bytes;
-        if (ok && launch_stage_pipe(sa, bf, h->stage_pub_early, h->cur, true)) {
+        const int min_tiles = h->stage_fuse == 2 ? 1 : 256;
+        if (ok && launch_stage_pipe(sa, bf, h->stage_pub_early, min_tiles, h->stage_sync_bytes, h->cur, true)) {
             snprintf(nm, sizeof nm, "backbone.stage%d.1-%d.dw+pw2+pw1n", stage, R - 2);
             const std::string sname = nm;
             if (!dbg_skip(h, sname) && !dbg_skip(h, name(1) + ".chain")) {
                 Bracket br(h, sname, fl, by);
-                (void)launch_stage_pipe(sa, bf, h->stage_pub_early, h->cur);
+                (void)launch_stage_pipe(sa, bf, h->stage_pub_early, min_tiles, h->stage_sync_bytes, h->cur);
             }
             staged = R - 2;
         }

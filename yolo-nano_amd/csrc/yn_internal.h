@@ -80,7 +80,7 @@ struct StageUnit {
 constexpr int YN_STAGE_MAX = 7;
 struct StageArgs {
     StageUnit u[YN_STAGE_MAX];
-    int nunits, M, H, W, tiles;
+    int nunits, M, H, W, tiles;                 // tiles: set by launch_stage_pipe (the form's tile height)
     float inv_w, inv_h;
     unsigned* ovf;                              // split-f16 range guard flag or null
     unsigned* sync;                             // stage_sync_words() words, zero between launches (the kernel leaves them zero)
@@ -92,7 +92,7 @@ constexpr int STAGE_EXIT = 8 * STAGE_HEAD_STRIDE;
 constexpr int STAGE_TIMEOUT = STAGE_EXIT + 1;
 constexpr int STAGE_FLAGS = 1024;
 size_t stage_sync_words(int tiles, int nunits);
-bool launch_stage_pipe(const StageArgs& a, int bf, int pub_early, hipStream_t s, bool dry = false);   // false = no form for this shape, nothing launched
+bool launch_stage_pipe(StageArgs a, int bf, int pub_early, int min_tiles, size_t sync_bytes, hipStream_t s, bool dry = false);   // false = no form for this shape / too few tiles, nothing launched
 bool launch_unit_chain(const ChainArgs& a, hipStream_t s);
 bool launch_unit_pipe(const ChainArgs& a, hipStream_t s, bool dry = false);   // kernels_pipe.hip: the persistent tile walk; false = not applicable, nothing launched
 
