@@ -130,10 +130,17 @@ def test_driver_default_command_prints_one_small_parseable_line():
     det = json.load(open(os.path.join(ROOT, d["detail_file"])))
     for k in ("kernels", "extras", "latency_bs1", "pipeline", "nms", "single_stream", "roofline_detail"):
         assert k in det, k
-    for v in det["extras"].values():
+    # round 6: the HEADLINE is the median of three 20-step regions too (all three in the summary), and the regions agree: the headline's within
+    # 15 % of each other, every extra's median within 15 % of its best region (one hiccup - the driver's round-5 run had a 3.4x one in an
+    # extra's first region - is absorbed by the median and tolerated here; a reported number no second region reproduces is not)
+    hreg = sorted(sm["timed_regions_images_per_s"])
+    assert len(hreg) == 3 and d["value"] == hreg[1] and hreg[0] >= 0.85 * hreg[2], hreg
+    assert "median of three" in d["config"]["ms_per_step_is"]
+    for name, v in det["extras"].items():
         if "timed_regions_images_per_s" in v:                  # every extra reports the MEDIAN of its timed regions, not the best
             reg = sorted(v["timed_regions_images_per_s"])
             assert len(reg) == 3 and v["images_per_s"] == reg[1]
+            assert reg[1] >= 0.85 * reg[2], (name, reg)
     assert "bench_detail " in r.stderr                         # and the same object went to stderr
 
 
