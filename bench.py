@@ -28,7 +28,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32 MFMA (= f32 vector) peak
 PEAK_SPLIT_TFLOPS = 2500.0 / 3  # split-f16 kernels: three f16 MFMAs (2.5 PF dense) per fp32 product => 833 TFLOP/s of fp32-class work
-PMC_LAYERS_FILES = ("r05_pmc_layers.json", "r05_pmc_layers_608_bs32.json", "r05_pmc_layers_05x_bs128.json")
+PMC_LAYERS_FILES = ("r06_pmc_layers.json", "r06_pmc_layers_608_bs32.json", "r06_pmc_layers_05x_bs128.json")
 
 
 def source_hash():
@@ -298,7 +298,7 @@ def _train_bench(args, rank, world, dev, dist, dtype="f32", brief=False):
     floor_ms = 3.0 * act_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
     line["roofline"] = {"bound": "hbm", "alg_bytes_per_step": int(3 * act_bytes), "hbm_floor_ms": round(floor_ms, 4), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "achieved": round(3.0 * act_bytes / (elapsed / args.steps) / 1e9, 1), "frac": round(floor_ms / (elapsed / args.steps * 1e3), 4),
-                        "traffic": None, "kernel": "whole step (per-kernel table: profiles/r05_kernel_stats_train_608_bs32_%s.csv)" % dtype}
+                        "traffic": None, "kernel": "whole step (per-kernel table: profiles/r06_kernel_stats_train_608_bs32_%s.csv)" % dtype}
     h.close()
     if brief:
         out = {k: line[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps", "losses_last_step_rank0", "finite", "roofline")}

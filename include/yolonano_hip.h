@@ -116,6 +116,14 @@ int  yn_tail_fuse(yn_handle* h, int enable);
  * one of their KEPT boxes suppresses before the dense pairwise phase (exact: a removed box suppresses nothing).  mode 0 = off, 1 (default) =
  * for batches of >= 4 images, 2 = always.  Same kept sets either way.  Env: YN_NMS_PREFILTER=0/1/2. */
 int  yn_nms_prefilter(yn_handle* h, int mode);
+/* Large class segments (> 1 024 boxes behind the prefilter) whose boxes are spread out get their suppression words from a sweep over bins of
+ * the boxes' left edges - only pairs whose x-extents intersect are evaluated, with the same exact predicate (models/yolo_nano.py:159-188: `ovr <=
+ * thresh` keeps) - instead of the dense 64 x 64 tiles; the kernel decides per segment from a pair-count estimate.  1 (default) / 0: every segment
+ * dense.  Kept sets are identical either way.  Env: YN_NMS_SWEEP=0/1. */
+int  yn_nms_sweep(yn_handle* h, int enable);
+/* Testing aid: how many (image, class) segments of the LAST yn_infer / yn_postprocess call (B images, C classes) the sweep handled
+ * (synchronises the handle's stream); -1 on a failed copy. */
+int  yn_nms_sweep_segments(yn_handle* h, int B, int C);
 /* Per-layer tile autotuning of the pointwise-conv GEMM (default on): the first eager execution of a layer
  * shape times every instantiated tile configuration of the layer's family (split-f16 by default, f32-MFMA under yn_exact_f32) on
  * the handle's stream and caches the fastest.  All configurations of a family produce bit-identical results; disabling falls back

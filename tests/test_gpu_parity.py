@@ -960,6 +960,66 @@ def test_postprocess_very_large_classes(hvoc, prefilter):
         hvoc.nms_prefilter(1)
 
 
+@pytest.mark.parametrize("thresh", [0.5, 0.3])
+def test_nms_sweep_spread_out_large_segments_bit_exact(hvoc, thresh):
+    """Round 6: nms_sweep_kernel - the suppression words of a large, spread-out class from a sweep over bins of the boxes' left edges (only pairs
+    whose x-extents intersect are evaluated, with the dense path's exact predicate) instead of the dense 64 x 64 tiles.  Four images (the
+    prefilter - and with it the sweep - runs from four), every kind of segment: 2 500 near-point boxes + exact duplicates (IoU = 1 chains) +
+    zero-area boxes (0/0 = NaN: they remove one another wherever they are - the irregular list), 2 200 thin full-height strips with real
+    overlaps, 1 500 wide boxes (the estimate sends them to matrix_kernel), a class of zero-area boxes only, small classes.  Kept sets against
+    the oracle's postprocess, bit for bit, and identical with the sweep off."""
+    N, C = 8000, 70                                         # (more than 256 (image, class) segments: the chunked sort's large-segment list, as in the benchmark)
+    def image(seed):
+        r = np.random.RandomState(seed)
+        boxes = np.zeros((N, 4), np.float32); cls = np.zeros(N, np.int64)
+        k = 0
+        def put(b, c):
+            nonlocal k
+            boxes[k:k + len(b)] = b; cls[k:k + len(b)] = c; k += len(b)
+        ctr = r.uniform(0.01, 0.99, (2300, 2)); wh = r.uniform(1e-5, 2e-3, (2300, 2))
+        tiny = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        put(tiny, 0); put(tiny[r.randint(0, 2300, 180)], 0)                     # duplicates: suppressed by their twin (or suppressing it)
+        z = r.uniform(0.1, 0.9, (20, 2)); put(np.concatenate([z, z + np.array([[0.0, 0.01]])], 1), 0)       # zero width: zero area
+        x0 = r.uniform(0.0, 0.995, 2200); w = r.uniform(5e-4, 4e-3, 2200)
+        put(np.stack([x0, np.zeros(2200), np.minimum(x0 + w, 1.0), np.ones(2200)], 1), 1)
+        ctr = r.uniform(0.2, 0.8, (1500, 2)); wh = r.uniform(0.1, 0.5, (1500, 2))
+        put(np.concatenate([ctr - wh / 2, ctr + wh / 2], 1), 2)
+        z = r.uniform(0.1, 0.9, (1100, 2)); put(np.concatenate([z, z], 1), 3)     # a whole class of points: all zero-area (more than the irregular list holds)
+        ctr = r.uniform(0.05, 0.95, (N - k, 2)); wh = r.uniform(0.02, 0.09, (N - k, 2))
+        rest = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        cls[k:] = r.randint(4, C, N - k); boxes[k:] = rest
+        boxes = np.clip(boxes, 0, 1).astype(np.float32)
+        conf = np.zeros((N, C), np.float32)
+        conf[np.arange(N), cls] = r.permutation(N).astype(np.float32) / N * 0.98 + 0.01        # distinct scores (no ties inside a class)
+        perm = r.permutation(N)
+        return boxes[perm], conf[perm]
+    imgs = [image(100 + i) for i in range(4)]
+    bx = dev(np.stack([b for b, _ in imgs])); cf = dev(np.stack([c for _, c in imgs]))
+    hvoc.set_thresholds(0.001, thresh)
+    try:
+        outs = {}
+        for sweep in (True, False):
+            hvoc.nms_sweep(sweep)
+            out = hvoc.postprocess(bx, cf)
+            outs[sweep] = [t.clone() for t in out]
+        counts = outs[True][4].cpu().tolist()
+        assert counts == outs[False][4].cpu().tolist()
+        for bi, (bb, cc) in enumerate(imgs):
+            k = counts[bi]
+            for t_on, t_off in zip(outs[True][:4], outs[False][:4]):
+                assert torch.equal(t_on[bi, :k], t_off[bi, :k]), bi
+            rb, rs_, rc = orc.postprocess(bb, cc, 0.001, thresh)
+            assert k == len(rs_), (bi, k, len(rs_))
+            assert np.array_equal(outs[True][0][bi, :k].cpu().numpy(), rb) and np.array_equal(outs[True][1][bi, :k].cpu().numpy(), rs_)
+            assert np.array_equal(outs[True][2][bi, :k].cpu().numpy().astype(np.int64), rc)
+        hvoc.nms_sweep(True)
+        hvoc.postprocess(bx, cf)
+        assert hvoc.nms_sweep_segments(4, C) == 8                   # per image: the near-point class and the strips; the wide class and the all-zero-area class stay dense
+    finally:
+        hvoc.set_thresholds(0.001, 0.5)
+        hvoc.nms_sweep(True)
+
+
 def test_postprocess_large_classes_many_segments(hvoc):
     """The same class sizes in a batch of MORE than 256 (image, class) segments - the regime of the benchmark: there the segments above
     1 024 boxes are sorted as 1 024-box chunks by the small segments' workgroups (sort_chunk_kernel) and placed by sort_merge_kernel

@@ -60,6 +60,8 @@ SIGNATURES = {
     "yn_down_fuse": (_i32, [_vp, _i32]),
     "yn_tail_fuse": (_i32, [_vp, _i32]),
     "yn_nms_prefilter": (_i32, [_vp, _i32]),
+    "yn_nms_sweep": (_i32, [_vp, _i32]),
+    "yn_nms_sweep_segments": (_i32, [_vp, _i32, _i32]),
     "yn_load_param": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_load_param_dev": (_i32, [_vp, ctypes.c_char_p, _vp, _i64p, _i32]),
     "yn_fold_bn": (_i32, [_vp]),
@@ -306,6 +308,14 @@ class Handle:
     def nms_prefilter(self, mode=1):
         """First-chunk prefilter of the per-class NMS: 0 off, 1 for batches of >= 4 images (default), 2 always; same kept sets."""
         self._ck(self.lib.yn_nms_prefilter(self.h, int(mode)), "yn_nms_prefilter")
+
+    def nms_sweep(self, on=True):
+        """Spread-out large class segments on nms_sweep_kernel (x-extent broad phase, exact predicate) instead of the dense tiles (default on)."""
+        self._ck(self.lib.yn_nms_sweep(self.h, int(bool(on))), "yn_nms_sweep")
+
+    def nms_sweep_segments(self, B, C):
+        """Testing aid: segments of the last NMS call (B images, C classes) that nms_sweep_kernel handled."""
+        return int(self.lib.yn_nms_sweep_segments(self.h, int(B), int(C)))
 
     def down_fuse(self, on=True):
         """Main branch of the stride-2 unit of stage 2 as one kernel (default on; bit-identical outputs either way)."""

@@ -1346,7 +1346,9 @@ __device__ __forceinline__ void matrix_tile(const float4* __restrict__ sb, int n
 template <bool DIOU>
 __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
                                                       const int32_t* __restrict__ seg_off, const int32_t* __restrict__ tile_off,
-                                                      int N, int C, float thresh, u64* __restrict__ M, size_t m_stride)
+                                                      int N, int C, float thresh, u64* __restrict__ M, size_t m_stride,
+                                                      const int32_t* __restrict__ work_off /* [B][C+1]: tile_off without the segments nms_sweep_kernel takes, or null (= tile_off) */,
+                                                      const int32_t* __restrict__ seg_sparse, const int32_t* __restrict__ large_list, int large_cap)
 {
     __shared__ float4 cbox_all[4][64];
     __shared__ float carea_all[4][64];
@@ -1354,13 +1356,26 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
     float4* cbox = cbox_all[wave];
     float* carea = carea_all[wave];
     const int b = blockIdx.y;
-    const int32_t* toff = tile_off + (size_t)b * (C + 1);
+    const int32_t* soff = tile_off + (size_t)b * (C + 1);                 // storage: where a segment's tiles live
+    const int32_t* toff = (work_off ? work_off : tile_off) + (size_t)b * (C + 1);   // work: the tiles this kernel evaluates (a marked segment has none)
+    const int waves = (int)gridDim.x * 4, wid = (int)blockIdx.x * 4 + wave;
+    // the marked segments' tiles: zeros, spread over the image's wavefronts (nms_sweep_kernel ORs its few hits into them afterwards)
+    if (seg_sparse && large_list) {
+        const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+        const int nl = ll[0];
+        for (int k = 0; k < nl; ++k) {
+            const int c = ll[1 + k];
+            if (!seg_sparse[(size_t)b * C + c]) continue;
+            u64* Ms = M + (size_t)b * m_stride + (size_t)soff[c] * 64;
+            const int nt = soff[c + 1] - soff[c];
+            for (int t = wid; t < nt; t += waves) Ms[(size_t)t * 64 + (threadIdx.x & 63)] = 0ull;
+        }
+    }
     const int total = toff[C];
     // A wavefront walks a CONTIGUOUS range of the image's tiles (round 5; it took tiles 4g + w, + 4G, ...): locating a tile - a binary search over
     // the classes' tile offsets, the (row chunk, column chunk) of the triangle by subtraction, the segment's count and offset: a dozen dependent
     // scalar loads, ~2.5 k cycles beside the tile's ~5 k - is paid once per range; the next tile is one step along the row (or the start of
     // the next row / segment).  Same tiles, same words.
-    const int waves = (int)gridDim.x * 4, wid = (int)blockIdx.x * 4 + wave;
     const int per = (total + waves - 1) / waves;
     int t = wid * per;
     const int t_end = min(total, t + per);
@@ -1368,6 +1383,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
     int lo = 0, hi = C;                                     // largest c with toff[c] <= t
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= t) lo = mid; else hi = mid; }
     int c = lo;
+    while (toff[c + 1] <= t) ++c;                           // (segments without work share their successor's offset: the one with tiles is the last of a run of equal offsets)
     int n = seg_count[(size_t)b * C + c];
     int T = (n + 63) >> 6;
     int rem = t - toff[c], ri = 0;
@@ -1375,7 +1391,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(const float4* __restrict__ 
     int ci = ri + rem;
     for (;;) {
         const float4* sb = sbox + (size_t)b * N + seg_off[(size_t)b * C + c];
-        u64* Ms = M + (size_t)b * m_stride + (size_t)toff[c] * 64;
+        u64* Ms = M + (size_t)b * m_stride + (size_t)soff[c] * 64;
         if (nms_colmajor(n)) matrix_tile<DIOU, true>(sb, n, T, ri, ci, thresh, Ms, cbox, carea);
         else matrix_tile<DIOU>(sb, n, T, ri, ci, thresh, Ms, cbox, carea);
         if (++t >= t_end) break;
@@ -1821,7 +1837,7 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
                                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, float thresh, int32_t* __restrict__ keep,
                                                              float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2,
-                                                             const int32_t* __restrict__ seg_order)
+                                                             const int32_t* __restrict__ seg_order, int32_t* __restrict__ seg_sparse)
 {
     __shared__ PrefilterLds L;
     // grid (B, C): workgroups start in id order, x fastest - every image's LARGEST segment first (seg_order), then the second largest ...:
@@ -1829,6 +1845,7 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
     const int b = blockIdx.x;
     const int c = seg_order ? seg_order[(size_t)b * C + blockIdx.y] : (int)blockIdx.y;
     const int n = seg_count[(size_t)b * C + c];
+    if (seg_sparse && threadIdx.x == 0) seg_sparse[(size_t)b * C + c] = 0;       // (nms_sweep_kernel's decide phase marks the segments it takes)
     if (n == 0) { if (threadIdx.x == 0) seg_count2[(size_t)b * C + c] = 0; return; }
     const int off = seg_off[(size_t)b * C + c];
     const float4* sb = sbox + (size_t)b * N + off;
@@ -1909,18 +1926,196 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
     }
 }
 
-// tile offsets of the prefiltered segments (one thread per image: C is small)
-__global__ void nms_tile_off_kernel(const int32_t* __restrict__ seg_count2, int C, int32_t* __restrict__ tile_off2)
+// ---- sweep: the suppression words of a LARGE segment whose boxes are spread out, without the dense tiles ----------------------------------------
+// The bit matrix costs n^2 / 2 pair evaluations whatever the boxes look like.  Two boxes whose x-extents do not intersect cannot suppress one
+// another (w = max(1e-28, x-overlap) = 1e-28: inter <= 1e-8 of either area, far below thr * union - shown below for REGULAR boxes), and on the
+// benchmark's largest classes almost no pair's do: 2 194 near-point boxes (all kept: 2.4 M pairs, none overlapping), 2 460 full-height strips
+// 0.002 wide (3.0 M pairs, ~12 k with intersecting x-extents) - together 1 134 of an image's 1 335 tiles at 416 x 416, 5 500 of 6 000 at 608 x 608.
+// A classic broad phase: count-sort the boxes by the bin of their left edge (1 024 bins over the segment's x-range), and for every box visit only
+// the boxes whose left edge lies in the bins its own extent covers - every pair with intersecting x-extents is found from the side of its
+// left-most box (the bin map is monotone).  Each found pair gets the EXACT predicate of the dense path (`suppressed`, symmetric in its two boxes),
+// and a hit sets its bit in the (zeroed) column-major tiles with an atomic OR - resolve reads the same words as after matrix_kernel.
+//   REGULAR box: finite coordinates, width > 1e-20, area >= 1e-20.  For a pair with one regular box i and disjoint x-extents: w = 1e-28,
+//   h = max(1e-28, dh) with dh <= h_i = a_i / w_i <= 1e20 a_i, so inter <= 1e-8 a_i; un = (a_i + a_j) - inter >= 0.99999999 a_i > 0 (a_j >= 0 or the
+//   box is irregular); p = thr * un >= 1e-6 * 0.99 * 1e-20 > 1e-30 and inter < 0.99999 p (thr >= 1e-6, launch condition): suppressed() returns false
+//   through its first early-out, exactly as it would in a dense tile.  IRREGULAR boxes (zero / negative / NaN extents: two zero-area boxes give
+//   0/0 = NaN -> removed, wherever they are) are tested against every box of the segment.
+// The kernel first ESTIMATES the pairs it would visit (bin counts); a segment over a quarter of n^2 / 2, with more than 64 irregular boxes or
+// beyond the LDS copy (6 144 boxes) stays with matrix_kernel (seg_sparse = 0).  One 1 024-thread workgroup per listed segment.
+#define YN_SWEEP_BINS 1024
+#define YN_SWEEP_MAXN 6144                                 // boxes (16 B) + the bin-sorted index (4 B) in LDS: 120 KB
+#define YN_SWEEP_IRR 64
+#define YN_SWEEP_SPLIT 2                                   // workgroups per segment in the pairs phase (each bins the segment itself, then takes every second box): 1 / 2 / 4 / 8 / 16
+                                                           // measured 55 / 40 / 43 / 49 / 57 us at 416 x 416 bs 32 (every workgroup repeats the 13 k-cycle binning; a launch of these 1 024-thread,
+                                                           // 60-120 KB workgroups costs ~15 us whatever it does)
+__device__ __forceinline__ bool sweep_regular(const float4 b)
+{
+    const float w = b.z - b.x, a = w * (b.w - b.y);
+    return (b.x - b.x == 0.0f) && (b.y - b.y == 0.0f) && (b.z - b.z == 0.0f) && (b.w - b.w == 0.0f) && w > 1e-20f && a >= 1e-20f && a < 3.0e38f;
+}
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
+                                                         const int32_t* __restrict__ tile_off, int N, int C, float thresh, u64* __restrict__ M, size_t m_stride,
+                                                         const int32_t* __restrict__ large_list, int large_cap, int32_t* __restrict__ seg_sparse, int phase, int maxn)
+{
+    // phase 0 (in front of nms_tile_off_kernel / matrix_kernel): DECIDE - bins + visit count -> seg_sparse (matrix_kernel then leaves the segment's
+    // tiles out of its work list and only zeroes them, chip-wide: one workgroup zeroing its own 300 KB took 100-140 k cycles, most of this kernel).
+    // phase 1 (behind matrix_kernel): the PAIRS of the marked segments - bins again (~10 k cycles), exact tests, atomic ORs into the zeroed tiles.
+    extern __shared__ __attribute__((aligned(16))) float4 sw_box[];     // [n] the segment's boxes (score order), then [n] ints: box indices grouped by the bin of their left edge
+    __shared__ int start[YN_SWEEP_BINS + 2];
+    __shared__ int irr[YN_SWEEP_IRR];
+    __shared__ unsigned xlo_u, xhi_u;
+    __shared__ int n_irr;
+    __shared__ unsigned long long work;
+    const int b = blockIdx.y;
+    const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+    if ((int)blockIdx.x >= ll[0]) return;
+    const int c = ll[1 + blockIdx.x];
+    const int n = seg_count[(size_t)b * C + c];
+    if (!nms_colmajor(n) || n > maxn) return;                           // (seg_sparse stays 0: matrix_kernel's)
+    if (phase == 1 && !seg_sparse[(size_t)b * C + c]) return;
+    const float4* sb = sbox + (size_t)b * N + seg_off[(size_t)b * C + c];
+    int* sw_order = reinterpret_cast<int*>(sw_box + n);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < YN_SWEEP_BINS + 2; i += 1024) start[i] = 0;
+    if (tid == 0) { xlo_u = 0xffffffffu; xhi_u = 0u; n_irr = 0; work = 0ull; }
+    __syncthreads();
+    // the boxes into LDS (every later pass and every pair test reads them there); the x-range of the regular ones (ordered-uint min / max), the irregular ones listed
+    {
+        unsigned mn = 0xffffffffu, mx = 0u;                              // (per thread, then per wavefront: 1 024 atomics on one LDS word serialise - 125 us in the first form)
+        for (int i = tid; i < n; i += 1024) {
+            const float4 bx = sb[i];
+            sw_box[i] = bx;
+            if (sweep_regular(bx)) { mn = min(mn, order_bits(bx.x)); mx = max(mx, order_bits(bx.z)); }
+            else { const int k = atomicAdd(&n_irr, 1); if (k < YN_SWEEP_IRR) irr[k] = i; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, o)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
+        if (lane == 0) { atomicMin(&xlo_u, mn); atomicMax(&xhi_u, mx); }
+    }
+    __syncthreads();
+    const int nirr = n_irr;
+    if (nirr > YN_SWEEP_IRR) return;
+    const unsigned lo_u = xlo_u, hi_u = xhi_u;
+    const float xlo = __uint_as_float((lo_u & 0x80000000u) ? (lo_u & 0x7fffffffu) : ~lo_u);
+    const float xhi = __uint_as_float((hi_u & 0x80000000u) ? (hi_u & 0x7fffffffu) : ~hi_u);
+    const float scale = (xhi > xlo) ? (float)YN_SWEEP_BINS / (xhi - xlo) : 0.0f;
+    auto bin_of = [&](float x) {                                         // monotone in x (one rounding per step, each monotone), clamped
+        const float f = (x - xlo) * scale;
+        int q = (int)f;
+        q = f >= (float)YN_SWEEP_BINS ? YN_SWEEP_BINS - 1 : q;
+        return q < 0 ? 0 : q;
+    };
+    for (int i = tid; i < n; i += 1024) {
+        const float4 bx = sw_box[i];
+        if (sweep_regular(bx)) atomicAdd(&start[bin_of(bx.x) + 2], 1);  // counts, two slots up
+    }
+    __syncthreads();
+    if (wave == 0) {                                                     // exclusive prefix over the bins (16 per lane + a wave scan)
+        int mine = 0;
+        for (int q = 0; q < YN_SWEEP_BINS / 64; ++q) mine += start[2 + lane * (YN_SWEEP_BINS / 64) + q];
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int run = incl - mine;
+        for (int q = 0; q < YN_SWEEP_BINS / 64; ++q) { const int k = 2 + lane * (YN_SWEEP_BINS / 64) + q; const int cnt = start[k]; start[k] = run; run += cnt; }
+    }
+    __syncthreads();
+    // start[q + 2] = first index of bin q; the scatter bumps it to the bin's end: afterwards first(q) = start[q + 1] (start[1] = 0), end(q) = start[q + 2]
+    for (int i = tid; i < n; i += 1024) {
+        const float4 bx = sw_box[i];
+        if (sweep_regular(bx)) sw_order[atomicAdd(&start[bin_of(bx.x) + 2], 1)] = i;
+    }
+    __syncthreads();
+    {   // the visit count of the sweep
+        unsigned long long w = 0;
+        for (int i = tid; i < n; i += 1024) {
+            const float4 bx = sw_box[i];
+            if (sweep_regular(bx)) w += (unsigned long long)(start[bin_of(bx.z) + 2] - start[bin_of(bx.x) + 1]);
+        }
+        w += (unsigned long long)(tid < nirr ? n : 0);
+        unsigned lo = (unsigned)(w & 0xffffffffull), hi = (unsigned)(w >> 32);      // (a thread's share is far below 2^32: the halves add without carries across 64 lanes... summed as 64-bit below)
+        unsigned long long ws = w;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)(ws & 0xffffffffull), o), h2 = (unsigned)__shfl_xor((int)(unsigned)(ws >> 32), o);
+            ws += ((unsigned long long)h2 << 32) | l2;
+        }
+        (void)lo; (void)hi;
+        if (lane == 0) atomicAdd(&work, ws);
+    }
+    __syncthreads();
+    if (phase == 0) {
+        if (tid == 0 && work <= (unsigned long long)n * (unsigned long long)(n - 1) / 8ull) seg_sparse[(size_t)b * C + c] = 1;     // else: not spread out enough - the dense tiles
+        return;
+    }
+    u64* Ms = M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64;      // (zeroed by matrix_kernel)
+    // the pair test: matrix_kernel's division-free decision first (tile_word_boxes: inter against thr * union with a 1e-5 guard band - ~25 instructions;
+    // `suppressed` inlined whole is ~100, and this loop is VALU-bound: 16 wavefronts on four SIMDs), the exact predicate only inside the band / for
+    // union <= 0 / NaN.  A sure decision is implied by the exact arithmetic (rounding is monotonic), so the bits are those of the dense tiles.
+    const float c_hi = thresh * 1.00001f, c_lo = thresh * 0.99999f;
+    auto test = [&](int i, int j, const float4 bi, float ai, const float4 bj) {
+        const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+        const float w = vmax_raw(1e-28f, vmin_raw(bi.z, bj.z) - vmax_raw(bi.x, bj.x));
+        const float h = vmax_raw(1e-28f, vmin_raw(bi.w, bj.w) - vmax_raw(bi.y, bj.y));
+        const float inter = w * h;
+        const float un = (ai + aj) - inter;
+        const float hi = un * c_hi, lo = un * c_lo;
+        bool hit;
+        if (lo > 1e-30f && inter < lo) return;                           // surely kept (almost every visit)
+        if (lo > 1e-30f && inter > hi) hit = true;
+        else hit = suppressed(bi, ai, bj, aj, thresh, 0);
+        if (hit) {
+            const int r = i < j ? i : j, t = i < j ? j : i;
+            atomicOr(Ms + ctile_off(r >> 6, t >> 6) + (r & 63), 1ull << (t & 63));
+        }
+    };
+    // SIXTEEN lanes per box, over the boxes whose left edge lies in the bins its extent covers: from its OWN bin only the later ones (the earlier ones
+    // find this box themselves), from later bins all (their own sweep starts at their bin: it never looks back).  A visit is ~100 instructions
+    // (index, box, the exact test, the tile address of a hit), and a wavefront runs as long as its longest lane: a thread per box (first forms) left
+    // three lanes of four idle - 131 k cycles for 50 k visits.  The segment's boxes are dealt to YN_SWEEP_SPLIT workgroups (blockIdx.z; each has
+    // binned the whole segment itself).
+    const int kz = blockIdx.z, KZ = gridDim.z;
+    const int grp = tid >> 4, gl = tid & 15;
+    for (int i = kz + KZ * grp; i < n; i += 64 * KZ) {                    // (box i belongs to workgroup i % KZ)
+        const float4 bi = sw_box[i];
+        if (!sweep_regular(bi)) continue;
+        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+        const int q0 = bin_of(bi.x), q1 = bin_of(bi.z);
+        const int p0 = start[q0 + 1], pm = start[q0 + 2], p1 = start[q1 + 2];
+        for (int p = p0 + gl; p < p1; p += 16) {
+            const int j = sw_order[p];
+            if (p < pm ? j > i : true) test(i, j, bi, ai, sw_box[j]);
+        }
+    }
+    for (int k = 0; k < nirr; ++k) {                                     // irregular boxes: against everything (each pair once: regular partners, and later irregular ones)
+        const int i = irr[k];
+        const float4 bi = sw_box[i];
+        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+        for (int j = kz + KZ * tid; j < n; j += 1024 * KZ) {
+            if (j == i) continue;
+            const float4 bj = sw_box[j];
+            if (sweep_regular(bj) || j > i) test(i, j, bi, ai, bj);
+        }
+    }
+}
+
+// tile offsets of the prefiltered segments (one thread per image: C is small): tile_off2 = where a segment's tiles are STORED (every segment),
+// work_off = the same prefix over the segments matrix_kernel evaluates (all but the ones nms_sweep_kernel has marked)
+__global__ void nms_tile_off_kernel(const int32_t* __restrict__ seg_count2, int C, int32_t* __restrict__ tile_off2, const int32_t* __restrict__ seg_sparse,
+                                    int32_t* __restrict__ work_off)
 {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
-    int tiles = 0;
+    int tiles = 0, wtiles = 0;
     for (int c = 0; c < C; ++c) {
         tile_off2[(size_t)b * (C + 1) + c] = tiles;
+        if (work_off) work_off[(size_t)b * (C + 1) + c] = wtiles;
         const int T = (seg_count2[(size_t)b * C + c] + 63) >> 6;
         tiles += T * (T + 1) / 2;
+        if (!(seg_sparse && seg_sparse[(size_t)b * C + c])) wtiles += T * (T + 1) / 2;
     }
     tile_off2[(size_t)b * (C + 1) + C] = tiles;
+    if (work_off) work_off[(size_t)b * (C + 1) + C] = wtiles;
 }
 
 // ---- single-class entry (YOLONano.nms): one segment = items 0..n-1 ------------------------------------
@@ -2168,21 +2363,45 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     const int32_t* m_ids = wk.bucket;
     const float4* m_box = sbox;
     const int prefilter_env = wk.prefilter;
+    bool sweep = false;
+    int sweep_maxn = 0, sweep_slots = 0;
     // (small batches: the prefilter is two more launches in a serial chain - bs = 1 latency 0.69 -> 0.72 ms - for chip time nobody else wants)
     if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
         hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
-                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order);
-        hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2);
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order, wk.seg_sparse);
         m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
+        // large segments whose boxes are spread out: their suppression words from a sweep over bins of the left edges instead of the dense tiles
+        // (nms_sweep_kernel): decided here, zeroed by matrix_kernel, filled in behind it
+        sweep = wk.sweep && !few && wk.seg_sparse && wk.work_off && wk.large_list && large_cap > 0 && N > YN_SORT_SMALL && nms_thresh >= 1e-6f && !(skip & 2);
+        // its workgroups carry the segment in LDS (20 bytes per box): 60 KB - two per CU - for maps of up to 16 K candidates (a class above 3 072 boxes stays
+        // dense there), 120 KB beyond (608 x 608: ~5 000-box classes); the first four listed segments of an image only (the list is by size: a fifth class above
+        // 1 024 boxes is rare, and every listed slot is a workgroup with that LDS to schedule whether it has work or not)
+        sweep_maxn = N <= 16384 ? YN_SWEEP_MAXN / 2 : YN_SWEEP_MAXN;
+        sweep_slots = large_cap < 4 ? large_cap : 4;
+        if (sweep) {
+            static unsigned long long attr_sw = 0;
+            if (attr_pending(attr_sw)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SWEEP_MAXN * 20);
+            mark("nms_sweep_kernel");
+            hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
+                               M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, wk.seg_sparse, 0, sweep_maxn);
+        }
+        hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2, (const int32_t*)(sweep ? wk.seg_sparse : nullptr), sweep ? wk.work_off : nullptr);
     }
     int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
     if (G < 32) G = 32;
     if (G > 2048) G = 2048;
     mark(diou ? "matrix_kernel<true>" : "matrix_kernel<false>");
     if (skip & 2) {}
-    else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
-    else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride);
+    else if (diou) hipLaunchKernelGGL(matrix_kernel<true>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride,
+                                      (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, 0);
+    else      hipLaunchKernelGGL(matrix_kernel<false>, dim3(G, B), dim3(256), 0, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh, M, wk.matrix_stride,
+                                 (const int32_t*)(sweep ? wk.work_off : nullptr), (const int32_t*)(sweep ? wk.seg_sparse : nullptr), (const int32_t*)wk.large_list, large_cap);
+    if (sweep) {
+        mark("nms_sweep_kernel");
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, YN_SWEEP_SPLIT), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
+                           M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, wk.seg_sparse, 1, sweep_maxn);
+    }
     mark("resolve_kernel");
     const bool split = N > YN_SORT_SMALL && wk.large_list && large_cap > 0;
     if (!(skip & 4) && (long)B * C <= 256) {

@@ -554,7 +554,10 @@ bool launch_stage_pipe(StageArgs a, int bf, int pub_early, int min_tiles, size_t
     static const int wg_env = getenv("YN_STAGE_G") ? atoi(getenv("YN_STAGE_G")) : 0;
     // 416 x 416 / bs 32, stage 3: 384 / 448 / 512 workgroups all run 96-98 us (fewer stalls against fewer slots); the narrow branches (<= 48
     // channels: 52 KB of LDS, 168 registers) fit three workgroups per CU: 0.5x bs 128 stage 2 149 -> 130 us with 768
-    const int wg4 = wg_env > 0 ? wg_env : (bf <= 48 ? 768 : 512);
+    // Under contention (bench.py's four handles on four streams, same box, 4 x 200-step runs): per-unit launches 47.62 k images/s, this kernel with
+    // 320 / 384 / 448 / 512 workgroups 47.51 / 47.43 / 47.32 / 47.22 k - a workgroup that waits for a flag holds a CU slot another stream's kernel
+    // could use, and the per-unit launches' idle tails are filled by the other streams anyway.  One stream: 384 ... 512 all +0.4 %.  384.
+    const int wg4 = wg_env > 0 ? wg_env : (bf <= 48 ? 768 : 384);
     // two four-wavefront workgroups per CU where their windows fit (80 KB each), else one of eight (twice the rows per tile; 608 x 608 stage 3: W = 38)
 #define YN_SP(BFv, NWv)                                                                                                  \
     if (bf == BFv) {                                                                                                     \

@@ -369,7 +369,7 @@ int ensure_post(yn_handle* h, int B, int N, int C)
     if (need_seg > h->nms_seg_cap) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         void** ptrs[] = {(void**)&h->nms.seg_count, (void**)&h->nms.seg_off, (void**)&h->nms.tile_off, (void**)&h->nms.large_list,
-                         (void**)&h->nms.seg_count2, (void**)&h->nms.tile_off2, (void**)&h->nms.seg_order, (void**)&h->nms.ctr};
+                         (void**)&h->nms.seg_count2, (void**)&h->nms.tile_off2, (void**)&h->nms.seg_order, (void**)&h->nms.ctr, (void**)&h->nms.seg_sparse, (void**)&h->nms.work_off};
         for (void** q : ptrs) if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_off, need_seg * sizeof(int32_t)));
@@ -378,6 +378,8 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_count2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.tile_off2, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.seg_order, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.seg_sparse, need_seg * sizeof(int32_t)));
+        HIPCHK(h, hipMalloc((void**)&h->nms.work_off, need_seg * sizeof(int32_t)));
         HIPCHK(h, hipMalloc((void**)&h->nms.ctr, need_seg * sizeof(int32_t)));          // >= 2 * B ints
         HIPCHK(h, hipMemsetAsync(h->nms.ctr, 0, need_seg * sizeof(int32_t), h->stream));
         h->nms_seg_cap = need_seg;
@@ -1246,6 +1248,7 @@ int yn_create(const yn_config* cfg, yn_handle** out)
     h->cur = h->stream;
     if (const char* e7 = getenv("YN_EXACT_F32")) h->exact_f32 = atoi(e7) != 0;
     h->nms.prefilter = getenv("YN_NMS_PREFILTER") ? atoi(getenv("YN_NMS_PREFILTER")) : 1;
+    h->nms.sweep = getenv("YN_NMS_SWEEP") ? (atoi(getenv("YN_NMS_SWEEP")) != 0) : 1;
     if (const char* e9 = getenv("YN_GROUP")) h->group_launch = atoi(e9) != 0;
     if (const char* e10 = getenv("YN_DOWN_FUSE")) h->down_fuse = atoi(e10) != 0;
     if (const char* e11 = getenv("YN_DWPW_FUSE")) h->dwpw_fuse = atoi(e11) != 0;
@@ -1290,7 +1293,7 @@ void yn_destroy(yn_handle* h)
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
-                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr};
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr, h->nms.seg_sparse, h->nms.work_off};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -1419,6 +1422,23 @@ int yn_nms_prefilter(yn_handle* h, int mode)
     if (mode < 0 || mode > 2) return fail(h, "yn_nms_prefilter: mode %d is not 0, 1 or 2", mode);
     if (mode != h->nms.prefilter) drop_graphs(h);
     h->nms.prefilter = mode;
+    return 0;
+}
+int yn_nms_sweep_segments(yn_handle* h, int B, int C)
+{
+    YN_ENTER(h);
+    if (!h->nms.seg_sparse || B <= 0 || C <= 0 || (size_t)B * C > h->nms_seg_cap) return 0;
+    std::vector<int32_t> v((size_t)B * C);
+    if (hipMemcpyAsync(v.data(), h->nms.seg_sparse, v.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    int k = 0;
+    for (int32_t x : v) k += x == 1;
+    return k;
+}
+int yn_nms_sweep(yn_handle* h, int enable)
+{
+    if (!h) return 1;
+    if ((enable != 0) != (h->nms.sweep != 0)) drop_graphs(h);
+    h->nms.sweep = enable != 0;
     return 0;
 }
 

@@ -206,8 +206,11 @@ struct NmsWork {                                // per-handle scratch, sized for
     int32_t* bucket2; float* sbox2;             // [B][N], [B][N][4]: the candidates that survive the first-chunk prefilter, per segment at seg_off
     int32_t* seg_count2; int32_t* tile_off2;    // [B][C], [B][C+1] of that list
     int32_t* seg_order;                         // [B][C]  the image's class ids by segment size, largest first (bucket_kernel)
+    int32_t* seg_sparse;                        // [B][C]  1 = the segment's suppression words come from nms_sweep_kernel (matrix_kernel only zeroes its tiles)
+    int32_t* work_off;                          // [B][C+1] tile_off2 without those segments: matrix_kernel's work list
     int32_t* ctr;                               // [B][2]  bucket_sort_kernel's position cursor / finished-workgroup count (zero between launches)
     int      prefilter;                         // 0 off, 1 for batches of >= 4 images, 2 always
+    int      sweep;                             // 1: spread-out large segments on nms_sweep_kernel (behind the prefilter), 0: every segment on matrix_kernel
     int      large_cap;
     const unsigned* ovf;                        // yn_infer: the split-f16 range flag of the network kernels that produced the candidates, or null.
                                                 // Set => compact_kernel reports count[b] = -1 - kept (the results are invalid: yn_range_status)
