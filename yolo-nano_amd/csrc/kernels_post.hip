@@ -1251,7 +1251,8 @@ __device__ __forceinline__ float vmax_raw(float a, float b) { float r; asm("v_ma
 // word of sorted item ri*64+lane: bit t = "it suppresses sorted item ci*64+t" (columns after itself only on the diagonal tile)
 // core: this lane's row box bx (valid when jr < n) against the chunk's column boxes, this lane's one being cb
 template <bool DIOU>
-__device__ __forceinline__ u64 tile_word_boxes(const float4 bx, const float4 cb, int n, int ri, int ci, float thresh, float4* cbox, float* carea)
+__device__ __forceinline__ u64 tile_word_boxes(const float4 bx, const float4 cb, int n, int ri, int ci, float thresh, float4* cbox, float* carea,
+                                               int t_begin = 0, int t_end = 64)      // only columns [t_begin, t_end) of the chunk (multiples of 8)
 {
     const int lane = threadIdx.x & 63;
     const float ca = (cb.z - cb.x) * (cb.w - cb.y);
@@ -1267,6 +1268,8 @@ __device__ __forceinline__ u64 tile_word_boxes(const float4 bx, const float4 cb,
         const int t1 = min(64, n - ci * 64);
         u64 valid = (t1 == 64 ? ~0ull : ((1ull << t1) - 1ull));
         valid &= (t0 >= 64) ? 0ull : ~((1ull << t0) - 1ull);
+        if (t_begin > 0 || t_end < 64) valid &= (t_end >= 64 ? ~0ull : ((1ull << t_end) - 1ull)) & ~((1ull << t_begin) - 1ull);
+        const int t_stop = t1 < t_end ? t1 : t_end;
         u64 slow = valid;
         if (!DIOU) {
             // Dense, branch-free pass over the chunk's columns (uniform loop, broadcast LDS reads, 8 columns per step, only the
@@ -1278,7 +1281,7 @@ __device__ __forceinline__ u64 tile_word_boxes(const float4 bx, const float4 cb,
             // (thr > 0) also says union > 0.  thr <= 0: nothing is decided here, every group goes to the exact path.
             const u64 tmask = thresh > 0.0f ? ~0ull : 0ull;
             const float c_hi = thresh * 1.00001f, c_lo = thresh * 0.99999f;
-            for (int t8 = 0; t8 < t1; t8 += 8) {
+            for (int t8 = t_begin; t8 < t_stop; t8 += 8) {
                 unsigned s8 = 0;                            // bit 7-u = column t8+u surely suppressed (built by shift-in, reversed below)
                 unsigned nd = 0;                            // decided pairs of this lane in the group of 8
 #pragma unroll
@@ -1831,32 +1834,61 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
 // the survivors into a second candidate list.  matrix / resolve run on that list (chunk 0 is finished: its kept boxes are flagged here).
 // Segments of <= 64 boxes never reach the dense phase.  Exact: the kept sets equal the plain pipeline's (parity suite).
 #define YN_PRE_W 8                                         // wavefronts per prefilter workgroup
-struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int part[64 * YN_PRE_W]; float4 cbox[YN_PRE_W][64]; float carea[YN_PRE_W][64]; };
+// A LARGE segment (more than 1 024 boxes) is one workgroup's work for 40-60 us - 38-85 band tiles on half a CU, ~5 us per round of eight, while
+// the other 2 500 workgroups of the launch are done after 25 us (measured with s_memrealtime stamps, round 6).  Its band is SLICED over YN_PRE_Z
+// workgroups instead: each resolves chunk 0 for itself (the same tile, the same serial walk: identical kept masks), takes every YN_PRE_Z-th
+// round of band tiles and leaves its survivor words in global memory (agent-scope stores, fence, one ticket per workgroup); the workgroup that
+// draws the last ticket reads all words back and compacts.  No workgroup waits for another.  Sliced: the first YN_PRE_RANKS segments of an
+// image in seg_order (by size - the only ones that can be large in practice; a fifth one stays on one workgroup), grid.y = C + RANKS * (Z - 1)
+// with the slices first.
+#define YN_PRE_Z 8
+#define YN_PRE_RANKS 4
+#define YN_PRE_TICKETS 4096                                // pre_sync: [YN_PRE_TICKETS] ticket counters (image, rank) - a fixed region, zero between launches whatever B and N were -
+__host__ __device__ inline size_t pre_sync_words(int N) { return (size_t)(N / 64 + 2); }             // then per (image, rank) a survivor word per chunk
+struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int last; __attribute__((aligned(8))) unsigned char dpart[64][YN_PRE_W]; int part[64 * YN_PRE_W]; float4 cbox[YN_PRE_W][64]; float carea[YN_PRE_W][64]; };
 
-__global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
+__global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
                                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, float thresh, int32_t* __restrict__ keep,
                                                              float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2,
-                                                             const int32_t* __restrict__ seg_order, int32_t* __restrict__ seg_sparse)
+                                                             const int32_t* __restrict__ seg_order, int32_t* __restrict__ seg_sparse,
+                                                             u64* __restrict__ pre_sync, int sliced_ranks)
 {
     __shared__ PrefilterLds L;
-    // grid (B, C): workgroups start in id order, x fastest - every image's LARGEST segment first (seg_order), then the second largest ...:
+    // grid (B, C + ...): workgroups start in id order, x fastest - every image's LARGEST segment first (seg_order), then the second largest ...:
     // the few 2 000-box segments of a batch, whose workgroups run 10x longer than the rest, no longer start behind 2 000 short ones
     const int b = blockIdx.x;
-    const int c = seg_order ? seg_order[(size_t)b * C + blockIdx.y] : (int)blockIdx.y;
+    int rank = blockIdx.y, z = 0;
+    if ((int)blockIdx.y < sliced_ranks * YN_PRE_Z) { rank = blockIdx.y / YN_PRE_Z; z = blockIdx.y % YN_PRE_Z; }
+    else rank = blockIdx.y - sliced_ranks * (YN_PRE_Z - 1);
+    const int c = seg_order ? seg_order[(size_t)b * C + rank] : rank;
     const int n = seg_count[(size_t)b * C + c];
-    if (seg_sparse && threadIdx.x == 0) seg_sparse[(size_t)b * C + c] = 0;       // (nms_sweep_kernel's decide phase marks the segments it takes)
+    const int T = (n + 63) >> 6;
+    const bool sliced = rank < sliced_ranks && T - 1 > YN_PRE_W;               // more than one round of band tiles: a round per slice
+    const int ZS = sliced ? min(YN_PRE_Z, (T - 1 + YN_PRE_W - 1) / YN_PRE_W) : 1;
+    if (z >= ZS) return;
+    if (seg_sparse && threadIdx.x == 0 && z == 0) seg_sparse[(size_t)b * C + c] = 0;       // (nms_sweep_kernel's decide phase marks the segments it takes)
     if (n == 0) { if (threadIdx.x == 0) seg_count2[(size_t)b * C + c] = 0; return; }
     const int off = seg_off[(size_t)b * C + c];
     const float4* sb = sbox + (size_t)b * N + off;
     const int32_t* ids = bucket + (size_t)b * N + off;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int T = (n + 63) >> 6;
     float4* cbox = L.cbox[wave];
     float* carea = L.carea[wave];
-    if (wave == 0) {                                        // chunk 0 among itself: the reference's loop restricted to 64 boxes
-        const u64 diag = tile_word<false>(sb, n, 0, 0, thresh, cbox, carea);
+    // chunk 0 among itself.  Its 64 x 64 tile eight columns per wavefront, the row words put together through LDS (one wavefront on the whole tile:
+    // ~4.5 us, the life of the ~2 000 one-chunk workgroups of a batch and the head of every large segment's critical path); then the reference's
+    // loop restricted to 64 boxes, wave 0
+    float4 bx0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n) bx0 = sb[lane];
+    {
+        u64 part = 0;
+        if (wave * 8 < n) part = tile_word_boxes<false>(bx0, bx0, n, 0, 0, thresh, cbox, carea, wave * 8, wave * 8 + 8);
+        L.dpart[lane][wave] = (unsigned char)(part >> (8 * wave));
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const u64 diag = *reinterpret_cast<const u64*>(L.dpart[lane]);
         const int cnt = min(64, n);
         u64 alive = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
         u64 work = __ballot(((alive >> lane) & 1ull) && (diag & alive));
@@ -1868,7 +1900,7 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
             alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
             work &= alive & ~(1ull << i);
         }
-        if ((alive >> lane) & 1ull) keep[(size_t)b * N + ids[lane]] = 1;
+        if (((alive >> lane) & 1ull) && z == 0) keep[(size_t)b * N + ids[lane]] = 1;
         if (lane == 0) L.keepm = alive;
     }
     if (T == 1) {                                           // nothing beyond chunk 0: no band, no scan, no survivors (most segments of a batch)
@@ -1879,12 +1911,15 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
     const u64 keepm = L.keepm;
     {   // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes.  The row boxes are loaded once, the next tile's column
         // boxes are requested before the current tile is evaluated.
-        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f), cb = bx, cbn = bx;
-        if (lane < n) bx = sb[lane];
-        int ci = 1 + wave;
+        const float4 bx = bx0;
+        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cbn = cb;
+        const size_t slot = (size_t)b * YN_PRE_RANKS + (rank < YN_PRE_RANKS ? rank : 0);
+        u64* ticket = pre_sync + slot;
+        u64* gs = pre_sync + YN_PRE_TICKETS + slot * pre_sync_words(N);
+        int ci = 1 + z * YN_PRE_W + wave;
         if (ci < T && ci * 64 + lane < n) cb = sb[ci * 64 + lane];
-        for (; ci < T; ci += YN_PRE_W) {
-            const int cn = ci + YN_PRE_W;
+        for (; ci < T; ci += YN_PRE_W * ZS) {
+            const int cn = ci + YN_PRE_W * ZS;
             cbn = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cn < T && cn * 64 + lane < n) cbn = sb[cn * 64 + lane];
             u64 w = keepm ? tile_word_boxes<false>(bx, cb, n, 0, ci, thresh, cbox, carea) : 0ull;
@@ -1894,8 +1929,24 @@ __global__ __launch_bounds__(64 * YN_PRE_W) void nms_prefilter_kernel(const floa
             for (int o = 32; o >= 1; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
             const int cnt = min(64, n - ci * 64);
             const u64 valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-            if (lane == 0) L.surv[ci] = valid & ~(((u64)hi << 32) | (u64)lo);
+            const u64 sv = valid & ~(((u64)hi << 32) | (u64)lo);
+            if (lane == 0) { if (sliced) __hip_atomic_store(&gs[ci], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else L.surv[ci] = sv; }
             cb = cbn;
+        }
+        if (sliced) {
+            // every slice's words out, then its ticket; the last one in reads them all and goes on alone.  The hand-off of DESIGN 4.3d: write-through
+            // (agent-scope) stores, retired by the storing wavefront before the barrier, a relaxed ticket, agent-scope loads on the other side - no
+            // fence (an agent-scope release here writes the XCD's whole L2 back: 150 us for this launch, measured)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const u64 t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.last = t == (u64)(ZS - 1);
+                if (L.last) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero between launches)
+            }
+            __syncthreads();
+            if (!L.last) return;
+            for (int k = 1 + tid; k < T; k += 64 * YN_PRE_W) L.surv[k] = __hip_atomic_load(&gs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -2281,6 +2332,7 @@ void launch_pack(const float* boxes, const float* scores, const int32_t* cls, co
     hipLaunchKernelGGL(pack_kernel, dim3(B), dim3(256), 0, s, boxes, scores, cls, count, B, N, rec, offsets);
 }
 
+size_t nms_pre_sync_words(int B, int N) { return YN_PRE_TICKETS + (size_t)B * YN_PRE_RANKS * pre_sync_words(N); }
 size_t nms_matrix_words_per_image(int N, int C)
 {
     const size_t Tsum = (size_t)(N + 63) / 64 + C;          // sum_c ceil(n_c/64) <= N/64 + C
@@ -2368,8 +2420,9 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     // (small batches: the prefilter is two more launches in a serial chain - bs = 1 latency 0.69 -> 0.72 ms - for chip time nobody else wants)
     if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
-        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
-                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order, wk.seg_sparse);
+        const int pre_ranks = (seg_order && wk.pre_sync && (size_t)B * YN_PRE_RANKS <= YN_PRE_TICKETS) ? (C < YN_PRE_RANKS ? C : YN_PRE_RANKS) : 0;      // large segments: band sliced over YN_PRE_Z workgroups
+        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C + pre_ranks * (YN_PRE_Z - 1)), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order, wk.seg_sparse, reinterpret_cast<u64*>(wk.pre_sync), pre_ranks);
         m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
         // large segments whose boxes are spread out: their suppression words from a sweep over bins of the left edges instead of the dense tiles
         // (nms_sweep_kernel): decided here, zeroed by matrix_kernel, filled in behind it

@@ -97,6 +97,7 @@ struct yn_handle {
     size_t nms_cap = 0;           // elements B*N currently allocated
     size_t nms_seg_cap = 0;       // B*(C+1)
     size_t nms_m_cap = 0;         // uint64 words of suppression matrix
+    size_t nms_ps_cap = 0;        // uint64 words of the prefilter's slice sync
     float* heads_int[3] = {nullptr, nullptr, nullptr};
     size_t heads_cap = 0;
     float* fwd_only[3] = {nullptr, nullptr, nullptr};     // yn_train_forward: the training executors stop after the forward pass and copy the raw heads here
@@ -390,6 +391,15 @@ int ensure_post(yn_handle* h, int B, int N, int C)
         if (h->nms.matrix) { HIPCHK(h, hipFree(h->nms.matrix)); h->nms.matrix = nullptr; }
         HIPCHK(h, hipMalloc(&h->nms.matrix, need_m * sizeof(unsigned long long)));
         h->nms_m_cap = need_m;
+        drop_graphs(h);
+    }
+    const size_t need_ps = nms_pre_sync_words(B, N);
+    if (need_ps > h->nms_ps_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->nms.pre_sync) { HIPCHK(h, hipFree(h->nms.pre_sync)); h->nms.pre_sync = nullptr; }
+        HIPCHK(h, hipMalloc(&h->nms.pre_sync, need_ps * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemsetAsync(h->nms.pre_sync, 0, need_ps * sizeof(unsigned long long), h->stream));
+        h->nms_ps_cap = need_ps;
         drop_graphs(h);
     }
     h->nms.matrix_stride = m_stride;
@@ -1293,7 +1303,7 @@ void yn_destroy(yn_handle* h)
     }
     void* ptrs[] = {h->arena, h->cand_boxes, h->cand_scores, h->cand_cls, h->nms.bucket, h->nms.keep, h->nms.sbox,
                     h->nms.seg_count, h->nms.seg_off, h->nms.tile_off, h->nms.large_list, h->nms.matrix, h->heads_int[0], h->loss_partial,
-                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr, h->nms.seg_sparse, h->nms.work_off};
+                    h->nms.bucket2, h->nms.sbox2, h->nms.seg_count2, h->nms.tile_off2, h->nms.seg_order, h->nms.ctr, h->nms.seg_sparse, h->nms.work_off, h->nms.pre_sync};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (GraphEntry& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);

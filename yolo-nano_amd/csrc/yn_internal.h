@@ -208,6 +208,7 @@ struct NmsWork {                                // per-handle scratch, sized for
     int32_t* seg_order;                         // [B][C]  the image's class ids by segment size, largest first (bucket_kernel)
     int32_t* seg_sparse;                        // [B][C]  1 = the segment's suppression words come from nms_sweep_kernel (matrix_kernel only zeroes its tiles)
     int32_t* work_off;                          // [B][C+1] tile_off2 without those segments: matrix_kernel's work list
+    void*    pre_sync;                          // [nms_pre_sync_words(B, N)] uint64: nms_prefilter_kernel's sliced large segments - ticket counter (zero between launches) + survivor words
     int32_t* ctr;                               // [B][2]  bucket_sort_kernel's position cursor / finished-workgroup count (zero between launches)
     int      prefilter;                         // 0 off, 1 for batches of >= 4 images, 2 always
     int      sweep;                             // 1: spread-out large segments on nms_sweep_kernel (behind the prefilter), 0: every segment on matrix_kernel
@@ -217,6 +218,7 @@ struct NmsWork {                                // per-handle scratch, sized for
     unsigned* ovf_host;                         // with ovf: one word of pinned host memory (device view) that compact_kernel sets to 1 beside the negative counts, or null
 };
 size_t nms_matrix_words_per_image(int N, int C);
+size_t nms_pre_sync_words(int B, int N);
 int nms_max_segment();                      // largest per-class segment resolve_segment() can hold (its removed-mask lives in LDS)
 // optional per-kernel hook of launch_nms_pipeline: called with the kernel's name right before each launch (profiling brackets)
 struct NmsHook { void (*fn)(void* ctx, const char* kernel); void* ctx; };
