@@ -1996,6 +1996,8 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
 #define YN_SWEEP_BINS 1024
 #define YN_SWEEP_MAXN 6144                                 // boxes (16 B) + the bin-sorted index (4 B) in LDS: 120 KB
 #define YN_SWEEP_IRR 64
+#define YN_SWEEP_WIDE 256                                  // listed wide boxes per workgroup (more: sixteen lanes each, as the narrow ones)
+#define YN_SWEEP_WIDE_VISITS 256                           // a box with more visits than this is wide
 #define YN_SWEEP_SPLIT 2                                   // workgroups per segment in the pairs phase (each bins the segment itself, then takes every second box): 1 / 2 / 4 / 8 / 16
                                                            // measured 55 / 40 / 43 / 49 / 57 us at 416 x 416 bs 32 (every workgroup repeats the 13 k-cycle binning; a launch of these 1 024-thread,
                                                            // 60-120 KB workgroups costs ~15 us whatever it does)
@@ -2014,6 +2016,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
     extern __shared__ __attribute__((aligned(16))) float4 sw_box[];     // [n] the segment's boxes (score order), then [n] ints: box indices grouped by the bin of their left edge
     __shared__ int start[YN_SWEEP_BINS + 2];
     __shared__ int irr[YN_SWEEP_IRR];
+    __shared__ int wide[YN_SWEEP_WIDE];
+    __shared__ int n_wide;
     __shared__ unsigned xlo_u, xhi_u;
     __shared__ int n_irr;
     __shared__ unsigned long long work;
@@ -2028,7 +2032,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
     int* sw_order = reinterpret_cast<int*>(sw_box + n);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < YN_SWEEP_BINS + 2; i += 1024) start[i] = 0;
-    if (tid == 0) { xlo_u = 0xffffffffu; xhi_u = 0u; n_irr = 0; work = 0ull; }
+    if (tid == 0) { xlo_u = 0xffffffffu; xhi_u = 0u; n_irr = 0; n_wide = 0; work = 0ull; }
     __syncthreads();
     // the boxes into LDS (every later pass and every pair test reads them there); the x-range of the regular ones (ordered-uint min / max), the irregular ones listed
     {
@@ -2133,9 +2137,30 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
         const float ai = (bi.z - bi.x) * (bi.w - bi.y);
         const int q0 = bin_of(bi.x), q1 = bin_of(bi.z);
         const int p0 = start[q0 + 1], pm = start[q0 + 2], p1 = start[q1 + 2];
+        if (p1 - p0 > YN_SWEEP_WIDE_VISITS) {                            // a WIDE box: listed for the whole workgroup below (sixteen lanes on 5 000 visits: the kernel's long pole,
+            int k = 0;                                                   // whatever the split - 136 us at 608 x 608)
+            if (gl == 0) k = atomicAdd(&n_wide, 1);
+            k = __shfl(k, 0, 16);
+            if (k < YN_SWEEP_WIDE) { if (gl == 0) wide[k] = i; continue; }
+        }
         for (int p = p0 + gl; p < p1; p += 16) {
             const int j = sw_order[p];
             if (p < pm ? j > i : true) test(i, j, bi, ai, sw_box[j]);
+        }
+    }
+    __syncthreads();
+    {
+        const int nw = n_wide < YN_SWEEP_WIDE ? n_wide : YN_SWEEP_WIDE;
+        for (int k = 0; k < nw; ++k) {
+            const int i = wide[k];
+            const float4 bi = sw_box[i];
+            const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+            const int q0 = bin_of(bi.x), q1 = bin_of(bi.z);
+            const int p0 = start[q0 + 1], pm = start[q0 + 2], p1 = start[q1 + 2];
+            for (int p = p0 + tid; p < p1; p += 1024) {
+                const int j = sw_order[p];
+                if (p < pm ? j > i : true) test(i, j, bi, ai, sw_box[j]);
+            }
         }
     }
     for (int k = 0; k < nirr; ++k) {                                     // irregular boxes: against everything (each pair once: regular partners, and later irregular ones)
@@ -2452,7 +2477,9 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                                  (const int32_t*)(sweep ? wk.work_off : nullptr), (const int32_t*)(sweep ? wk.seg_sparse : nullptr), (const int32_t*)wk.large_list, large_cap);
     if (sweep) {
         mark("nms_sweep_kernel");
-        hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, YN_SWEEP_SPLIT), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
+        static const int split_env = getenv("YN_EXP_SWEEP_SPLIT") ? atoi(getenv("YN_EXP_SWEEP_SPLIT")) : 0;
+        const int sweep_split = split_env > 0 ? split_env : YN_SWEEP_SPLIT;
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, sweep_split), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
                            M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, wk.seg_sparse, 1, sweep_maxn);
     }
     mark("resolve_kernel");
