@@ -1833,89 +1833,205 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
 // band (0, ci) for every later chunk (the dense tile code, row words OR-ed over the kept rows), then an order-preserving compaction of
 // the survivors into a second candidate list.  matrix / resolve run on that list (chunk 0 is finished: its kept boxes are flagged here).
 // Segments of <= 64 boxes never reach the dense phase.  Exact: the kept sets equal the plain pipeline's (parity suite).
+// (nms_sweep_kernel's constants and box classes: its decision is taken at the end of the prefilter, the kernel itself follows below)
+#define YN_SWEEP_BINS 1024
+#define YN_SWEEP_MAXN 6144                                 // boxes (16 B) + the bin-sorted index (4 B) in LDS: 120 KB
+#define YN_SWEEP_IRR 64
+#define YN_SWEEP_WIDE 256                                  // listed wide boxes per workgroup (more: sixteen lanes each, as the narrow ones)
+#define YN_SWEEP_WIDE_VISITS 256                           // a box with more visits than this is wide
+#define YN_SWEEP_SPLIT 2                                   // workgroups per segment in the pairs phase (each bins the segment itself, then takes every second box): 1 / 2 / 4 / 8 / 16
+                                                           // measured 55 / 40 / 43 / 49 / 57 us at 416 x 416 bs 32 (every workgroup repeats the 13 k-cycle binning; a launch of these 1 024-thread,
+                                                           // 60-120 KB workgroups costs ~15 us whatever it does)
+struct SweepBins {                                          // the bin of an x coordinate: monotone in x (one rounding per step, each monotone), clamped
+    float xlo, scale;
+    __device__ __forceinline__ SweepBins(unsigned lo_u, unsigned hi_u)      // the x-range as ordered bits (order_bits)
+    {
+        xlo = __uint_as_float((lo_u & 0x80000000u) ? (lo_u & 0x7fffffffu) : ~lo_u);
+        const float xhi = __uint_as_float((hi_u & 0x80000000u) ? (hi_u & 0x7fffffffu) : ~hi_u);
+        scale = (xhi > xlo) ? (float)YN_SWEEP_BINS / (xhi - xlo) : 0.0f;
+    }
+    __device__ __forceinline__ int of(float x) const
+    {
+        const float f = (x - xlo) * scale;
+        int q = (int)f;
+        q = f >= (float)YN_SWEEP_BINS ? YN_SWEEP_BINS - 1 : q;
+        return q < 0 ? 0 : q;
+    }
+};
+__device__ __forceinline__ bool sweep_regular(const float4 b)
+{
+    const float w = b.z - b.x, a = w * (b.w - b.y);
+    return (b.x - b.x == 0.0f) && (b.y - b.y == 0.0f) && (b.z - b.z == 0.0f) && (b.w - b.w == 0.0f) && w > 1e-20f && a >= 1e-20f && a < 3.0e38f;
+}
 #define YN_PRE_W 8                                         // wavefronts per prefilter workgroup
-// A LARGE segment (more than 1 024 boxes) is one workgroup's work for 40-60 us - 38-85 band tiles on half a CU, ~5 us per round of eight, while
-// the other 2 500 workgroups of the launch are done after 25 us (measured with s_memrealtime stamps, round 6).  Its band is SLICED over YN_PRE_Z
-// workgroups instead: each resolves chunk 0 for itself (the same tile, the same serial walk: identical kept masks), takes every YN_PRE_Z-th
-// round of band tiles and leaves its survivor words in global memory (agent-scope stores, fence, one ticket per workgroup); the workgroup that
+// A LARGE segment (more than 1 024 boxes) was one workgroup's work for 40-60 us - 38-85 band tiles on half a CU, ~5 us per round of eight, while
+// the other 2 500 workgroups of the launch are done after 25 us (measured with s_memrealtime stamps, round 6).  Its band is SLICED over up to
+// YN_PRE_Z workgroups instead: each resolves chunk 0 for itself (the same tile, the same serial walk: identical kept masks), takes every ZS-th
+// round of band tiles and leaves its survivor words in global memory (write-through stores, one ticket per workgroup); the workgroup that
 // draws the last ticket reads all words back and compacts.  No workgroup waits for another.  Sliced: the first YN_PRE_RANKS segments of an
-// image in seg_order (by size - the only ones that can be large in practice; a fifth one stays on one workgroup), grid.y = C + RANKS * (Z - 1)
-// with the slices first.
+// image in seg_order (by size - the only ones that can be large in practice; a fifth one stays on one workgroup), grid.y = C + RANKS * YN_PRE_Z
+// with the slices first.  One MORE workgroup per sliced segment takes the sweep's decision (below) beside the band slices.
 #define YN_PRE_Z 8
 #define YN_PRE_RANKS 4
 #define YN_PRE_TICKETS 4096                                // pre_sync: [YN_PRE_TICKETS] ticket counters (image, rank) - a fixed region, zero between launches whatever B and N were -
-__host__ __device__ inline size_t pre_sync_words(int N) { return (size_t)(N / 64 + 2); }             // then per (image, rank) a survivor word per chunk
+__host__ __device__ inline size_t pre_sync_words(int N) { return (size_t)(N / 64 + 2); }             // then per (image, rank): word 0 = the sweep's decision, words 1 .. T - 1 = a survivor word per chunk
 struct PrefilterLds { u64 surv[YN_RESOLVE_MAX_T]; int base[YN_RESOLVE_MAX_T]; u64 keepm; int last; __attribute__((aligned(8))) unsigned char dpart[64][YN_PRE_W]; int part[64 * YN_PRE_W]; float4 cbox[YN_PRE_W][64]; float carea[YN_PRE_W][64]; };
+
+// The sweep's DECISION for a large segment (a launch of its own at first - 22 us of 1 024-thread workgroups -, then the tail of the compacting
+// workgroup - 16 us on the launch's critical path; now a workgroup of its own beside the band slices): would nms_sweep_kernel visit at most a
+// quarter of the n^2 / 2 pairs?  Bins of the left edges counted in LDS (the compaction's arrays), a visit count from their prefix sums; not more
+// than YN_SWEEP_IRR irregular boxes - the classifier and the bin map are nms_sweep_kernel's own.  Taken on the segment's boxes BEFORE the
+// prefilter (chunks >= 1): the survivors are a subset - fewer irregular boxes, fewer visits -, and either answer is correct (it only chooses
+// between two exact ways to the same suppression words).  Every thread of the workgroup calls it; block-uniform result.
+__device__ bool sweep_spread_out(const float4* __restrict__ sb, int n, PrefilterLds& L)
+{
+    constexpr int NTH = 64 * YN_PRE_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* hist = L.base;                                                  // [YN_SWEEP_BINS + 1]
+    unsigned* sc = reinterpret_cast<unsigned*>(L.part);                  // [0] min left edge, [1] max right edge (ordered bits), [2] irregular boxes
+    for (int i = tid; i < YN_SWEEP_BINS + 1; i += NTH) hist[i] = 0;
+    if (tid == 0) { sc[0] = 0xffffffffu; sc[1] = 0u; sc[2] = 0u; L.keepm = 0ull; }
+    __syncthreads();
+    constexpr int PER = (YN_SWEEP_MAXN + NTH - 1) / NTH;                 // boxes per thread: up to 12 at 6 144
+    if (n - 64 > PER * NTH) return false;
+    {
+        unsigned mn = 0xffffffffu, mx = 0u, irr = 0u;
+        for (int i = 64 + tid; i < n; i += NTH) {
+            const float4 bx = sb[i];
+            if (sweep_regular(bx)) { mn = min(mn, order_bits(bx.x)); mx = max(mx, order_bits(bx.z)); }
+            else ++irr;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { mn = min(mn, (unsigned)__shfl_xor((int)mn, o)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); irr += (unsigned)__shfl_xor((int)irr, o); }
+        if (lane == 0) { atomicMin(&sc[0], mn); atomicMax(&sc[1], mx); if (irr) atomicAdd(&sc[2], irr); }
+    }
+    __syncthreads();
+    const int nirr = (int)sc[2];
+    if (nirr > YN_SWEEP_IRR) return false;
+    const SweepBins bins(sc[0], sc[1]);
+    unsigned qq[PER];                                                    // a thread's boxes: first bin | last bin << 10 | regular << 31 (the counts and the visit sum below read these)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = 64 + tid + u * NTH;
+        qq[u] = 0u;
+        if (i < n) {
+            const float4 bx = sb[i];
+            if (sweep_regular(bx)) { const int q0 = bins.of(bx.x); qq[u] = (unsigned)q0 | ((unsigned)bins.of(bx.z) << 10) | 0x80000000u; atomicAdd(&hist[q0], 1); }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                                                     // exclusive prefix: hist[q] = boxes left of bin q, hist[BINS] = all regular ones
+        int mine = 0;
+        for (int q = 0; q < YN_SWEEP_BINS / 64; ++q) mine += hist[lane * (YN_SWEEP_BINS / 64) + q];
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int run = incl - mine;
+        for (int q = 0; q < YN_SWEEP_BINS / 64; ++q) { const int k = lane * (YN_SWEEP_BINS / 64) + q; const int cnt = hist[k]; hist[k] = run; run += cnt; }
+        if (lane == 63) hist[YN_SWEEP_BINS] = run;
+    }
+    __syncthreads();
+    {
+        unsigned long long w = (unsigned long long)(tid < nirr ? n : 0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) if (qq[u] >> 31) w += (unsigned long long)(hist[((qq[u] >> 10) & 1023u) + 1] - hist[qq[u] & 1023u]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)(w & 0xffffffffull), o), h2 = (unsigned)__shfl_xor((int)(unsigned)(w >> 32), o);
+            w += ((unsigned long long)h2 << 32) | l2;
+        }
+        if (lane == 0) atomicAdd(&L.keepm, w);
+    }
+    __syncthreads();
+    const int m = n - 64;
+    return L.keepm <= (unsigned long long)m * (unsigned long long)(m - 1) / 8ull;
+}
 
 __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count,
                                                              const int32_t* __restrict__ seg_off, const int32_t* __restrict__ bucket,
                                                              int N, int C, float thresh, int32_t* __restrict__ keep,
                                                              float4* __restrict__ sbox2, int32_t* __restrict__ bucket2, int32_t* __restrict__ seg_count2,
                                                              const int32_t* __restrict__ seg_order, int32_t* __restrict__ seg_sparse,
-                                                             u64* __restrict__ pre_sync, int sliced_ranks)
+                                                             u64* __restrict__ pre_sync, int sliced_ranks,
+                                                             const int32_t* __restrict__ large_list, int large_cap, int sweep_slots, int sweep_maxn)
 {
     __shared__ PrefilterLds L;
     // grid (B, C + ...): workgroups start in id order, x fastest - every image's LARGEST segment first (seg_order), then the second largest ...:
     // the few 2 000-box segments of a batch, whose workgroups run 10x longer than the rest, no longer start behind 2 000 short ones
+    constexpr int NTH = 64 * YN_PRE_W;
     const int b = blockIdx.x;
     int rank = blockIdx.y, z = 0;
-    if ((int)blockIdx.y < sliced_ranks * YN_PRE_Z) { rank = blockIdx.y / YN_PRE_Z; z = blockIdx.y % YN_PRE_Z; }
-    else rank = blockIdx.y - sliced_ranks * (YN_PRE_Z - 1);
+    if ((int)blockIdx.y < sliced_ranks * (YN_PRE_Z + 1)) { rank = blockIdx.y / (YN_PRE_Z + 1); z = blockIdx.y % (YN_PRE_Z + 1); }
+    else rank = blockIdx.y - sliced_ranks * YN_PRE_Z;
     const int c = seg_order ? seg_order[(size_t)b * C + rank] : rank;
     const int n = seg_count[(size_t)b * C + c];
     const int T = (n + 63) >> 6;
     const bool sliced = rank < sliced_ranks && T - 1 > YN_PRE_W;               // more than one round of band tiles: a round per slice
     const int ZS = sliced ? min(YN_PRE_Z, (T - 1 + YN_PRE_W - 1) / YN_PRE_W) : 1;
-    if (z >= ZS) return;
-    if (seg_sparse && threadIdx.x == 0 && z == 0) seg_sparse[(size_t)b * C + c] = 0;       // (nms_sweep_kernel's decide phase marks the segments it takes)
-    if (n == 0) { if (threadIdx.x == 0) seg_count2[(size_t)b * C + c] = 0; return; }
+    // the sweep's decision: for a sliced segment above 1 024 boxes among the image's first `sweep_slots` listed ones (the sweep's workgroups)
+    bool decide = false;
+    if (sliced && seg_sparse && sweep_slots > 0 && large_list && nms_colmajor(n)) {
+        const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
+        const int nl = ll[0] < sweep_slots ? ll[0] : sweep_slots;
+        for (int k = 0; k < nl; ++k) decide |= ll[1 + k] == c;
+    }
+    const bool decider = decide && z == ZS;                                     // (one workgroup behind the band slices)
+    if (z >= ZS && !decider) return;
+    // (seg_count2 / seg_sparse of a segment: written by ONE workgroup - the one that compacts it.  Two workgroups' plain stores to one word sit in two
+    // XCDs' L2s, and which is written back last is anybody's guess: an early `seg_sparse = 0` by slice 0 lost or won against the compacting
+    // workgroup's 1 from run to run)
+    if (n == 0) { if (threadIdx.x == 0) { seg_count2[(size_t)b * C + c] = 0; if (seg_sparse) seg_sparse[(size_t)b * C + c] = 0; } return; }
     const int off = seg_off[(size_t)b * C + c];
     const float4* sb = sbox + (size_t)b * N + off;
     const int32_t* ids = bucket + (size_t)b * N + off;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    float4* cbox = L.cbox[wave];
-    float* carea = L.carea[wave];
-    // chunk 0 among itself.  Its 64 x 64 tile eight columns per wavefront, the row words put together through LDS (one wavefront on the whole tile:
-    // ~4.5 us, the life of the ~2 000 one-chunk workgroups of a batch and the head of every large segment's critical path); then the reference's
-    // loop restricted to 64 boxes, wave 0
-    float4 bx0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < n) bx0 = sb[lane];
-    {
-        u64 part = 0;
-        if (wave * 8 < n) part = tile_word_boxes<false>(bx0, bx0, n, 0, 0, thresh, cbox, carea, wave * 8, wave * 8 + 8);
-        L.dpart[lane][wave] = (unsigned char)(part >> (8 * wave));
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const u64 diag = *reinterpret_cast<const u64*>(L.dpart[lane]);
-        const int cnt = min(64, n);
-        u64 alive = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
-        u64 work = __ballot(((alive >> lane) & 1ull) && (diag & alive));
-        const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
-        while (work) {
-            const int i = __ffsll((long long)work) - 1;                                  // alive at its turn: kept
-            const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
-            const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
-            alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
-            work &= alive & ~(1ull << i);
+    const size_t slot = (size_t)b * YN_PRE_RANKS + (rank < YN_PRE_RANKS ? rank : 0);
+    u64* ticket = pre_sync + slot;
+    u64* gs = pre_sync + YN_PRE_TICKETS + slot * pre_sync_words(N);
+    if (decider) {
+        const bool sp = sweep_spread_out(sb, n, L);
+        if (tid == 0) __hip_atomic_store(&gs[0], sp ? 1ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        float4* cbox = L.cbox[wave];
+        float* carea = L.carea[wave];
+        // chunk 0 among itself.  Its 64 x 64 tile eight columns per wavefront, the row words put together through LDS (one wavefront on the whole tile:
+        // ~4.5 us, the life of the ~2 000 one-chunk workgroups of a batch and the head of every large segment's critical path); then the reference's
+        // loop restricted to 64 boxes, wave 0
+        float4 bx0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < n) bx0 = sb[lane];
+        {
+            u64 part = 0;
+            if (wave * 8 < n) part = tile_word_boxes<false>(bx0, bx0, n, 0, 0, thresh, cbox, carea, wave * 8, wave * 8 + 8);
+            L.dpart[lane][wave] = (unsigned char)(part >> (8 * wave));
         }
-        if (((alive >> lane) & 1ull) && z == 0) keep[(size_t)b * N + ids[lane]] = 1;
-        if (lane == 0) L.keepm = alive;
-    }
-    if (T == 1) {                                           // nothing beyond chunk 0: no band, no scan, no survivors (most segments of a batch)
-        if (tid == 0) seg_count2[(size_t)b * C + c] = 0;
-        return;
-    }
-    __syncthreads();
-    const u64 keepm = L.keepm;
-    {   // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes.  The row boxes are loaded once, the next tile's column
+        __syncthreads();
+        if (wave == 0) {
+            const u64 diag = *reinterpret_cast<const u64*>(L.dpart[lane]);
+            const int cnt = min(64, n);
+            u64 alive = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            u64 work = __ballot(((alive >> lane) & 1ull) && (diag & alive));
+            const unsigned dlo = (unsigned)(diag & 0xffffffffu), dhi = (unsigned)(diag >> 32);
+            while (work) {
+                const int i = __ffsll((long long)work) - 1;                                  // alive at its turn: kept
+                const unsigned lo_i = (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                const unsigned hi_i = (unsigned)__builtin_amdgcn_readlane((int)dhi, i);
+                alive &= ~(((u64)hi_i << 32) | (u64)lo_i);
+                work &= alive & ~(1ull << i);
+            }
+            if (((alive >> lane) & 1ull) && z == 0) keep[(size_t)b * N + ids[lane]] = 1;
+            if (lane == 0) L.keepm = alive;
+        }
+        if (T == 1) {                                           // nothing beyond chunk 0: no band, no scan, no survivors (most segments of a batch)
+            if (tid == 0) { seg_count2[(size_t)b * C + c] = 0; if (seg_sparse) seg_sparse[(size_t)b * C + c] = 0; }
+            return;
+        }
+        __syncthreads();
+        const u64 keepm = L.keepm;
+        // band (0, ci): which boxes of chunk ci survive chunk 0's kept boxes.  The row boxes are loaded once, the next tile's column
         // boxes are requested before the current tile is evaluated.
         const float4 bx = bx0;
         float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cbn = cb;
-        const size_t slot = (size_t)b * YN_PRE_RANKS + (rank < YN_PRE_RANKS ? rank : 0);
-        u64* ticket = pre_sync + slot;
-        u64* gs = pre_sync + YN_PRE_TICKETS + slot * pre_sync_words(N);
         int ci = 1 + z * YN_PRE_W + wave;
         if (ci < T && ci * 64 + lane < n) cb = sb[ci * 64 + lane];
         for (; ci < T; ci += YN_PRE_W * ZS) {
@@ -1933,25 +2049,26 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
             if (lane == 0) { if (sliced) __hip_atomic_store(&gs[ci], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else L.surv[ci] = sv; }
             cb = cbn;
         }
-        if (sliced) {
-            // every slice's words out, then its ticket; the last one in reads them all and goes on alone.  The hand-off of DESIGN 4.3d: write-through
-            // (agent-scope) stores, retired by the storing wavefront before the barrier, a relaxed ticket, agent-scope loads on the other side - no
-            // fence (an agent-scope release here writes the XCD's whole L2 back: 150 us for this launch, measured)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                const u64 t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                L.last = t == (u64)(ZS - 1);
-                if (L.last) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero between launches)
-            }
-            __syncthreads();
-            if (!L.last) return;
-            for (int k = 1 + tid; k < T; k += 64 * YN_PRE_W) L.surv[k] = __hip_atomic_load(&gs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool spread = false;
+    if (sliced) {
+        // every slice's words out, then its ticket; the last one in reads them all and goes on alone.  The hand-off of DESIGN 4.3d: write-through
+        // (agent-scope) stores, retired by the storing wavefront before the barrier, a relaxed ticket, agent-scope loads on the other side - no
+        // fence (an agent-scope release here writes the XCD's whole L2 back: 150 us for this launch, measured)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const u64 t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.last = t == (u64)(ZS + (decide ? 1 : 0) - 1);
+            if (L.last) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero between launches)
         }
+        __syncthreads();
+        if (!L.last) return;
+        for (int k = 1 + tid; k < T; k += NTH) L.surv[k] = __hip_atomic_load(&gs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (decide) spread = __hip_atomic_load(&gs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
     }
     __syncthreads();
     // order-preserving compaction: exclusive prefix of the chunks' survivor counts (thread = a run of Q chunks, then a block scan)
-    constexpr int NTH = 64 * YN_PRE_W;
     const int Q = (T - 1 + NTH - 1) / NTH;
     int mine = 0;
     for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) mine += __popcll(L.surv[ci]); }
@@ -1965,7 +2082,12 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
     }
     int run = L.part[tid] - mine;                           // exclusive
     for (int q = 0; q < Q; ++q) { const int ci = 1 + tid * Q + q; if (ci < T) { L.base[ci] = run; run += __popcll(L.surv[ci]); } }
-    if (tid == NTH - 1) seg_count2[(size_t)b * C + c] = L.part[NTH - 1];
+    const int n2 = L.part[NTH - 1];
+    if (tid == NTH - 1) {
+        seg_count2[(size_t)b * C + c] = n2;
+        // to nms_sweep_kernel: spread out, and a list of survivors that is still large and fits its LDS (else: the dense tiles, as every other segment)
+        if (seg_sparse) seg_sparse[(size_t)b * C + c] = (spread && nms_colmajor(n2) && n2 <= sweep_maxn) ? 1 : 0;
+    }
     __syncthreads();
     for (int ci = 1 + wave; ci < T; ci += YN_PRE_W) {
         const u64 m = L.surv[ci];
@@ -1993,26 +2115,12 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
 //   0/0 = NaN -> removed, wherever they are) are tested against every box of the segment.
 // The kernel first ESTIMATES the pairs it would visit (bin counts); a segment over a quarter of n^2 / 2, with more than 64 irregular boxes or
 // beyond the LDS copy (6 144 boxes) stays with matrix_kernel (seg_sparse = 0).  One 1 024-thread workgroup per listed segment.
-#define YN_SWEEP_BINS 1024
-#define YN_SWEEP_MAXN 6144                                 // boxes (16 B) + the bin-sorted index (4 B) in LDS: 120 KB
-#define YN_SWEEP_IRR 64
-#define YN_SWEEP_WIDE 256                                  // listed wide boxes per workgroup (more: sixteen lanes each, as the narrow ones)
-#define YN_SWEEP_WIDE_VISITS 256                           // a box with more visits than this is wide
-#define YN_SWEEP_SPLIT 2                                   // workgroups per segment in the pairs phase (each bins the segment itself, then takes every second box): 1 / 2 / 4 / 8 / 16
-                                                           // measured 55 / 40 / 43 / 49 / 57 us at 416 x 416 bs 32 (every workgroup repeats the 13 k-cycle binning; a launch of these 1 024-thread,
-                                                           // 60-120 KB workgroups costs ~15 us whatever it does)
-__device__ __forceinline__ bool sweep_regular(const float4 b)
-{
-    const float w = b.z - b.x, a = w * (b.w - b.y);
-    return (b.x - b.x == 0.0f) && (b.y - b.y == 0.0f) && (b.z - b.z == 0.0f) && (b.w - b.w == 0.0f) && w > 1e-20f && a >= 1e-20f && a < 3.0e38f;
-}
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                          const int32_t* __restrict__ tile_off, int N, int C, float thresh, u64* __restrict__ M, size_t m_stride,
-                                                         const int32_t* __restrict__ large_list, int large_cap, int32_t* __restrict__ seg_sparse, int phase, int maxn)
+                                                         const int32_t* __restrict__ large_list, int large_cap, const int32_t* __restrict__ seg_sparse, int maxn)
 {
-    // phase 0 (in front of nms_tile_off_kernel / matrix_kernel): DECIDE - bins + visit count -> seg_sparse (matrix_kernel then leaves the segment's
-    // tiles out of its work list and only zeroes them, chip-wide: one workgroup zeroing its own 300 KB took 100-140 k cycles, most of this kernel).
-    // phase 1 (behind matrix_kernel): the PAIRS of the marked segments - bins again (~10 k cycles), exact tests, atomic ORs into the zeroed tiles.
+    // Behind matrix_kernel, on the segments nms_prefilter_kernel has marked: matrix_kernel has left their tiles out of its work list and zeroed
+    // them chip-wide (one workgroup zeroing its own 300 KB took 100-140 k cycles); here: bins (~13 k cycles), exact tests, atomic ORs.
     extern __shared__ __attribute__((aligned(16))) float4 sw_box[];     // [n] the segment's boxes (score order), then [n] ints: box indices grouped by the bin of their left edge
     __shared__ int start[YN_SWEEP_BINS + 2];
     __shared__ int irr[YN_SWEEP_IRR];
@@ -2020,19 +2128,17 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
     __shared__ int n_wide;
     __shared__ unsigned xlo_u, xhi_u;
     __shared__ int n_irr;
-    __shared__ unsigned long long work;
     const int b = blockIdx.y;
     const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
     if ((int)blockIdx.x >= ll[0]) return;
     const int c = ll[1 + blockIdx.x];
     const int n = seg_count[(size_t)b * C + c];
-    if (!nms_colmajor(n) || n > maxn) return;                           // (seg_sparse stays 0: matrix_kernel's)
-    if (phase == 1 && !seg_sparse[(size_t)b * C + c]) return;
+    if (!nms_colmajor(n) || n > maxn || !seg_sparse[(size_t)b * C + c]) return;
     const float4* sb = sbox + (size_t)b * N + seg_off[(size_t)b * C + c];
     int* sw_order = reinterpret_cast<int*>(sw_box + n);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < YN_SWEEP_BINS + 2; i += 1024) start[i] = 0;
-    if (tid == 0) { xlo_u = 0xffffffffu; xhi_u = 0u; n_irr = 0; n_wide = 0; work = 0ull; }
+    if (tid == 0) { xlo_u = 0xffffffffu; xhi_u = 0u; n_irr = 0; n_wide = 0; }
     __syncthreads();
     // the boxes into LDS (every later pass and every pair test reads them there); the x-range of the regular ones (ordered-uint min / max), the irregular ones listed
     {
@@ -2048,18 +2154,9 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
         if (lane == 0) { atomicMin(&xlo_u, mn); atomicMax(&xhi_u, mx); }
     }
     __syncthreads();
-    const int nirr = n_irr;
-    if (nirr > YN_SWEEP_IRR) return;
-    const unsigned lo_u = xlo_u, hi_u = xhi_u;
-    const float xlo = __uint_as_float((lo_u & 0x80000000u) ? (lo_u & 0x7fffffffu) : ~lo_u);
-    const float xhi = __uint_as_float((hi_u & 0x80000000u) ? (hi_u & 0x7fffffffu) : ~hi_u);
-    const float scale = (xhi > xlo) ? (float)YN_SWEEP_BINS / (xhi - xlo) : 0.0f;
-    auto bin_of = [&](float x) {                                         // monotone in x (one rounding per step, each monotone), clamped
-        const float f = (x - xlo) * scale;
-        int q = (int)f;
-        q = f >= (float)YN_SWEEP_BINS ? YN_SWEEP_BINS - 1 : q;
-        return q < 0 ? 0 : q;
-    };
+    const int nirr = n_irr;                                             // (<= YN_SWEEP_IRR: counted with the same classifier where the segment was marked)
+    const SweepBins bins(xlo_u, xhi_u);
+    auto bin_of = [&](float x) { return bins.of(x); };
     for (int i = tid; i < n; i += 1024) {
         const float4 bx = sw_box[i];
         if (sweep_regular(bx)) atomicAdd(&start[bin_of(bx.x) + 2], 1);  // counts, two slots up
@@ -2081,28 +2178,6 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
         if (sweep_regular(bx)) sw_order[atomicAdd(&start[bin_of(bx.x) + 2], 1)] = i;
     }
     __syncthreads();
-    {   // the visit count of the sweep
-        unsigned long long w = 0;
-        for (int i = tid; i < n; i += 1024) {
-            const float4 bx = sw_box[i];
-            if (sweep_regular(bx)) w += (unsigned long long)(start[bin_of(bx.z) + 2] - start[bin_of(bx.x) + 1]);
-        }
-        w += (unsigned long long)(tid < nirr ? n : 0);
-        unsigned lo = (unsigned)(w & 0xffffffffull), hi = (unsigned)(w >> 32);      // (a thread's share is far below 2^32: the halves add without carries across 64 lanes... summed as 64-bit below)
-        unsigned long long ws = w;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned l2 = (unsigned)__shfl_xor((int)(unsigned)(ws & 0xffffffffull), o), h2 = (unsigned)__shfl_xor((int)(unsigned)(ws >> 32), o);
-            ws += ((unsigned long long)h2 << 32) | l2;
-        }
-        (void)lo; (void)hi;
-        if (lane == 0) atomicAdd(&work, ws);
-    }
-    __syncthreads();
-    if (phase == 0) {
-        if (tid == 0 && work <= (unsigned long long)n * (unsigned long long)(n - 1) / 8ull) seg_sparse[(size_t)b * C + c] = 1;     // else: not spread out enough - the dense tiles
-        return;
-    }
     u64* Ms = M + (size_t)b * m_stride + (size_t)tile_off[(size_t)b * (C + 1) + c] * 64;      // (zeroed by matrix_kernel)
     // the pair test: matrix_kernel's division-free decision first (tile_word_boxes: inter against thr * union with a 1e-5 guard band - ~25 instructions;
     // `suppressed` inlined whole is ~100, and this loop is VALU-bound: 16 wavefronts on four SIMDs), the exact predicate only inside the band / for
@@ -2177,21 +2252,34 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
 
 // tile offsets of the prefiltered segments (one thread per image: C is small): tile_off2 = where a segment's tiles are STORED (every segment),
 // work_off = the same prefix over the segments matrix_kernel evaluates (all but the ones nms_sweep_kernel has marked)
-__global__ void nms_tile_off_kernel(const int32_t* __restrict__ seg_count2, int C, int32_t* __restrict__ tile_off2, const int32_t* __restrict__ seg_sparse,
-                                    int32_t* __restrict__ work_off)
+__global__ __launch_bounds__(64) void nms_tile_off_kernel(const int32_t* __restrict__ seg_count2, int C, int32_t* __restrict__ tile_off2, const int32_t* __restrict__ seg_sparse,
+                                                          int32_t* __restrict__ work_off)
 {
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    // one wavefront per image, a class per lane, a wave scan (one thread walking the 80 classes: 6.5 us of dependent loads)
+    const int b = blockIdx.x, lane = threadIdx.x;
     int tiles = 0, wtiles = 0;
-    for (int c = 0; c < C; ++c) {
-        tile_off2[(size_t)b * (C + 1) + c] = tiles;
-        if (work_off) work_off[(size_t)b * (C + 1) + c] = wtiles;
-        const int T = (seg_count2[(size_t)b * C + c] + 63) >> 6;
-        tiles += T * (T + 1) / 2;
-        if (!(seg_sparse && seg_sparse[(size_t)b * C + c])) wtiles += T * (T + 1) / 2;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        int t = 0, w = 0;
+        if (c < C) {
+            const int T = (seg_count2[(size_t)b * C + c] + 63) >> 6;
+            t = T * (T + 1) / 2;
+            w = (seg_sparse && seg_sparse[(size_t)b * C + c]) ? 0 : t;
+        }
+        int ti = t, wi = w;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(ti, o), d = __shfl_up(wi, o); if (lane >= o) { ti += a; wi += d; } }
+        if (c < C) {
+            tile_off2[(size_t)b * (C + 1) + c] = tiles + ti - t;
+            if (work_off) work_off[(size_t)b * (C + 1) + c] = wtiles + wi - w;
+        }
+        tiles += __shfl(ti, 63);
+        wtiles += __shfl(wi, 63);
     }
-    tile_off2[(size_t)b * (C + 1) + C] = tiles;
-    if (work_off) work_off[(size_t)b * (C + 1) + C] = wtiles;
+    if (lane == 0) {
+        tile_off2[(size_t)b * (C + 1) + C] = tiles;
+        if (work_off) work_off[(size_t)b * (C + 1) + C] = wtiles;
+    }
 }
 
 // ---- single-class entry (YOLONano.nms): one segment = items 0..n-1 ------------------------------------
@@ -2445,25 +2533,20 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     // (small batches: the prefilter is two more launches in a serial chain - bs = 1 latency 0.69 -> 0.72 ms - for chip time nobody else wants)
     if (!diou && wk.sbox2 && (prefilter_env == 2 || (prefilter_env == 1 && B >= 4))) {
         mark("nms_prefilter_kernel");
-        const int pre_ranks = (seg_order && wk.pre_sync && (size_t)B * YN_PRE_RANKS <= YN_PRE_TICKETS) ? (C < YN_PRE_RANKS ? C : YN_PRE_RANKS) : 0;      // large segments: band sliced over YN_PRE_Z workgroups
-        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C + pre_ranks * (YN_PRE_Z - 1)), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
-                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order, wk.seg_sparse, reinterpret_cast<u64*>(wk.pre_sync), pre_ranks);
-        m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
         // large segments whose boxes are spread out: their suppression words from a sweep over bins of the left edges instead of the dense tiles
-        // (nms_sweep_kernel): decided here, zeroed by matrix_kernel, filled in behind it
-        sweep = wk.sweep && !few && wk.seg_sparse && wk.work_off && wk.large_list && large_cap > 0 && N > YN_SORT_SMALL && nms_thresh >= 1e-6f && !(skip & 2);
-        // its workgroups carry the segment in LDS (20 bytes per box): 60 KB - two per CU - for maps of up to 16 K candidates (a class above 3 072 boxes stays
+        // (nms_sweep_kernel): decided at the end of the prefilter, zeroed by matrix_kernel, filled in behind it.
+        // The sweep's workgroups carry the segment in LDS (20 bytes per box): 60 KB - two per CU - for maps of up to 16 K candidates (a class above 3 072 boxes stays
         // dense there), 120 KB beyond (608 x 608: ~5 000-box classes); the first four listed segments of an image only (the list is by size: a fifth class above
         // 1 024 boxes is rare, and every listed slot is a workgroup with that LDS to schedule whether it has work or not)
+        sweep = wk.sweep && !few && wk.seg_sparse && wk.work_off && wk.large_list && large_cap > 0 && N > YN_SORT_SMALL && nms_thresh >= 1e-6f && !(skip & 2);
         sweep_maxn = N <= 16384 ? YN_SWEEP_MAXN / 2 : YN_SWEEP_MAXN;
         sweep_slots = large_cap < 4 ? large_cap : 4;
-        if (sweep) {
-            static unsigned long long attr_sw = 0;
-            if (attr_pending(attr_sw)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SWEEP_MAXN * 20);
-            mark("nms_sweep_kernel");
-            hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
-                               M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, wk.seg_sparse, 0, sweep_maxn);
-        }
+        const int pre_ranks = (seg_order && wk.pre_sync && (size_t)B * YN_PRE_RANKS <= YN_PRE_TICKETS) ? (C < YN_PRE_RANKS ? C : YN_PRE_RANKS) : 0;      // large segments: band sliced over YN_PRE_Z workgroups
+        hipLaunchKernelGGL(nms_prefilter_kernel, dim3(B, C + pre_ranks * YN_PRE_Z), dim3(64 * YN_PRE_W), 0, s, sbox, wk.seg_count, wk.seg_off, wk.bucket, N, C, nms_thresh, wk.keep,
+                           reinterpret_cast<float4*>(wk.sbox2), wk.bucket2, wk.seg_count2, seg_order, wk.seg_sparse, reinterpret_cast<u64*>(wk.pre_sync), pre_ranks,
+                           (const int32_t*)wk.large_list, large_cap, sweep ? sweep_slots : 0, sweep_maxn);
+        m_count = wk.seg_count2; m_toff = wk.tile_off2; m_ids = wk.bucket2; m_box = reinterpret_cast<const float4*>(wk.sbox2);
+        mark("nms_tile_off_kernel");
         hipLaunchKernelGGL(nms_tile_off_kernel, dim3(B), dim3(64), 0, s, wk.seg_count2, C, wk.tile_off2, (const int32_t*)(sweep ? wk.seg_sparse : nullptr), sweep ? wk.work_off : nullptr);
     }
     int G = 4096 / (B > 0 ? B : 1);                         // x4 wavefronts per block
@@ -2479,8 +2562,10 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
         mark("nms_sweep_kernel");
         static const int split_env = getenv("YN_EXP_SWEEP_SPLIT") ? atoi(getenv("YN_EXP_SWEEP_SPLIT")) : 0;
         const int sweep_split = split_env > 0 ? split_env : YN_SWEEP_SPLIT;
+        static unsigned long long attr_sw = 0;
+        if (attr_pending(attr_sw)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SWEEP_MAXN * 20);
         hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, sweep_split), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
-                           M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, wk.seg_sparse, 1, sweep_maxn);
+                           M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, (const int32_t*)wk.seg_sparse, sweep_maxn);
     }
     mark("resolve_kernel");
     const bool split = N > YN_SORT_SMALL && wk.large_list && large_cap > 0;
