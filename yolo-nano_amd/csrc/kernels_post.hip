@@ -2113,8 +2113,9 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
 //   box is irregular); p = thr * un >= 1e-6 * 0.99 * 1e-20 > 1e-30 and inter < 0.99999 p (thr >= 1e-6, launch condition): suppressed() returns false
 //   through its first early-out, exactly as it would in a dense tile.  IRREGULAR boxes (zero / negative / NaN extents: two zero-area boxes give
 //   0/0 = NaN -> removed, wherever they are) are tested against every box of the segment.
-// The kernel first ESTIMATES the pairs it would visit (bin counts); a segment over a quarter of n^2 / 2, with more than 64 irregular boxes or
-// beyond the LDS copy (6 144 boxes) stays with matrix_kernel (seg_sparse = 0).  One 1 024-thread workgroup per listed segment.
+// WHICH segments: nms_prefilter_kernel estimates the pairs the sweep would visit (sweep_spread_out: bin counts); a segment over a quarter of
+// n^2 / 2, with more than 64 irregular boxes or beyond the LDS copy (6 144 boxes) stays with matrix_kernel (seg_sparse = 0).
+// YN_SWEEP_SPLIT 1 024-thread workgroups per marked segment.
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                          const int32_t* __restrict__ tile_off, int N, int C, float thresh, u64* __restrict__ M, size_t m_stride,
                                                          const int32_t* __restrict__ large_list, int large_cap, const int32_t* __restrict__ seg_sparse, int maxn)
@@ -2560,8 +2561,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                                  (const int32_t*)(sweep ? wk.work_off : nullptr), (const int32_t*)(sweep ? wk.seg_sparse : nullptr), (const int32_t*)wk.large_list, large_cap);
     if (sweep) {
         mark("nms_sweep_kernel");
-        static const int split_env = getenv("YN_EXP_SWEEP_SPLIT") ? atoi(getenv("YN_EXP_SWEEP_SPLIT")) : 0;
-        const int sweep_split = split_env > 0 ? split_env : YN_SWEEP_SPLIT;
+        const int sweep_split = YN_SWEEP_SPLIT;
         static unsigned long long attr_sw = 0;
         if (attr_pending(attr_sw)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SWEEP_MAXN * 20);
         hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, sweep_split), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
