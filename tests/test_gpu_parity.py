@@ -1051,6 +1051,60 @@ def test_postprocess_large_classes_many_segments(hvoc):
         assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
 
 
+@pytest.mark.parametrize("C,sizes_list", [
+    (70, [{0: 577, 1: 576, 2: 640, 3: 641, 4: 575, 5: 65, 6: 64, 7: 63},            # T - 1 = 8 / 9 band tiles: the first sliced size and its neighbours
+          {0: 1088, 1: 1089, 2: 1024, 3: 1025, 4: 513, 5: 129},                     # 16 / 17 tiles (two / three slices), the large-segment threshold
+          {0: 1153, 1: 1601, 2: 2113, 3: 4200, 4: 600},                              # 3, 4, 5, 8 slices (the last one with several rounds each); a fifth sliceable class on one workgroup
+          {0: 3000, 1: 3000, 2: 3000, 3: 600}]),                                     # equal sizes at the top
+    (3, [{0: 1500, 1: 1000, 2: 500}, {0: 700, 1: 650, 2: 600}]),                     # fewer classes than sliced ranks
+])
+def test_prefilter_slices_boundaries_bit_exact(hvoc, C, sizes_list):
+    """Round 6: nms_prefilter_kernel slices the band of a segment with more than one round of tiles over up to eight workgroups (tickets, survivor
+    words through global memory, the last one in compacts) and takes the sweep's decision in one more.  Segment sizes on every boundary of
+    that scheme, clustered boxes (the prefilter removes most of them) next to spread-out ones (the sweep takes them), in batches of more than
+    256 segments: kept sets against the oracle, bit for bit, twice (the tickets must be back at zero)."""
+    rs = np.random.RandomState(5 + C)
+    N = 12000 if C > 3 else 3000
+    def image(sizes, k):
+        cls = np.concatenate([np.full(n, c) for c, n in sizes.items()] + ([rs.randint(10, C, N - sum(sizes.values()))] if C > 10 else [])).astype(np.int64)
+        cls = np.concatenate([cls, np.full(N - len(cls), -1)]) if len(cls) < N else cls
+        boxes = np.zeros((N, 4), np.float32)
+        for c in set(sizes):
+            m = np.where(cls == c)[0]
+            if (c + k) % 2 == 0:                                     # clustered: 40 centres, boxes of similar size around them
+                ctr = rs.uniform(0.1, 0.9, (40, 2))[rs.randint(0, 40, len(m))] + rs.normal(0, 0.01, (len(m), 2)); wh = rs.uniform(0.05, 0.08, (len(m), 2))
+            else:                                                    # spread out: small boxes everywhere
+                ctr = rs.uniform(0.02, 0.98, (len(m), 2)); wh = rs.uniform(0.002, 0.01, (len(m), 2))
+            boxes[m] = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        m = np.where((cls >= 10) | (cls < 0))[0]
+        ctr = rs.uniform(0.05, 0.95, (len(m), 2)); wh = rs.uniform(0.02, 0.09, (len(m), 2))
+        boxes[m] = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        boxes = np.clip(boxes, 0, 1).astype(np.float32)
+        conf = np.zeros((N, C), np.float32)
+        ok = cls >= 0
+        conf[np.arange(N)[ok], cls[ok]] = (rs.permutation(N).astype(np.float32) / N * 0.98 + 0.01)[ok]
+        perm = rs.permutation(N)
+        return boxes[perm], conf[perm]
+    imgs = [image(sz, k) for k, sz in enumerate(sizes_list)]
+    B = 4 * len(imgs) if C > 3 else 100                                              # 1 120 / 300 segments
+    boxes = np.stack([imgs[i % len(imgs)][0] for i in range(B)])
+    conf = np.stack([imgs[i % len(imgs)][1] for i in range(B)])
+    hvoc.set_thresholds(0.001, 0.5)
+    refs = [orc.postprocess(bb, cc, 0.001, 0.5) for bb, cc in imgs]
+    bx, cf = dev(boxes), dev(conf)
+    for rep in range(2):
+        out = hvoc.postprocess(bx, cf)
+        counts = out[4].cpu().tolist()
+        if C > 3:
+            assert hvoc.nms_sweep_segments(B, C) >= 8                # (the decision workgroups ran: the spread-out 1 601- and 4 200-box classes of the third image, four copies)
+        for bi in range(B):
+            rb, rs_, rc = refs[bi % len(imgs)]
+            k = counts[bi]
+            assert k == len(rs_), (rep, bi, k, len(rs_))
+            assert np.array_equal(out[0][bi, :k].cpu().numpy(), rb) and np.array_equal(out[1][bi, :k].cpu().numpy(), rs_)
+            assert np.array_equal(out[2][bi, :k].cpu().numpy().astype(np.int64), rc)
+
+
 def test_pack_detections(hcoco):
     """yn_pack_detections: the whole batch's kept rows as one record list + offsets == the per-image outputs."""
     hcoco.set_grid(416)
