@@ -1812,8 +1812,11 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
                                                              const int32_t* __restrict__ large_list, int large_cap, int n_min)
 {
     __shared__ ResolveLds L;
-    const int b = blockIdx.y;
-    int c = blockIdx.x;                                     // large_list == null: every segment (few segments: one launch for all of them)
+    // large_list == null: grid (C, B), every segment (few segments: one launch for all of them).  With the list: grid (B, slots) - the image fastest:
+    // workgroups go to the XCDs round robin by linear id, and a slot count that is a multiple of eight in x would put an image's few long walks
+    // (slots 0 - 2) on the same three XCDs for every image (nms_sweep_kernel's grid did exactly that, round 6)
+    const int b = large_list ? blockIdx.x : blockIdx.y;
+    int c = large_list ? blockIdx.y : blockIdx.x;
     if (large_list) {
         const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
         if (c >= ll[0]) return;
@@ -1839,9 +1842,7 @@ __global__ __launch_bounds__(512) void resolve_large_kernel(const int32_t* __res
 #define YN_SWEEP_IRR 64
 #define YN_SWEEP_WIDE 256                                  // listed wide boxes per workgroup (more: sixteen lanes each, as the narrow ones)
 #define YN_SWEEP_WIDE_VISITS 256                           // a box with more visits than this is wide
-#define YN_SWEEP_SPLIT 2                                   // workgroups per segment in the pairs phase (each bins the segment itself, then takes every second box): 1 / 2 / 4 / 8 / 16
-                                                           // measured 55 / 40 / 43 / 49 / 57 us at 416 x 416 bs 32 (every workgroup repeats the 13 k-cycle binning; a launch of these 1 024-thread,
-                                                           // 60-120 KB workgroups costs ~15 us whatever it does)
+// (workgroups per segment in the pairs phase - each bins the segment itself, then takes every KZ-th box: chosen at launch, launch_nms_pipeline)
 struct SweepBins {                                          // the bin of an x coordinate: monotone in x (one rounding per step, each monotone), clamped
     float xlo, scale;
     __device__ __forceinline__ SweepBins(unsigned lo_u, unsigned hi_u)      // the x-range as ordered bits (order_bits)
@@ -2115,7 +2116,7 @@ __global__ __launch_bounds__(64 * YN_PRE_W, 8) void nms_prefilter_kernel(const f
 //   0/0 = NaN -> removed, wherever they are) are tested against every box of the segment.
 // WHICH segments: nms_prefilter_kernel estimates the pairs the sweep would visit (sweep_spread_out: bin counts); a segment over a quarter of
 // n^2 / 2, with more than 64 irregular boxes or beyond the LDS copy (6 144 boxes) stays with matrix_kernel (seg_sparse = 0).
-// YN_SWEEP_SPLIT 1 024-thread workgroups per marked segment.
+// Two to eight 1 024-thread workgroups per marked segment (launch_nms_pipeline).
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ seg_count, const int32_t* __restrict__ seg_off,
                                                          const int32_t* __restrict__ tile_off, int N, int C, float thresh, u64* __restrict__ M, size_t m_stride,
                                                          const int32_t* __restrict__ large_list, int large_cap, const int32_t* __restrict__ seg_sparse, int maxn)
@@ -2129,10 +2130,13 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
     __shared__ int n_wide;
     __shared__ unsigned xlo_u, xhi_u;
     __shared__ int n_irr;
-    const int b = blockIdx.y;
+    // grid (B, workgroups per segment, listed slots) - the IMAGE fastest: workgroups go to the XCDs round robin by their linear id, and with the slot
+    // in x (four of them, two with work) every workgroup that had anything to do landed on four of the eight XCDs - 128 at a time on a chip of 256 CUs
+    // whatever the split (start / end stamps of all workgroups, round 6)
+    const int b = blockIdx.x;
     const int32_t* ll = large_list + (size_t)b * (large_cap + 1);
-    if ((int)blockIdx.x >= ll[0]) return;
-    const int c = ll[1 + blockIdx.x];
+    if ((int)blockIdx.z >= ll[0]) return;
+    const int c = ll[1 + blockIdx.z];
     const int n = seg_count[(size_t)b * C + c];
     if (!nms_colmajor(n) || n > maxn || !seg_sparse[(size_t)b * C + c]) return;
     const float4* sb = sbox + (size_t)b * N + seg_off[(size_t)b * C + c];
@@ -2203,9 +2207,9 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float4* __restric
     // SIXTEEN lanes per box, over the boxes whose left edge lies in the bins its extent covers: from its OWN bin only the later ones (the earlier ones
     // find this box themselves), from later bins all (their own sweep starts at their bin: it never looks back).  A visit is ~100 instructions
     // (index, box, the exact test, the tile address of a hit), and a wavefront runs as long as its longest lane: a thread per box (first forms) left
-    // three lanes of four idle - 131 k cycles for 50 k visits.  The segment's boxes are dealt to YN_SWEEP_SPLIT workgroups (blockIdx.z; each has
+    // three lanes of four idle - 131 k cycles for 50 k visits.  The segment's boxes are dealt to the segment's workgroups (blockIdx.y; each has
     // binned the whole segment itself).
-    const int kz = blockIdx.z, KZ = gridDim.z;
+    const int kz = blockIdx.y, KZ = gridDim.y;
     const int grp = tid >> 4, gl = tid & 15;
     for (int i = kz + KZ * grp; i < n; i += 64 * KZ) {                    // (box i belongs to workgroup i % KZ)
         const float4 bi = sw_box[i];
@@ -2561,10 +2565,14 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
                                  (const int32_t*)(sweep ? wk.work_off : nullptr), (const int32_t*)(sweep ? wk.seg_sparse : nullptr), (const int32_t*)wk.large_list, large_cap);
     if (sweep) {
         mark("nms_sweep_kernel");
-        const int sweep_split = YN_SWEEP_SPLIT;
+        // workgroups per segment: about as many working ones (two marked segments per image, typically) as the chip holds - two per CU with the 60 KB
+        // form, one with the 120 KB form.  Measured (us; 416 bs 32 / 608 bs 32 / 0.5x bs 128 / 416 bs 8): 2 -> 32.8 / 122 / 29.1 / -, 4 -> 29.3 / 88.8 / 34.0 / 18.6,
+        // 8 -> 28.0 / 97.2 / 46.2 / 15.7 (every workgroup repeats the binning, ~13 k cycles)
+        int sweep_split = (sweep_maxn * 20 <= 64 * 1024 ? 256 : 128) / (B > 0 ? B : 1);
+        sweep_split = sweep_split < 2 ? 2 : (sweep_split > 8 ? 8 : sweep_split);
         static unsigned long long attr_sw = 0;
         if (attr_pending(attr_sw)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, YN_SWEEP_MAXN * 20);
-        hipLaunchKernelGGL(nms_sweep_kernel, dim3(sweep_slots, B, sweep_split), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(B, sweep_split, sweep_slots), dim3(1024), (size_t)sweep_maxn * 20, s, m_box, m_count, wk.seg_off, m_toff, N, C, nms_thresh,
                            M, wk.matrix_stride, (const int32_t*)wk.large_list, large_cap, (const int32_t*)wk.seg_sparse, sweep_maxn);
     }
     mark("resolve_kernel");
@@ -2577,7 +2585,7 @@ void launch_nms_pipeline(const float* boxes, const float* scores, const int32_t*
     } else if (!(skip & 4)) {
         hipLaunchKernelGGL(resolve_kernel, dim3(B, C), dim3(256), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride, wk.keep,
                            split ? YN_SORT_SMALL : 1 << 30, seg_order);
-        if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(large_cap, B), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
+        if (split) hipLaunchKernelGGL(resolve_large_kernel, dim3(B, large_cap), dim3(512), 0, s, m_count, wk.seg_off, m_toff, m_ids, N, C, M, wk.matrix_stride,
                                       wk.keep, (const int32_t*)wk.large_list, large_cap, YN_SORT_SMALL);
     }
     mark("compact_kernel");
